@@ -1,0 +1,119 @@
+"""ctypes binding of libeodiff.so (C ABI declared in include/eodiff.h).
+
+The library is the ONLY compute path of this package: there is no eager / CPU fallback.  If the
+shared object is missing or a call fails, an exception is raised -- nothing is silently rerouted.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeodiff.so")
+
+EOD_F32, EOD_F16 = 0, 1
+(OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
+ OP_POOL) = range(1, 11)
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", vp), ("x2", vp), ("w", vp), ("bias", vp), ("cbias", vp), ("res", vp), ("y", vp),
+                ("cbias_stride", i64), ("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("C0", i32), ("C1", i32),
+                ("Cout", i32), ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32), ("pad_tl", i32),
+                ("Ho", i32), ("Wo", i32), ("out_nchw_f32", i32), ("alpha", f32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("bias", vp), ("res", vp), ("c", vp), ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("sa0", i64), ("sa1", i64), ("sb0", i64), ("sb1", i64), ("sc0", i64), ("sc1", i64), ("dtype", i32),
+                ("M", i32), ("N", i32), ("K", i32), ("nb0", i32), ("nb1", i32), ("bias_mode", i32), ("c_f32", i32),
+                ("alpha", f32)]
+
+
+class TembDesc(C.Structure):
+    _fields_ = [("t", vp), ("freqs", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("label_emb", vp), ("y", vp),
+                ("wcat", vp), ("bcat", vp), ("h1", vp), ("emb", vp), ("out", vp), ("N", i32), ("D", i32), ("E", i32),
+                ("J", i32)]
+
+
+class SmallDesc(C.Structure):
+    _fields_ = [("p", vp * 6), ("l", i64 * 4), ("i", i32 * 10), ("f", f32 * 2)]
+
+
+class _OpU(C.Union):
+    _fields_ = [("conv", ConvDesc), ("gemm", GemmDesc), ("temb", TembDesc), ("small", SmallDesc)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("_pad", i32), ("u", _OpU)]
+
+
+# every symbol include/eodiff.h declares: (name, restype, argtypes)
+SYMBOLS = {
+    "eod_last_error": (C.c_char_p, []),
+    "eod_version": (i32, []),
+    "eod_struct_size": (i32, [i32]),
+    "eod_conv2d_igemm": (i32, [C.POINTER(ConvDesc), vp]),
+    "eod_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
+    "eod_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "eod_pack_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
+    "eod_nchw_to_nhwc": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "eod_nhwc_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
+    "eod_gn_partial": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
+    "eod_gn_finalize": (i32, [vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, i64, vp, vp]),
+    "eod_gn_apply": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
+    "eod_softmax_rows": (i32, [vp, i64, vp, i64, i32, i64, i32, vp]),
+    "eod_time_embed": (i32, [C.POINTER(TembDesc), vp]),
+    "eod_q_sample": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
+    "eod_repaint_mix": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
+    "eod_ddpm_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "eod_ddim_step": (i32, [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]),
+    "eod_randn_philox": (i32, [vp, i32, i64, C.c_uint64, i64, i32, i32, vp]),
+    "eod_program_run": (i32, [C.POINTER(Op), i32, vp]),
+    "eod_resample2x": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+class EodError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libeodiff.so once.  Raises if it is missing: the HIP extension is mandatory."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EodError(
+            f"libeodiff.so not found at {LIB_PATH}. Build it first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C eo_diffusion_amd/csrc). There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    for kind, st in ((1, ConvDesc), (2, GemmDesc), (3, TembDesc), (4, SmallDesc), (5, Op)):
+        if L.eod_struct_size(kind) != C.sizeof(st):
+            raise EodError(f"ABI mismatch: struct kind {kind}: C {L.eod_struct_size(kind)} vs ctypes {C.sizeof(st)}")
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().eod_last_error()
+        raise EodError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def dtype_id(torch_dtype):
+    import torch
+    if torch_dtype == torch.float16:
+        return EOD_F16
+    if torch_dtype == torch.float32:
+        return EOD_F32
+    raise EodError(f"unsupported storage dtype {torch_dtype}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,57 @@
+// Shared host/device helpers for libeodiff (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/eodiff.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+void eod_set_error(const char* fmt, ...);
+
+#define EOD_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            eod_set_error(__VA_ARGS__);   \
+            return EOD_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define EOD_CHECK_LAUNCH(what)                                                   \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            eod_set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+            return EOD_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline bool eod_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int eod_esize(int dtype) { return dtype == EOD_F16 ? 2 : 4; }
+
+template <typename T> struct dt;
+template <> struct dt<float> {
+    static constexpr int id = EOD_F32;
+    static constexpr int epc = 4;  // elements per 16-byte chunk
+};
+template <> struct dt<half_t> {
+    static constexpr int id = EOD_F16;
+    static constexpr int epc = 8;
+};
+
+// SiLU (nn.SiLU, unet_openai.py:314,330,338): precise form for the fp32 parity mode, fast form
+// (v_exp_f32 + v_rcp_f32) for the fp16 mode where the result is rounded to 11 bits anyway.
+template <bool FAST> __device__ __forceinline__ float silu_f(float v) {
+    if constexpr (FAST) {
+        return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    } else {
+        return v / (1.0f + expf(-v));
+    }
+}

@@ -1,0 +1,239 @@
+// Small HBM-bound helpers: weight packing, API-edge layout conversion, timestep-embedding MLP,
+// 2x resampling for resblock_updown.
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ T cvt(float v) { return (T)v; }
+
+// ---------------------------------------------------------------------------------------------
+// OIHW fp32 -> [tap][Cout][cin_pad] (zero padded input channels)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int taps, int cin_pad) {
+    const long long total = (long long)taps * Cout * cin_pad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin_pad);
+        const long long r = i / cin_pad;
+        const int co = (int)(r % Cout);
+        const int tap = (int)(r / Cout);
+        const float v = ci < Cin ? w[((long long)co * Cin + ci) * taps + tap] : 0.0f;
+        dst[i] = cvt<T>(v);
+    }
+}
+
+extern "C" int eod_pack_conv_weight(const float* w, void* dst, int dtype, int Cout, int Cin, int ksize, int cin_pad,
+                                    void* stream) {
+    EOD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && cin_pad >= Cin && (ksize == 1 || ksize == 3), "pack_conv_weight: bad args");
+    const int taps = ksize * ksize;
+    const long long total = (long long)taps * Cout * cin_pad;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(pack_conv_w_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, Cout, Cin, taps, cin_pad);
+    else
+        hipLaunchKernelGGL(pack_conv_w_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, Cout, Cin, taps, cin_pad);
+    EOD_CHECK_LAUNCH("pack_conv_weight");
+    return EOD_OK;
+}
+
+template <typename T>
+__global__ void pack_rows_kernel(const float* __restrict__ src, long long ld_src, const int* __restrict__ row_map,
+                                 T* __restrict__ dst, long long ld_dst, int rows, int cols) {
+    const long long total = (long long)rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        const int sr = row_map ? row_map[r] : r;
+        dst[(long long)r * ld_dst + c] = cvt<T>(src[(long long)sr * ld_src + c]);
+    }
+}
+
+extern "C" int eod_pack_rows(const float* src, int64_t ld_src, const int32_t* row_map, void* dst, int64_t ld_dst, int dtype,
+                             int rows, int cols, void* stream) {
+    EOD_REQUIRE(src && dst && rows > 0 && cols > 0, "pack_rows: bad args");
+    const long long total = (long long)rows * cols;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(pack_rows_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (long long)ld_src, row_map, (half_t*)dst, (long long)ld_dst, rows, cols);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (long long)ld_src, row_map, (float*)dst, (long long)ld_dst, rows, cols);
+    EOD_CHECK_LAUNCH("pack_rows");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW fp32 (two concatenated sources) -> NHWC storage dtype, channels zero-padded to c_pad.
+// One thread per (n, pixel): reads are coalesced along W per channel plane, writes are 16-byte chunks.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ s0, int C0, const float* __restrict__ s1, int C1, T* __restrict__ dst,
+                                    int N, long long HW, int c_pad) {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW, pix = i - n * HW;
+        T* d = dst + i * c_pad;
+        for (int c = 0; c < c_pad; ++c) {
+            float v = 0.0f;
+            if (c < C0)
+                v = s0[(n * C0 + c) * HW + pix];
+            else if (c < C0 + C1)
+                v = s1[(n * C1 + (c - C0)) * HW + pix];
+            d[c] = cvt<T>(v);
+        }
+    }
+}
+
+extern "C" int eod_nchw_to_nhwc(const float* src0, int C0, const float* src1, int C1, void* dst, int dtype, int N, int H, int W,
+                                int c_pad, void* stream) {
+    EOD_REQUIRE(src0 && dst && C0 > 0 && C1 >= 0 && (C1 == 0 || src1) && c_pad >= C0 + C1, "nchw_to_nhwc: bad args");
+    const long long total = (long long)N * H * W;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src0, C0, src1, C1, (half_t*)dst, N, (long long)H * W, c_pad);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src0, C0, src1, C1, (float*)dst, N, (long long)H * W, c_pad);
+    EOD_CHECK_LAUNCH("nchw_to_nhwc");
+    return EOD_OK;
+}
+
+// NHWC storage -> NCHW fp32 through a 32x32 LDS transpose tile (pixels x channels)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, long long HW, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const long long p0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const long long pix = p0 + r;
+        const int c = c0 + tx;
+        tile[r][tx] = (pix < HW && c < C) ? (float)src[((long long)n * HW + pix) * C + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r;
+        const long long pix = p0 + tx;
+        if (pix < HW && c < C) dst[((long long)n * C + c) * HW + pix] = tile[tx][r];
+    }
+}
+
+extern "C" int eod_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int H, int W, int C, void* stream) {
+    EOD_REQUIRE(src && dst && N > 0 && C > 0, "nhwc_to_nchw: bad args");
+    const long long HW = (long long)H * W;
+    dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N), block(32, 8);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, block, 0, (hipStream_t)stream, (const half_t*)src, dst, HW, C);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, dst, HW, C);
+    EOD_CHECK_LAUNCH("nhwc_to_nchw");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x resampling on NHWC (resblock_updown, unet_openai.py:320-325): mode 0 avg-pool 2x2, 1 nearest 2x
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int mode, int pad_tl) {
+    const int Ho = mode ? 2 * H + pad_tl : H / 2, Wo = mode ? 2 * W + pad_tl : W / 2;
+    const long long total = (long long)N * Ho * Wo * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho);
+        const long long n = r / Ho;
+        float v;
+        if (mode) {
+            const int hi = ho - pad_tl, wi = wo - pad_tl;
+            v = (hi >= 0 && wi >= 0) ? (float)x[((n * H + (hi >> 1)) * W + (wi >> 1)) * C + c] : 0.0f;
+        } else {
+            const T* b = x + ((n * H + 2 * ho) * W + 2 * wo) * C + c;
+            // same summation order as ATen's avg_pool2d (row-major window), then * 0.25
+            v = ((float)b[0] + (float)b[C] + (float)b[(long long)W * C] + (float)b[(long long)W * C + C]) * 0.25f;
+        }
+        y[i] = cvt<T>(v);
+    }
+}
+
+extern "C" int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y, void* stream) {
+    EOD_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "resample2x: bad args");
+    EOD_REQUIRE(mode == 1 || (H % 2 == 0 && W % 2 == 0), "resample2x: avg-pool needs even dims (%dx%d)", H, W);
+    const long long total = (long long)N * (mode ? 2 * H + pad_tl : H / 2) * (mode ? 2 * W + pad_tl : W / 2) * C;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(resample2x_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, N, H, W, C, mode, pad_tl);
+    else
+        hipLaunchKernelGGL(resample2x_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, N, H, W, C, mode, pad_tl);
+    EOD_CHECK_LAUNCH("resample2x");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// timestep embedding MLP (fp32).  One wave per output column j; lanes stride over k (coalesced
+// weight-row reads), loop over the N samples; wave reduction.  MODE 0: input = sinusoid(t) built in
+// LDS, output silu(.) ; MODE 1: plain ; MODE 2: input silu(.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int MODE>
+__global__ void temb_linear_kernel(const float* __restrict__ in, const long long* __restrict__ t, const float* __restrict__ freqs,
+                                   const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ label_emb,
+                                   const long long* __restrict__ y, float* __restrict__ out, float* __restrict__ out2, int N, int K,
+                                   int J) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= J) return;
+    const float* wr = w + (long long)j * K;
+    for (int n = 0; n < N; ++n) {
+        float acc = 0.0f;
+        if (MODE == 0) {
+            // timestep_embedding (unet_openai.py:91-99): [cos(t*f) | sin(t*f)] (+ one zero if K is odd)
+            const int half = K / 2;
+            const float tf = (float)t[n];
+            for (int k = lane; k < K; k += 64) {
+                float e = 0.0f;
+                if (k < half)
+                    e = cosf(tf * freqs[k]);
+                else if (k < 2 * half)
+                    e = sinf(tf * freqs[k - half]);
+                acc += e * wr[k];
+            }
+        } else {
+            const float* ir = in + (long long)n * K;
+            for (int k = lane; k < K; k += 64) {
+                float e = ir[k];
+                if (MODE == 2) e = silu_f<false>(e);
+                acc += e * wr[k];
+            }
+        }
+        acc = wsum(acc);
+        if (lane == 0) {
+            float v = acc + b[j];
+            if (MODE == 0) v = silu_f<false>(v);
+            if (MODE == 1 && label_emb) v += label_emb[y[n] * J + j];
+            out[(long long)n * J + j] = v;
+        }
+    }
+}
+
+extern "C" int eod_time_embed(const eod_temb_desc* d, void* stream) {
+    EOD_REQUIRE(d && d->emb, "time_embed: null pointer");
+    EOD_REQUIRE(d->N > 0 && d->E > 0 && d->J >= 0, "time_embed: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    if (d->w1) {  // stages 1-2: sinusoid -> Linear -> SiLU -> Linear (+label_emb).  w1 == NULL: `emb` is an input
+        EOD_REQUIRE(d->t && d->freqs && d->b1 && d->w2 && d->b2 && d->h1 && d->D > 0, "time_embed: null pointer");
+        EOD_REQUIRE((d->label_emb == nullptr) == (d->y == nullptr), "time_embed: label_emb / y mismatch");
+        const unsigned be = (unsigned)((d->E + 3) / 4);
+        hipLaunchKernelGGL(temb_linear_kernel<0>, dim3(be), dim3(256), 0, st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, nullptr, d->N, d->D, d->E);
+        hipLaunchKernelGGL(temb_linear_kernel<1>, dim3(be), dim3(256), 0, st, d->h1, nullptr, nullptr, d->w2, d->b2, d->label_emb, (const long long*)d->y, d->emb, nullptr, d->N, d->E, d->E);
+    }
+    if (d->J > 0) {
+        EOD_REQUIRE(d->wcat && d->bcat && d->out, "time_embed: null wcat/bcat/out");
+        const unsigned bj = (unsigned)((d->J + 3) / 4);
+        hipLaunchKernelGGL(temb_linear_kernel<2>, dim3(bj), dim3(256), 0, st, d->emb, nullptr, nullptr, d->wcat, d->bcat, nullptr, nullptr, d->out, nullptr, d->N, d->E, d->J);
+    }
+    EOD_CHECK_LAUNCH("time_embed");
+    return EOD_OK;
+}

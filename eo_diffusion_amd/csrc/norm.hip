@@ -1,0 +1,253 @@
+// GroupNorm32 (+SiLU) and row softmax on channels-last activations.  HBM-bound kernels: 16-byte
+// coalesced accesses, wavefront/LDS reductions, deterministic two-level sums (no atomics).
+//
+// GroupNorm over a *virtual concat* (th.cat([h, hs.pop()]) -> in_layers GN, unet_openai.py:773,313):
+// group boundaries straddle the seam between the two tensors (e.g. 512|384 channels -> 28/group), so
+// statistics are first reduced per CHANNEL (eod_gn_partial, one launch per source, writing into its
+// channel range), then per GROUP across both sources (eod_gn_finalize).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// partial: grid (P, N), block (CPP, RY)  with CPP = C / EPC 16-byte chunks per pixel (<= 256).
+// part[n][p][coff + c][0..1] = (sum, sumsq) over the pixels of chunk p.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gn_partial_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ part, int P, int Ctot,
+                                  int coff) {
+    constexpr int EPC = dt<T>::epc;
+    extern __shared__ float red[];  // [RY][CPP*EPC*2]
+    const int CPP = blockDim.x, RY = blockDim.y;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int p = blockIdx.x, n = blockIdx.y;
+    const int per = (HW + P - 1) / P;
+    const int p0 = p * per, p1 = min(HW, p0 + per);
+    float s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.0f;
+    const T* base = x + (long long)n * HW * C + (long long)tx * EPC;
+    for (int pix = p0 + ty; pix < p1; pix += RY) {
+        const i32x4 raw = *reinterpret_cast<const i32x4*>(base + (long long)pix * C);
+        if constexpr (EPC == 8) {
+            const half8 h = __builtin_bit_cast(half8, raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (float)h[e];
+                s[e] += v;
+                q[e] += v * v;
+            }
+        } else {
+            const f32x4 f = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += f[e];
+                q[e] += f[e] * f[e];
+            }
+        }
+    }
+    const int W2 = CPP * EPC * 2;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[ty * W2 + (tx * EPC + e) * 2 + 0] = s[e];
+        red[ty * W2 + (tx * EPC + e) * 2 + 1] = q[e];
+    }
+    __syncthreads();
+    // fixed-order sum over ty -> deterministic
+    const int tid = ty * CPP + tx, nthr = CPP * RY;
+    for (int i = tid; i < W2; i += nthr) {
+        float a = 0.0f;
+        for (int r = 0; r < RY; ++r) a += red[r * W2 + i];
+        const int c = i >> 1;
+        part[(((long long)n * P + p) * Ctot + coff + c) * 2 + (i & 1)] = a;
+    }
+}
+
+extern "C" int eod_gn_partial(const void* x, int dtype, int N, int HW, int C, float* part, int P, int Ctot, int coff,
+                              void* stream) {
+    EOD_REQUIRE(x && part && N > 0 && HW > 0 && C > 0 && P > 0 && P <= HW, "gn_partial: bad args");
+    const int epc = 16 / eod_esize(dtype);
+    EOD_REQUIRE(C % epc == 0 && C / epc <= 256, "gn_partial: C=%d unsupported", C);
+    EOD_REQUIRE(eod_aligned16(x), "gn_partial: alignment");
+    const int cpp = C / epc;
+    int ry = 256 / cpp;
+    if (ry < 1) ry = 1;
+    const size_t lds = (size_t)ry * cpp * epc * 2 * sizeof(float);
+    dim3 grid(P, N), block(cpp, ry);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(gn_partial_kernel<half_t>, grid, block, lds, (hipStream_t)stream, (const half_t*)x, HW, C, part, P, Ctot, coff);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<float>, grid, block, lds, (hipStream_t)stream, (const float*)x, HW, C, part, P, Ctot, coff);
+    EOD_CHECK_LAUNCH("gn_partial");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: grid (groups, N), block 256.  mean/var of group g of sample n over P chunks x cpg channels
+// (double accumulation), then scale/shift per channel:
+//     y = x*scale + shift,  scale = rstd*gamma,  shift = beta - mean*rstd*gamma
+// FiLM (use_scale_shift_norm, unet_openai.py:377-381): y' = y*(1+s) + t with film[n] = [s(0..C) | t(0..C)].
+// ---------------------------------------------------------------------------------------------
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int P, int Ctot, long long HW, int groups, float eps,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ film, long long film_stride, float* __restrict__ ss) {
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = Ctot / groups;
+    const int c0 = g * cpg;
+    double s = 0.0, q = 0.0;
+    const int total = P * cpg;
+    for (int i = tid; i < total; i += 256) {
+        const int p = i / cpg, c = c0 + (i - p * cpg);
+        const float* pp = part + (((long long)n * P + p) * Ctot + c) * 2;
+        s += (double)pp[0];
+        q += (double)pp[1];
+    }
+    rs[tid] = s;
+    rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            rs[tid] += rs[tid + o];
+            rq[tid] += rq[tid + o];
+        }
+        __syncthreads();
+    }
+    const double cnt = (double)HW * cpg;
+    const double mean = rs[0] / cnt;
+    double var = rq[0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    for (int c = c0 + tid; c < c0 + cpg; c += 256) {
+        float sc = rstd * gamma[c];
+        float sh = beta[c] - meanf * sc;
+        if (film) {
+            const float fs = 1.0f + film[(long long)n * film_stride + c];
+            const float ft = film[(long long)n * film_stride + Ctot + c];
+            sc = sc * fs;
+            sh = sh * fs + ft;
+        }
+        ss[((long long)n * Ctot + c) * 2 + 0] = sc;
+        ss[((long long)n * Ctot + c) * 2 + 1] = sh;
+    }
+}
+
+extern "C" int eod_gn_finalize(const float* part, int N, int P, int Ctot, int64_t HW, int groups, float eps,
+                               const float* gamma, const float* beta, const float* film, int64_t film_stride,
+                               float* scale_shift, void* stream) {
+    EOD_REQUIRE(part && gamma && beta && scale_shift, "gn_finalize: null pointer");
+    EOD_REQUIRE(N > 0 && P > 0 && groups > 0 && Ctot % groups == 0, "gn_finalize: Ctot=%d groups=%d", Ctot, groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part, P, Ctot, (long long)HW,
+                       groups, eps, gamma, beta, film, (long long)film_stride, scale_shift);
+    EOD_CHECK_LAUNCH("gn_finalize");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply: y[n][pix][coff + c] = act(x[n][pix][c] * scale[n][coff+c] + shift[n][coff+c])
+// grid-stride over 16-byte chunks; y rows are Ctot wide (materialises the concat, normalised).
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool SILU>
+__global__ void gn_apply_kernel(const T* __restrict__ x, long long nchunks, int HW, int C, const float* __restrict__ ss,
+                                int Ctot, int coff, T* __restrict__ y) {
+    constexpr int EPC = dt<T>::epc;
+    constexpr bool FAST = (EPC == 8);
+    const int cpp = C / EPC;
+    const long long per_n = (long long)HW * cpp;
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < nchunks; f += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(f / per_n);
+        const long long rem = f - (long long)n * per_n;
+        const long long pix = rem / cpp;
+        const int c = (int)(rem - pix * cpp) * EPC;
+        const i32x4 raw = *reinterpret_cast<const i32x4*>(x + f * EPC);
+        const float* sp = ss + ((long long)n * Ctot + coff + c) * 2;
+        i32x4 outv;
+        if constexpr (EPC == 8) {
+            const half8 h = __builtin_bit_cast(half8, raw);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (float)h[e] * sp[2 * e] + sp[2 * e + 1];
+                if (SILU) v = silu_f<FAST>(v);
+                o[e] = (half_t)v;
+            }
+            outv = __builtin_bit_cast(i32x4, o);
+        } else {
+            const f32x4 fv = __builtin_bit_cast(f32x4, raw);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = fv[e] * sp[2 * e] + sp[2 * e + 1];
+                if (SILU) v = silu_f<FAST>(v);
+                o[e] = v;
+            }
+            outv = __builtin_bit_cast(i32x4, o);
+        }
+        *reinterpret_cast<i32x4*>(y + (((long long)n * HW + pix) * Ctot + coff + c)) = outv;
+    }
+}
+
+extern "C" int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot, int coff,
+                            int silu, void* y, void* stream) {
+    EOD_REQUIRE(x && y && scale_shift && N > 0 && HW > 0 && C > 0, "gn_apply: bad args");
+    const int epc = 16 / eod_esize(dtype);
+    EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_apply: channel alignment");
+    EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(y), "gn_apply: alignment");
+    const long long nchunks = (long long)N * HW * (C / epc);
+    long long blocks = (nchunks + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(T, S) hipLaunchKernelGGL((gn_apply_kernel<T, S>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, nchunks, HW, C, scale_shift, Ctot, coff, (T*)y)
+    if (dtype == EOD_F16) {
+        if (silu) LAUNCH(half_t, true); else LAUNCH(half_t, false);
+    } else {
+        if (silu) LAUNCH(float, true); else LAUNCH(float, false);
+    }
+#undef LAUNCH
+    EOD_CHECK_LAUNCH("gn_apply");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row softmax (th.softmax(weight.float(), dim=-1), unet_openai.py:479/513): one wave per row, fp32 math,
+// output in the storage dtype, columns [n, ldp) zero-filled (K padding of the P.V GEMM).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T>
+__global__ void softmax_rows_kernel(const float* __restrict__ s, long long lds, T* __restrict__ p, long long ldp, long long rows,
+                                    int n) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * lds;
+    float m = -INFINITY;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, sr[i]);
+    m = wave_max(m);
+    float sum = 0.0f;
+    for (int i = lane; i < n; i += 64) sum += expf(sr[i] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* pr = p + row * ldp;
+    for (int i = lane; i < (int)ldp; i += 64) pr[i] = (i < n) ? (T)(expf(sr[i] - m) * inv) : (T)0.0f;
+}
+
+extern "C" int eod_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int dtype, int64_t rows, int n,
+                                void* stream) {
+    EOD_REQUIRE(s && p && rows > 0 && n > 0 && ldp >= n && lds >= n, "softmax: bad args");
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(softmax_rows_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, (long long)lds, (half_t*)p, (long long)ldp, (long long)rows, n);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, (long long)lds, (float*)p, (long long)ldp, (long long)rows, n);
+    EOD_CHECK_LAUNCH("softmax_rows");
+    return EOD_OK;
+}

@@ -1,0 +1,251 @@
+"""Program builder / executor for the HIP path.
+
+A `Program` is the host-side view of one static launch plan: a flat list of C descriptors
+(`_lib.Op`), the device buffers they point into (activations are channels-last, see include/eodiff.h)
+and a few named *bindings* -- descriptor fields that are re-pointed at caller tensors on every run
+(input image, timesteps, labels, output).  `Program.run()` is ONE FFI call: `eod_program_run` walks
+the descriptor array natively and enqueues every kernel on the current HIP stream.
+
+torch is used here only for device memory (torch.empty / zeros), stream handles and dtype plumbing.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (OP_CONV, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
+                   OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
+
+PRECISIONS = {"fp32": torch.float32, "fp16": torch.float16}
+
+
+def current_stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.EodError(
+            f"{what}: tensor is on '{getattr(t, 'device', None)}'. eo_diffusion_amd runs on MI355X (HIP) only; "
+            "there is no CPU / eager fallback.")
+
+
+class Act:
+    """Channels-last activation handle: tensor of shape [N, H, W, C] in the storage dtype."""
+    __slots__ = ("t", "N", "H", "W", "C")
+
+    def __init__(self, t, N, H, W, C):
+        self.t, self.N, self.H, self.W, self.C = t, N, H, W, C
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+
+class Program:
+    def __init__(self, device, precision):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {list(PRECISIONS)}")
+        self.device = torch.device(device)
+        self.precision = precision
+        self.tdtype = PRECISIONS[precision]
+        self.dt = _lib.dtype_id(self.tdtype)
+        self.epc = 16 // self.tdtype.itemsize  # elements per 16-byte chunk
+        self.ops = []
+        self.keep = []       # tensors owned by the program
+        self.bindings = {}   # name -> list[(op_index, setter)]
+        self._arr = None
+        self.L = _lib.lib()
+        self.nbytes = 0
+
+    # ------------------------------------------------------------------ memory
+    def empty(self, shape, dtype=None, zero=False):
+        dtype = dtype or self.tdtype
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        self.nbytes += t.numel() * t.element_size()
+        return t
+
+    def act(self, N, H, W, C, zero=False):
+        return Act(self.empty((N, H, W, C), zero=zero), N, H, W, C)
+
+    def own(self, t):
+        self.keep.append(t)
+        return t
+
+    def f32(self, param):
+        """fp32 contiguous device view of a parameter (biases, GN affine, MLP weights stay fp32)."""
+        t = param.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        return self.own(t)
+
+    # ------------------------------------------------------------------ weight packing (one-off, at build time)
+    def pack_conv(self, weight, cin_pad=None):
+        """Conv2d/Conv1d weight (OIHW / OIK fp32) -> [tap][Cout][cin_pad] in the storage dtype."""
+        w = self.f32(weight)
+        cout, cin = w.shape[0], w.shape[1]
+        k = w.shape[2] if w.dim() >= 3 else 1
+        cin_pad = cin_pad or cin
+        dst = self.empty((k * k if w.dim() == 4 else 1, cout, cin_pad))
+        ks = k if w.dim() == 4 else 1
+        check(self.L.eod_pack_conv_weight(ptr(w), ptr(dst), self.dt, cout, cin, ks, cin_pad,
+                                          current_stream_ptr(self.device)), "pack_conv_weight")
+        return dst
+
+    def pack_rows(self, weight2d, row_index=None):
+        """rows of an fp32 [R][K] matrix (optionally gathered by row_index) -> storage dtype [r][K]."""
+        w = self.f32(weight2d)
+        rows = w.shape[0] if row_index is None else len(row_index)
+        cols = w.shape[1]
+        rm = None
+        if row_index is not None:
+            rm = self.own(torch.tensor(row_index, dtype=torch.int32, device=self.device))
+        dst = self.empty((rows, cols))
+        check(self.L.eod_pack_rows(ptr(w), w.stride(0), ptr(rm), ptr(dst), cols, self.dt, rows, cols,
+                                   current_stream_ptr(self.device)), "pack_rows")
+        return dst
+
+    # ------------------------------------------------------------------ op emission
+    def _push(self, kind):
+        op = Op()
+        op.kind = kind
+        self.ops.append(op)
+        self._arr = None
+        return op, len(self.ops) - 1
+
+    def bind(self, name, op_index, setter):
+        self.bindings.setdefault(name, []).append((op_index, setter))
+
+    def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
+             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None):
+        ups = 2 if upsample else 1
+        heff, weff = x.H * ups + int(pad_tl), x.W * ups + int(pad_tl)
+        ho = (heff + 2 * pad - ksize) // stride + 1
+        wo = (weff + 2 * pad - ksize) // stride + 1
+        op, idx = self._push(OP_CONV)
+        d = op.u.conv
+        d.x, d.x2, d.w = ptr(x.t), ptr(x2.t) if x2 is not None else 0, ptr(w_packed)
+        d.bias, d.cbias, d.cbias_stride = ptr(bias), ptr(cbias), cbias_stride
+        d.res = ptr(res.t) if res is not None else 0
+        d.dtype, d.N, d.H, d.W = self.dt, x.N, x.H, x.W
+        d.C0, d.C1, d.Cout = x.C, (x2.C if x2 is not None else 0), cout
+        d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
+        d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
+        if out_nchw_f32:
+            y = None  # bound by the caller (external NCHW fp32 tensor)
+        else:
+            y = out if out is not None else self.act(x.N, ho, wo, cout)
+            d.y = ptr(y.t)
+        if x2 is not None:
+            assert (x2.N, x2.H, x2.W) == (x.N, x.H, x.W)
+        if res is not None:
+            assert (res.N, res.H, res.W, res.C) == (x.N, ho, wo, cout), "residual shape"
+        return y, idx
+
+    def gemm(self, a, b, c, M, N, K, lda, ldb, ldc, *, bias=None, bias_mode=1, res=None, alpha=1.0, c_f32=False,
+             nb0=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0):
+        """C = alpha*A.B^T (+bias)(+res); a/b/c are tensors, *_off element offsets into them."""
+        op, idx = self._push(OP_GEMM)
+        d = op.u.gemm
+        es = self.tdtype.itemsize
+        d.a = ptr(a) + a_off * es
+        d.b = ptr(b) + b_off * es
+        d.c = ptr(c) + c_off * (4 if c_f32 else es)
+        d.bias = ptr(bias)
+        d.res = ptr(res)
+        d.lda, d.ldb, d.ldc = lda, ldb, ldc
+        d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
+        d.dtype, d.M, d.N, d.K, d.nb0, d.nb1 = self.dt, M, N, K, nb0, nb1
+        d.bias_mode, d.c_f32, d.alpha = (bias_mode if bias is not None else 0), int(c_f32), alpha
+        return idx
+
+    def _small(self, kind, p=(), l=(), i=(), f=()):
+        op, idx = self._push(kind)
+        s = op.u.small
+        for k, v in enumerate(p):
+            s.p[k] = v
+        for k, v in enumerate(l):
+            s.l[k] = v
+        for k, v in enumerate(i):
+            s.i[k] = v
+        for k, v in enumerate(f):
+            s.f[k] = v
+        return idx
+
+    def group_norm(self, srcs, gamma, beta, *, silu, eps=1e-5, groups=32, film=None, film_stride=0):
+        """GroupNorm32 [+FiLM] [+SiLU] over the virtual channel-concat of `srcs` (1 or 2 Acts).
+        Returns one Act with sum(C) channels (this materialises the concat, already normalised)."""
+        x0 = srcs[0]
+        N, H, W = x0.N, x0.H, x0.W
+        HW = H * W
+        ctot = sum(s.C for s in srcs)
+        if ctot % groups:
+            raise ValueError(f"GroupNorm: {ctot} channels not divisible by {groups} groups")
+        P = max(1, min(256, HW // 64))
+        part = self.empty((N, P, ctot, 2), torch.float32)
+        ss = self.empty((N, ctot, 2), torch.float32)
+        coff = 0
+        for s in srcs:
+            self._small(OP_GN_PARTIAL, p=(ptr(s.t), ptr(part)), i=(self.dt, N, HW, s.C, P, ctot, coff))
+            coff += s.C
+        self._small(OP_GN_FINALIZE, p=(ptr(part), ptr(gamma), ptr(beta), ptr(film) if film is not None else 0, ptr(ss)),
+                    l=(HW, film_stride), i=(N, P, ctot, groups), f=(eps,))
+        y = self.act(N, H, W, ctot)
+        coff = 0
+        for s in srcs:
+            self._small(OP_GN_APPLY, p=(ptr(s.t), ptr(ss), ptr(y.t)), i=(self.dt, N, HW, s.C, ctot, coff, int(silu)))
+            coff += s.C
+        return y
+
+    def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):
+        return self._small(OP_SOFTMAX, p=(ptr(s_f32), ptr(p_out)), l=(lds, ldp, rows), i=(self.dt, n))
+
+    def to_nhwc(self, N, C0, C1, H, W, c_pad):
+        y = self.act(N, H, W, c_pad)
+        idx = self._small(OP_TO_NHWC, p=(0, 0, ptr(y.t)), i=(C0, C1, self.dt, N, H, W, c_pad))
+        return y, idx
+
+    def to_nchw(self, x):
+        idx = self._small(OP_TO_NCHW, p=(ptr(x.t), 0), i=(self.dt, x.N, x.H, x.W, x.C))
+        return idx
+
+    def resample2x(self, x, mode, pad_tl=False):
+        if mode == 1:
+            ho, wo = 2 * x.H + int(pad_tl), 2 * x.W + int(pad_tl)
+        else:
+            ho, wo = x.H // 2, x.W // 2
+        y = self.act(x.N, ho, wo, x.C)
+        self._small(OP_POOL, p=(ptr(x.t), ptr(y.t)), i=(self.dt, x.N, x.H, x.W, x.C, mode, int(pad_tl)))
+        return y
+
+    def temb(self, desc_fields):
+        op, idx = self._push(OP_TEMB)
+        for k, v in desc_fields.items():
+            setattr(op.u.temb, k, v)
+        return idx
+
+    # ------------------------------------------------------------------ execution
+    def finalize(self):
+        arr = (Op * len(self.ops))()
+        for k, o in enumerate(self.ops):
+            C.memmove(C.byref(arr, k * C.sizeof(Op)), C.byref(o), C.sizeof(Op))
+        self._arr = arr
+        return self
+
+    def set_binding(self, name, value_ptr):
+        if self._arr is None:
+            self.finalize()
+        for op_index, setter in self.bindings[name]:
+            setter(self._arr[op_index], value_ptr)
+
+    def run(self, stream=None):
+        if self._arr is None:
+            self.finalize()
+        st = stream if stream is not None else current_stream_ptr(self.device)
+        check(self.L.eod_program_run(self._arr, len(self.ops), st), "eod_program_run")
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m

@@ -1,0 +1,207 @@
+/*
+ * eodiff.h -- C ABI of libeodiff.so: the MI355X (gfx950) replacement for the stock-torch op call
+ * sites on the EODiffusion hot path.
+ *
+ * Contract: stateless, stream-ordered entry points.  Every function returns 0 on success and a
+ * negative EOD_E* code on failure (message via eod_last_error()).  The caller owns every buffer
+ * (raw device pointers); nothing is allocated, freed or synchronised inside, so every call is
+ * hipGraph-capturable.  `stream` is a hipStream_t passed as void*.  No torch types cross here.
+ *
+ * Activation layout inside the library is channels-last ("NHWC": [N][H][W][C], C contiguous) in
+ * the storage dtype of the precision mode (EOD_F32: exact-fp32 MFMA; EOD_F16: fp16 storage,
+ * fp16 MFMA, fp32 accumulate).  The reference API layout (NCHW fp32) is converted at the edges.
+ *
+ * Each entry point cites the reference call site (file:line in furio1999/EO_Diffusion) it replaces.
+ */
+#ifndef EODIFF_H
+#define EODIFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EOD_OK 0
+#define EOD_EINVAL (-1)  /* bad shape / alignment / argument */
+#define EOD_ELAUNCH (-2) /* HIP launch error */
+#define EOD_ENOSYS (-3)  /* variant not built */
+
+enum { EOD_F32 = 0, EOD_F16 = 1 };
+
+const char* eod_last_error(void);
+int eod_version(void);
+/* sizeof() of the descriptor structs as compiled (1 conv, 2 gemm, 3 temb, 4 small, 5 op): lets a
+ * foreign-language binding verify its mirror of the layouts at load time. */
+int eod_struct_size(int kind);
+
+/* ------------------------------------------------------------------------------------------
+ * k1/k2/k3/k4/k9/k10: implicit-GEMM convolution on MFMA.
+ * Replaces nn.Conv2d call sites: ResBlock.in_layers[2]/out_layers[3] unet_openai.py:315,341;
+ * skip_connection 1x1 :352; Downsample.op (stride 2) :262-264; Upsample.conv after nearest-2x
+ * F.interpolate :227,236 (the 2x is virtual: upsample=1 indexes h>>1,w>>1); th.cat :773 is
+ * virtual too (two A sources x | x2); first/last conv :609,742.
+ * y[n,ho,wo,co] = alpha * sum_{tap,c} A(n, ho*stride-pad+dy, wo*stride-pad+dx, c) * w[tap][co][c]
+ *                 + bias[co] + cbias[n*cbias_stride + co] + res[n,ho,wo,co]
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* x;       /* A source 0, NHWC [N][H][W][C0], storage dtype                      */
+    const void* x2;      /* A source 1 (virtual concat) [N][H][W][C1], or NULL when C1 == 0     */
+    const void* w;       /* packed weights [ksize*ksize][Cout][C0+C1], storage dtype            */
+    const float* bias;   /* [Cout] fp32 or NULL                                                 */
+    const float* cbias;  /* per-sample bias (timestep embedding, unet_openai.py:374-383) or NULL */
+    const void* res;     /* residual, NHWC [N][Ho][Wo][Cout], storage dtype, or NULL (:385)      */
+    void* y;             /* output: NHWC storage dtype (out_nchw_f32=0) or NCHW fp32 (=1)        */
+    int64_t cbias_stride;
+    int32_t dtype;       /* EOD_F32 | EOD_F16 */
+    int32_t N, H, W;     /* input spatial dims as stored (before the virtual 2x upsample)        */
+    int32_t C0, C1, Cout;
+    int32_t ksize;       /* 1 or 3 */
+    int32_t stride;      /* 1 or 2 */
+    int32_t pad;         /* 0 or 1 */
+    int32_t upsample;    /* 1: A is the nearest-2x upsampling of x (H,W are the stored dims)     */
+    int32_t pad_tl;      /* 1: extra zero row/col on top/left after upsampling (3x3 -> 7x7 hack,
+                            unet_openai.py:237-239)                                              */
+    int32_t Ho, Wo;      /* output spatial dims */
+    int32_t out_nchw_f32;
+    float alpha;
+} eod_conv_desc;
+int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * k3/k7/k8: batched GEMM on MFMA,  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] (+bias)(+res)
+ * A and B are both K-contiguous ("NT").  Used for the attention block (unet_openai.py:427-433):
+ * qkv / proj_out Conv1d(1x1) :414,422 and the two einsums of QKVAttention(Legacy) :476-480.
+ * batch index z = b0 * nb1 + b1, each operand has one stride per level (elements).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* a;
+    const void* b;
+    const float* bias; /* fp32, or NULL */
+    const void* res;   /* same layout/dtype as c, or NULL */
+    void* c;
+    int64_t lda, ldb, ldc;
+    int64_t sa0, sa1, sb0, sb1, sc0, sc1; /* batch strides (elements) */
+    int32_t dtype;     /* dtype of a, b (and res / c unless c_f32) */
+    int32_t M, N, K;   /* K must be a multiple of 16 bytes worth of elements */
+    int32_t nb0, nb1;
+    int32_t bias_mode; /* 0 none, 1 per column n, 2 per row m */
+    int32_t c_f32;     /* 1: store c as fp32 regardless of dtype */
+    float alpha;
+} eod_gemm_desc;
+int eod_gemm_nt(const eod_gemm_desc* d, void* stream);
+
+/* weights: OIHW fp32 (Conv2d.weight, unet_openai.py:21-25) -> [tap][Cout][cin_pad] storage dtype */
+int eod_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int ksize,
+                         int cin_pad, void* stream);
+/* generic strided 2-D cast-copy: dst[r][c] = (dtype) src[row_index(r)*ld_src + c]; row_map may be NULL */
+int eod_pack_rows(const float* src, int64_t ld_src, const int32_t* row_map, void* dst, int64_t ld_dst,
+                  int dtype, int rows, int cols, void* stream);
+
+/* API-edge layout conversion (x.type(self.dtype) / th.cat([x,cond],1), unet_openai.py:756,767):
+ * dst NHWC [N][H][W][c_pad] = concat(src0 NCHW fp32 [N][C0], src1 NCHW fp32 [N][C1]), zero padded. */
+int eod_nchw_to_nhwc(const float* src0, int C0, const float* src1, int C1, void* dst, int dtype,
+                     int N, int H, int W, int c_pad, void* stream);
+int eod_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * k5: GroupNorm32(32, C) [+ SiLU]  (unet_openai.py:11-13, 71-78, 312-316, 336-343, 739-743)
+ * three stream-ordered phases, deterministic (no atomics):
+ *   partial : per (n, pixel-chunk p, channel) sum / sum-of-squares       -> part[N][P][Ctot][2]
+ *   finalize: per (n, group) mean/rstd over BOTH concat sources, folded with gamma/beta (and the
+ *             FiLM scale/shift of use_scale_shift_norm :377-381) into scale/shift[N][Ctot]
+ *   apply   : y = act(x * scale + shift), written at channel offset `coff` of a Ctot-wide tensor
+ * ------------------------------------------------------------------------------------------ */
+int eod_gn_partial(const void* x, int dtype, int N, int HW, int C, float* part, int P, int Ctot,
+                   int coff, void* stream);
+int eod_gn_finalize(const float* part, int N, int P, int Ctot, int64_t HW, int groups, float eps,
+                    const float* gamma, const float* beta, const float* film, int64_t film_stride,
+                    float* scale_shift, void* stream);
+int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot,
+                 int coff, int silu, void* y, void* stream);
+
+/* k8 (softmax of QKVAttention, unet_openai.py:479/513): p[r][0..ldp) = softmax(s[r][0..n)), zero pad */
+int eod_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int dtype, int64_t rows, int n,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * k6: timestep embedding MLP (unet_openai.py:81-99, 597-602, 604-605, 329-335, 763-766).
+ *   emb   = W2 * silu(W1 * [cos(t f) | sin(t f)] + b1) + b2 (+ label_emb[y])
+ *   out   = Wcat * silu(emb) + bcat             (all ResBlock emb_layers batched into one GEMV)
+ * all fp32.  freqs[half] is the host-computed fp32 table of :92-94.  t is int64 [N].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const int64_t* t;
+    const float* freqs;
+    const float* w1; const float* b1; /* [E][D], [E] */
+    const float* w2; const float* b2; /* [E][E], [E] */
+    const float* label_emb;           /* [num_classes][E] or NULL */
+    const int64_t* y;                 /* [N] or NULL */
+    const float* wcat; const float* bcat; /* [J][E], [J] */
+    float* h1;   /* scratch [N][E] */
+    float* emb;  /* out [N][E] (pre-SiLU, as the reference's emb) */
+    float* out;  /* out [N][J] */
+    int32_t N, D, E, J;
+} eod_temb_desc;
+int eod_time_embed(const eod_temb_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * k11-k15: fused sampler updates.  fp32, built with -ffp-contract=off so that every rounding of
+ * the reference's torch op sequence is reproduced bit-for-bit.  x/pred/noise/out are [N][CHW] fp32.
+ * tables are the EODiffusion buffers (model.py:23-32), t is int64 [N].
+ * ------------------------------------------------------------------------------------------ */
+/* model.py:94-98 (== ddpm.py:279-282) */
+int eod_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp,
+                 const float* sqrt_1m_acp, float* out, int N, int64_t chw, int T, void* stream);
+/* model.py:58-60  x_t <- mask*q_sample(gt,t,noise) + (1-mask)*x_t ; mask is [N][1][H][W] */
+int eod_repaint_mix(const float* x_t, const float* gt, const float* mask, const float* noise,
+                    const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, float* out,
+                    int N, int C, int64_t hw, int T, void* stream);
+/* model.py:126-150 (clip=1) / :101-122 (clip=0), including the batch-wide `t.min()>0` branch */
+int eod_ddpm_step(const float* x_t, const float* pred, const float* noise, const int64_t* t,
+                  const float* betas, const float* alphas, const float* acp, const float* sqrt_1m_acp,
+                  float* out, int N, int64_t chw, int T, int clip, void* stream);
+/* ddim.py:192-206; the four scalars are the fp32-rounded table entries of :192-195 */
+int eod_ddim_step(const float* x, const float* e_t, const float* noise, float a_t, float a_prev,
+                  float sigma_t, float sqrt_1m_at, float temperature, float* x_prev, float* pred_x0,
+                  int64_t numel, void* stream);
+/* k15: counter-based N(0,1): Philox4x32-10 keyed by seed, counter = (element/4, sample0+n, step, stream_id)
+ * -> results are invariant to how samples are sharded over ranks. */
+int eod_randn_philox(float* out, int N, int64_t chw, uint64_t seed, int64_t sample0, int32_t step,
+                     int32_t stream_id, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Native executor: run a pre-built program (array of tagged descriptors) on one stream without
+ * returning to the host language between launches (replaces the ~100-180 Python-dispatched
+ * ATen launches per UNet forward).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    EOD_OP_CONV = 1, EOD_OP_GEMM = 2, EOD_OP_GN_PARTIAL = 3, EOD_OP_GN_FINALIZE = 4,
+    EOD_OP_GN_APPLY = 5, EOD_OP_SOFTMAX = 6, EOD_OP_TEMB = 7, EOD_OP_TO_NHWC = 8, EOD_OP_TO_NCHW = 9,
+    EOD_OP_POOL = 10
+};
+typedef struct {
+    const void* p[6];
+    int64_t l[4];
+    int32_t i[10];
+    float f[2];
+} eod_small_desc; /* argument pack of the small ops, field use documented in csrc/program.hip */
+typedef struct {
+    int32_t kind;
+    int32_t _pad;
+    union {
+        eod_conv_desc conv;
+        eod_gemm_desc gemm;
+        eod_temb_desc temb;
+        eod_small_desc small;
+    } u;
+} eod_op;
+int eod_program_run(const eod_op* ops, int n_ops, void* stream);
+/* resblock_updown helpers (unet_openai.py:320-325): mode 0 = 2x2 average pool, 1 = nearest 2x */
+int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference]
+
+The reference never travels to the GPU box; only the .npz / .json data written here does.
+Harness-side adaptations (NOT reference behaviour):
+  (1) torchvision stub (model.py:7-8 import it only for PNG dumps);
+  (2) DDIMSampler.register_buffer (ddim.py:18-22) hard-codes "cuda" -> identity on CPU;
+  (3) masked DDIM calls _forward_diffusion(x0, ts) without noise (ddim.py:147) -> noise=randn_like(x0);
+  (4) x0 passed explicitly to DDIMSampler.sample (inference.py:125 omits it);
+  (5) weights (zero_module ones included) come from tests/synth.py;
+  (6) torch.randn / torch.randn_like are wrapped to RECORD the tensors the reference draws.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(1, REF)
+sys.dont_write_bytecode = True
+
+from tests.synth import rect_mask, synth_input, synth_state_dict  # noqa: E402
+
+
+def _stub_torchvision():
+    tv = types.ModuleType("torchvision")
+    tvu = types.ModuleType("torchvision.utils")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvu.save_image = lambda *a, **k: None
+    tv.utils, tv.transforms, tvt.functional = tvu, tvt, tvf
+    for n, m in [("torchvision", tv), ("torchvision.utils", tvu), ("torchvision.transforms", tvt),
+                 ("torchvision.transforms.functional", tvf)]:
+        sys.modules[n] = m
+
+
+_stub_torchvision()
+import backbones.unet_openai as R  # noqa: E402  (reference)
+import diffusion.util as RU  # noqa: E402
+from diffusion.ddim import DDIMSampler  # noqa: E402
+from diffusion.model import EODiffusion  # noqa: E402
+
+assert R.__file__.startswith(REF), R.__file__
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def load_synth(module, seed=0):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    module.load_state_dict(synth_state_dict(shapes, seed))
+    return shapes
+
+
+class Recorder:
+    """Wraps torch.randn / randn_like / randint and records what the reference draws, in order."""
+
+    def __enter__(self):
+        self.draws = []
+        self._o = (torch.randn, torch.randn_like, torch.randint)
+        rec = self.draws
+
+        def randn(*a, **k):
+            t = self._o[0](*a, **k)
+            rec.append(("randn", t.clone()))
+            return t
+
+        def randn_like(*a, **k):
+            t = self._o[1](*a, **k)
+            rec.append(("randn_like", t.clone()))
+            return t
+
+        def randint(*a, **k):
+            t = self._o[2](*a, **k)
+            rec.append(("randint", t.clone()))
+            return t
+
+        torch.randn, torch.randn_like, torch.randint = randn, randn_like, randint
+        return self
+
+    def __exit__(self, *e):
+        torch.randn, torch.randn_like, torch.randint = self._o
+
+
+# --------------------------------------------------------------------------- schedules
+def gen_schedules():
+    print("schedules")
+    dummy = torch.nn.Identity()
+    for T in (20, 200, 1000):
+        m = EODiffusion(dummy, timesteps=T, image_size=8, in_channels=3)
+        save(f"schedule_T{T}", **{k: getattr(m, k) for k in
+                                  ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod",
+                                   "sqrt_one_minus_alphas_cumprod")})
+    for sch in ("linear", "cosine", "sqrt_linear", "sqrt"):
+        save(f"ldm_betas_{sch}_T1000", betas=RU.make_beta_schedule(sch, 1000))
+    m = EODiffusion(dummy, timesteps=1000, image_size=8, in_channels=3)
+    m20 = EODiffusion(dummy, timesteps=20, image_size=8, in_channels=3)
+    for model, T, Ss in ((m, 1000, (50, 250, 600, 1000)), (m20, 20, (10, 20))):
+        for S in Ss:
+            for eta in (0.0, 0.5):
+                s = DDIMSampler(model)
+                s.register_buffer = lambda name, attr, s=s: setattr(s, name, attr)
+                s.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
+                save(f"ddim_S{S}_T{T}_eta{eta}", steps=np.asarray(s.ddim_timesteps, dtype=np.int64),
+                     a=s.ddim_alphas, a_prev=np.asarray(s.ddim_alphas_prev, dtype=np.float64),
+                     sigma=torch.as_tensor(s.ddim_sigmas).double(),
+                     sqrt_1m_a=torch.as_tensor(s.ddim_sqrt_one_minus_alphas))
+    save("ddim_quad_S50_T1000", steps=RU.make_ddim_timesteps("quad", 50, 1000, verbose=False).astype(np.int64))
+    ts = torch.tensor([0, 1, 499, 999])
+    save("temb", t=ts, d32=R.timestep_embedding(ts, 32), d128=R.timestep_embedding(ts, 128),
+         d33=R.timestep_embedding(ts, 33))
+
+
+# --------------------------------------------------------------------------- modules
+def gen_modules():
+    print("modules")
+    emb = synth_input("emb", (2, 128), 1)
+    cases = {
+        "res_same": dict(channels=32, out_channels=None),
+        "res_change": dict(channels=32, out_channels=64),
+        "res_cat96": dict(channels=96, out_channels=32),
+        "res_skip3x3": dict(channels=32, out_channels=64, use_conv=True),
+        "res_film": dict(channels=64, out_channels=32, use_scale_shift_norm=True),
+        "res_up": dict(channels=32, out_channels=32, up=True),
+        "res_down": dict(channels=32, out_channels=64, down=True),
+    }
+    for name, kw in cases.items():
+        blk = R.ResBlock(emb_channels=128, dropout=0.0, **kw).eval()
+        load_synth(blk, 3)
+        x = synth_input(name, (2, kw["channels"], 8, 8), 2)
+        with torch.no_grad():
+            save("mod_" + name, x=x, emb=emb, y=blk(x, emb))
+    for name, (C, heads, nhc, new, hw) in {
+        "attn_c64_h1_legacy": (64, 1, -1, False, (4, 4)),
+        "attn_c128_h4_legacy": (128, 4, -1, False, (4, 4)),
+        "attn_c384_h8_legacy": (384, 8, -1, False, (4, 4)),
+        "attn_c128_d128_new": (128, 1, 128, True, (7, 7)),
+        "attn_c128_h8_new": (128, 8, -1, True, (5, 3)),
+        "attn_c512_h8_legacy": (512, 8, -1, False, (6, 6)),
+    }.items():
+        blk = R.AttentionBlock(C, num_heads=heads, num_head_channels=nhc, use_new_attention_order=new).eval()
+        load_synth(blk, 4)
+        x = synth_input(name, (2, C) + hw, 2)
+        with torch.no_grad():
+            save("mod_" + name, x=x, y=blk(x))
+    for name, (cls, C, kw, hw) in {
+        "up_conv": (R.Upsample, 32, dict(use_conv=True), (8, 8)),
+        "up_conv_3x3": (R.Upsample, 32, dict(use_conv=True), (3, 3)),
+        "up_noconv": (R.Upsample, 32, dict(use_conv=False), (4, 4)),
+        "down_conv": (R.Downsample, 32, dict(use_conv=True), (8, 8)),
+        "down_conv_odd": (R.Downsample, 32, dict(use_conv=True), (7, 7)),
+        "down_pool": (R.Downsample, 32, dict(use_conv=False), (8, 8)),
+    }.items():
+        blk = cls(C, **kw).eval()
+        if kw["use_conv"]:
+            load_synth(blk, 5)
+        x = synth_input(name, (2, C) + hw, 2)
+        with torch.no_grad():
+            save("mod_" + name, x=x, y=blk(x))
+
+
+# --------------------------------------------------------------------------- UNets
+UNETS = {
+    # name: (ctor kwargs, batch, extra)
+    "u_a0_tiny": dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
+                      attention_resolutions=[], channel_mult=[1, 2], num_heads=1),
+    "u_a1_tiny": dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=2,
+                      attention_resolutions=[1, 2], channel_mult=[1, 2], num_heads=4),
+    "u_a0_seams": dict(image_size=32, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
+                       attention_resolutions=[], channel_mult=[1, 2, 3, 4], num_heads=1),
+    "u_a1_seams": dict(image_size=32, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=2,
+                       attention_resolutions=[4, 8], channel_mult=[1, 2, 3, 4], num_heads=8),
+    "u_cond_cls": dict(image_size=16, in_channels=7, model_channels=32, out_channels=3, num_res_blocks=1,
+                       attention_resolutions=[2], channel_mult=[1, 2], num_heads=2, num_classes=5),
+    "u_film_updown": dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
+                          attention_resolutions=[2], channel_mult=[1, 2], num_head_channels=16,
+                          use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True),
+    "u_mnist": dict(image_size=28, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1,
+                    attention_resolutions=[], channel_mult=[2, 4], num_heads=1),
+    "u_s2_13ch": dict(image_size=16, in_channels=13, model_channels=32, out_channels=13, num_res_blocks=1,
+                      attention_resolutions=[2], channel_mult=[1, 2], num_heads=8),
+}
+
+
+def gen_unets():
+    print("unets")
+    for name, kw in UNETS.items():
+        u = R.UNetModel(**kw).eval()
+        load_synth(u, 7)
+        n = 2
+        hw = kw["image_size"]
+        cin = kw["in_channels"]
+        t = torch.tensor([3, 17], dtype=torch.int64)
+        cond = y = None
+        if name == "u_cond_cls":
+            x = synth_input(name, (n, 3, hw, hw), 2)
+            cond = synth_input(name + "c", (n, 4, hw, hw), 2, uniform=True)
+            y = torch.tensor([1, 4])
+        else:
+            x = synth_input(name, (n, cin, hw, hw), 2)
+        with torch.no_grad():
+            out = u(x, t, cond=cond, y=y)
+        assert out.abs().max() > 1e-3
+        arrs = dict(x=x, t=t, y_out=out)
+        if cond is not None:
+            arrs.update(cond=cond, y=y)
+        save("unet_" + name, **arrs)
+    with open(os.path.join(HERE, "unet_cfgs.json"), "w") as f:
+        json.dump(UNETS, f, indent=1)
+
+
+def gen_keys():
+    print("state_dict key contracts")
+    archs = {
+        "A0": dict(image_size=64, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=1,
+                   attention_resolutions=[], channel_mult=[1, 2, 3, 4], num_heads=1),
+        "A1": dict(image_size=64, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2,
+                   attention_resolutions=[4, 8], channel_mult=[1, 2, 3, 4], num_heads=8),
+        "MNIST": UNETS["u_mnist"],
+        "FILM": UNETS["u_film_updown"],
+        "CLS": UNETS["u_cond_cls"],
+    }
+    out = {}
+    for name, kw in archs.items():
+        with torch.device("meta"):
+            u = R.UNetModel(**kw)
+        m = EODiffusion(u, timesteps=1000, image_size=kw["image_size"], in_channels=3)
+        out[name] = {"cfg": kw, "unet": {k: list(v.shape) for k, v in u.state_dict().items()},
+                     "eodiffusion": {k: list(v.shape) for k, v in m.state_dict().items()}}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f)
+
+
+# --------------------------------------------------------------------------- sampler steps + trajectories
+def gen_sampler():
+    print("sampler")
+    u = R.UNetModel(**UNETS["u_a0_tiny"]).eval()
+    load_synth(u, 7)
+    T = 1000
+    m = EODiffusion(u, timesteps=T, image_size=16, in_channels=3).eval()
+
+    class Fixed(torch.nn.Module):  # lets the step functions run with an injected eps_hat
+        def forward(self, x, t, cond=None, y=None):
+            return self.pred
+
+    fm = EODiffusion(Fixed(), timesteps=T, image_size=8, in_channels=3)
+    arrs = {}
+    for tag, tv in {"t999": [999, 999], "t500": [500, 500], "t1": [1, 1], "t0": [0, 0], "tmix0": [0, 5],
+                    "tmix": [3, 700]}.items():
+        t = torch.tensor(tv, dtype=torch.int64)
+        x = synth_input("sx" + tag, (2, 3, 8, 8), 9)
+        pred = synth_input("sp" + tag, (2, 3, 8, 8), 9)
+        noise = synth_input("sn" + tag, (2, 3, 8, 8), 9)
+        fm.model.pred = pred
+        arrs[tag + "_t"] = t
+        arrs[tag + "_x"], arrs[tag + "_pred"], arrs[tag + "_noise"] = x, pred, noise
+        arrs[tag + "_clip"] = fm._reverse_diffusion_with_clip(x, t, noise)
+        arrs[tag + "_noclip"] = fm._reverse_diffusion(x, t, noise)
+        arrs[tag + "_q"] = fm._forward_diffusion(x, t, noise)
+    save("sampler_steps_T1000", **arrs)
+
+    # --- short DDPM trajectories through the reference's own sampling() (T = 20) ---
+    T = 20
+    m = EODiffusion(u, timesteps=T, image_size=16, in_channels=3, cond_type="sum").eval()
+    gt = synth_input("gt", (2, 3, 16, 16), 11, uniform=True)
+    mask = rect_mask(2, 16, 16, 11)
+    cond = torch.cat([gt, mask], 1)
+    for clip in (True, False):
+        torch.manual_seed(100)
+        with Recorder() as r:
+            out = m.sampling(2, clipped_reverse_diffusion=clip, device="cpu", cond=cond)
+        xT = r.draws[0][1]
+        noises = torch.stack([d[1] for d in r.draws[1:]])
+        assert r.draws[0][0] == "randn" and noises.shape[0] == T
+        save(f"traj_ddpm_repaint_{'clip' if clip else 'noclip'}_T20", x_T=xT, noises=noises, gt=gt, mask=mask, out=out)
+    m2 = EODiffusion(u, timesteps=T, image_size=16, in_channels=3).eval()
+    torch.manual_seed(101)
+    with Recorder() as r:
+        out = m2.sampling(2, clipped_reverse_diffusion=True, device="cpu")
+    save("traj_ddpm_uncond_clip_T20", x_T=r.draws[0][1], noises=torch.stack([d[1] for d in r.draws[1:]]), out=out)
+
+    # --- training forward (model.py:38-44): randint t, q_sample, UNet ---
+    x0 = synth_input("x0", (2, 3, 16, 16), 12)
+    nz = synth_input("nz", (2, 3, 16, 16), 12)
+    torch.manual_seed(102)
+    with Recorder() as r, torch.no_grad():
+        pred = m2(x0, nz)
+    save("train_forward_T20", x0=x0, noise=nz, t=r.draws[0][1], pred=pred)
+
+    # --- DDIM (ddim.py) ---
+    for tag, S, eta, masked in (("S10_eta0", 10, 0.0, False), ("S10_eta05_mask", 10, 0.5, True), ("S20_eta0_mask", 20, 0.0, True)):
+        s = DDIMSampler(m2)
+        s.register_buffer = lambda name, attr, s=s: setattr(s, name, attr)
+        m2.device = "cpu"
+        orig_fd = m2._forward_diffusion
+        if masked:
+            m2._forward_diffusion = lambda x0_, ts_, noise=None: orig_fd(x0_, ts_, torch.randn_like(x0_) if noise is None else noise)
+        torch.manual_seed(103)
+        with Recorder() as r:
+            out, inter = s.sample(S=S, batch_size=2, shape=(3, 16, 16), eta=eta, verbose=False,
+                                  mask=mask if masked else None, x0=gt if masked else None, log_every_t=5)
+        m2._forward_diffusion = orig_fd
+        draws = r.draws
+        xT = draws[0][1]
+        per = 3 if masked else 2  # [mix noise], randn_like (unused, ddim.py:171), randn via noise_like (:203)
+        rest = draws[1:]
+        nsteps = len(s.ddim_timesteps)
+        assert len(rest) == per * nsteps, (len(rest), per, nsteps)
+        step_noises = torch.stack([rest[i * per + per - 1][1] for i in range(nsteps)])
+        arrs = dict(x_T=xT, step_noises=step_noises, out=out, steps=np.asarray(s.ddim_timesteps, np.int64),
+                    pred_x0_last=inter["pred_x0"][-1], n_inter=len(inter["x_inter"]))
+        if masked:
+            arrs.update(mix_noises=torch.stack([rest[i * per][1] for i in range(nsteps)]), x0=gt, mask=mask)
+        save("traj_ddim_" + tag + "_T20", **arrs)
+
+    # single DDIM step with injected eps (T=1000, S=250)
+    m3 = EODiffusion(Fixed(), timesteps=1000, image_size=8, in_channels=3)
+    m3.device = "cpu"
+    s = DDIMSampler(m3)
+    s.register_buffer = lambda name, attr, s=s: setattr(s, name, attr)
+    arrs = {}
+    for eta in (0.0, 0.7):
+        s.make_schedule(ddim_num_steps=250, ddim_eta=eta, verbose=False)
+        for index in (249, 100, 1, 0):
+            x = synth_input(f"dx{index}", (2, 3, 8, 8), 13)
+            e = synth_input(f"de{index}", (2, 3, 8, 8), 13)
+            m3.model.pred = e
+            t = torch.full((2,), int(s.ddim_timesteps[index]), dtype=torch.long)
+            torch.manual_seed(104)
+            with Recorder() as r:
+                xp, p0 = s.p_sample_ddim(x, None, t, index=index)
+            k = f"eta{eta}_i{index}_"
+            arrs[k + "x"], arrs[k + "e"], arrs[k + "noise"] = x, e, r.draws[1][1]
+            arrs[k + "x_prev"], arrs[k + "pred_x0"] = xp, p0
+    save("ddim_steps_S250_T1000", **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_schedules()
+    gen_modules()
+    gen_unets()
+    gen_keys()
+    gen_sampler()
+    print("done")
