@@ -379,20 +379,23 @@ class AttentionBlock(_Emitter):
         self.attention = QKVAttention(self.num_heads) if use_new_attention_order else QKVAttentionLegacy(self.num_heads)
         self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
 
-    def _row_maps(self):
-        """rows of qkv.weight that produce q|k (in [q heads..., k heads...] order) and v (head-major)."""
+    def _row_maps(self, epc):
+        """rows of qkv.weight producing q|k (layout [q: heads x dpad | k: heads x dpad], each head zero-padded
+        to a multiple of one 16-byte chunk so that it can be the K dimension of the score GEMM) and v (head-major)."""
         Cc, nh = self.channels, self.num_heads
         assert (3 * Cc) % (3 * nh) == 0
         d = Cc // nh
-        if self.attention.new_order:
-            q = [h * d + j for h in range(nh) for j in range(d)]
-            k = [Cc + h * d + j for h in range(nh) for j in range(d)]
-            v = [2 * Cc + h * d + j for h in range(nh) for j in range(d)]
-        else:
-            q = [h * 3 * d + j for h in range(nh) for j in range(d)]
-            k = [h * 3 * d + d + j for h in range(nh) for j in range(d)]
-            v = [h * 3 * d + 2 * d + j for h in range(nh) for j in range(d)]
-        return q + k, v, d
+        dpad = round_up(d, epc)
+        if self.attention.new_order:   # [q|k|v][h][d]  (unet_openai.py:506-514)
+            base = lambda which, h: which * Cc + h * d
+        else:                          # [h][q|k|v][d]  (unet_openai.py:474)
+            base = lambda which, h: h * 3 * d + which * d
+        qk = []
+        for which in (0, 1):
+            for h in range(nh):
+                qk += [base(which, h) + j for j in range(d)] + [-1] * (dpad - d)
+        v = [base(2, h) + j for h in range(nh) for j in range(d)]
+        return qk, v, d, dpad
 
     def _emit(self, prog, x, ctx=None):
         if isinstance(x, tuple):
@@ -400,32 +403,32 @@ class AttentionBlock(_Emitter):
         Cc, nh = self.channels, self.num_heads
         assert x.C == Cc
         N, T = x.N, x.HW
-        qk_rows, v_rows, d = self._row_maps()
-        if d % prog.epc:
-            raise _lib.EodError(f"attention head dim {d} must be a multiple of {prog.epc} in {prog.precision} mode")
+        qk_rows, v_rows, d, dpad = self._row_maps(prog.epc)
+        Cq = nh * dpad
         w2d = self.qkv.weight.view(3 * Cc, Cc)
         wqk = prog.pack_rows(w2d, qk_rows)
         wv = prog.pack_rows(w2d, v_rows)
         bq = prog.f32(self.qkv.bias)
-        bqk = prog.own(bq[th.tensor(qk_rows, device=bq.device)].contiguous())
+        bq0 = th.cat([bq, bq.new_zeros(1)])  # index -1 -> 0 bias for the padding rows
+        bqk = prog.own(bq0[th.tensor(qk_rows, device=bq.device)].contiguous())
         bv = prog.own(bq[th.tensor(v_rows, device=bq.device)].contiguous())
         wproj = prog.pack_rows(self.proj_out.weight.view(Cc, Cc))
         bproj = prog.f32(self.proj_out.bias)
 
         xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps)
-        # q|k projection: [N*T][2C]
-        qk = prog.empty((N * T, 2 * Cc))
-        prog.gemm(xn.t, wqk, qk, N * T, 2 * Cc, Cc, Cc, Cc, 2 * Cc, bias=bqk, bias_mode=1)
+        # q|k projection: [N*T][2*Cq]
+        qk = prog.empty((N * T, 2 * Cq))
+        prog.gemm(xn.t, wqk, qk, N * T, 2 * Cq, Cc, Cc, Cc, 2 * Cq, bias=bqk, bias_mode=1)
         # v projection, produced TRANSPOSED ([N][C][ldt], keys contiguous) by swapping the GEMM operands:
         # vT[n][c][t] = sum_k Wv[c][k] * xn[n][t][k] + bv[c]
         ldt = round_up(T, prog.epc)
         vT = prog.empty((N, Cc, ldt), zero=True)
         prog.gemm(wv, xn.t, vT, Cc, T, Cc, Cc, Cc, ldt, bias=bv, bias_mode=2, nb0=N, sa=(0, 0), sb=(T * Cc, 0),
                   sc=(Cc * ldt, 0))
-        # S = (q*s)(k*s)^T, s = d^-1/4  ->  alpha = 1/sqrt(d); fp32 scores [N*nh][T][ldt]
+        # S = (q*s)(k*s)^T, s = d^-1/4 (unet_openai.py:475-478)  ->  alpha = 1/sqrt(d); fp32 scores [N*nh][T][ldt]
         S = prog.empty((N * nh, T, ldt), th.float32)
-        prog.gemm(qk, qk, S, T, T, d, 2 * Cc, 2 * Cc, ldt, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
-                  sa=(T * 2 * Cc, d), sb=(T * 2 * Cc, d), sc=(nh * T * ldt, T * ldt), b_off=Cc)
+        prog.gemm(qk, qk, S, T, T, dpad, 2 * Cq, 2 * Cq, ldt, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
+                  sa=(T * 2 * Cq, dpad), sb=(T * 2 * Cq, dpad), sc=(nh * T * ldt, T * ldt), b_off=Cq)
         P = prog.empty((N * nh, T, ldt))
         prog.softmax_rows(S, ldt, P, ldt, N * nh * T, T)
         # a[n][t][h*d + j] = sum_s P[n,h][t][s] * vT[n][h*d + j][s]

@@ -40,8 +40,8 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, long long ld_src
     const long long total = (long long)rows * cols;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(i / cols), c = (int)(i % cols);
-        const int sr = row_map ? row_map[r] : r;
-        dst[(long long)r * ld_dst + c] = cvt<T>(src[(long long)sr * ld_src + c]);
+        const int sr = row_map ? row_map[r] : r;  // a negative source row produces a zero row (padding)
+        dst[(long long)r * ld_dst + c] = cvt<T>(sr >= 0 ? src[(long long)sr * ld_src + c] : 0.0f);
     }
 }
 

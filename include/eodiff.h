@@ -94,7 +94,8 @@ int eod_gemm_nt(const eod_gemm_desc* d, void* stream);
 /* weights: OIHW fp32 (Conv2d.weight, unet_openai.py:21-25) -> [tap][Cout][cin_pad] storage dtype */
 int eod_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int ksize,
                          int cin_pad, void* stream);
-/* generic strided 2-D cast-copy: dst[r][c] = (dtype) src[row_index(r)*ld_src + c]; row_map may be NULL */
+/* generic strided 2-D cast-copy: dst[r][c] = (dtype) src[row_map[r]*ld_src + c]; row_map may be NULL
+ * (identity); a negative row_map entry yields a zero row (K padding of attention heads) */
 int eod_pack_rows(const float* src, int64_t ld_src, const int32_t* row_map, void* dst, int64_t ld_dst,
                   int dtype, int rows, int cols, void* stream);
 

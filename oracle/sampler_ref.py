@@ -1,7 +1,8 @@
 """Oracle: DDPM / DDIM sampler algebra on the CPU (test infrastructure -- see oracle/__init__.py).
 
-Each function replays the exact fp32 torch op sequence of the reference so that the fused HIP
-sampler kernels (built with -ffp-contract=off) can be compared BIT-EXACTLY:
+Each function replays the exact fp32 torch op sequence of the reference (with IEEE correctly-rounded
+sqrt, see _sqrt) so that the fused HIP sampler kernels (built with -ffp-contract=off) can be compared
+BIT-EXACTLY:
 
   q_sample                   diffusion/model.py:94-98   (== ddpm.py:279-282, util.py:113-116)
   ddpm_step_clip             diffusion/model.py:126-150 (given eps_hat instead of calling the UNet)
@@ -15,6 +16,16 @@ sampler kernels (built with -ffp-contract=off) can be compared BIT-EXACTLY:
 """
 import numpy as np
 import torch
+
+
+def _sqrt(x):
+    """IEEE correctly-rounded fp32 sqrt.  torch's AVX512 CPU sqrt is NOT correctly rounded and its
+    result depends on the CPU model (measured: 7/1000 entries of sqrt(alphas_cumprod) off by 1 ulp on the
+    build container, 216/1000 on the EPYC 9575F GPU host; numpy's float32 sqrt and the GPU are exact), so
+    the reference's own bits are machine-dependent here.  The oracle pins the IEEE result."""
+    if not torch.is_tensor(x):
+        x = torch.tensor(x, dtype=torch.float32)
+    return torch.from_numpy(np.sqrt(x.detach().cpu().numpy().astype(np.float32, copy=False))).reshape(x.shape)
 
 
 def _g(table, t, n):
@@ -37,14 +48,14 @@ def ddpm_step_clip(tb, x_t, t, noise, pred):
     alpha_t = _g(tb["alphas"], t, n)
     acp = _g(tb["alphas_cumprod"], t, n)
     beta_t = _g(tb["betas"], t, n)
-    x0 = torch.sqrt(1.0 / acp) * x_t - torch.sqrt(1.0 / acp - 1.0) * pred
+    x0 = _sqrt(1.0 / acp) * x_t - _sqrt(1.0 / acp - 1.0) * pred
     x0 = x0.clamp(-1.0, 1.0)
     if t.min() > 0:
         acp_prev = _g(tb["alphas_cumprod"], t - 1, n)
-        mean = (beta_t * torch.sqrt(acp_prev) / (1.0 - acp)) * x0 + (
-            (1.0 - acp_prev) * torch.sqrt(alpha_t) / (1.0 - acp)
+        mean = (beta_t * _sqrt(acp_prev) / (1.0 - acp)) * x0 + (
+            (1.0 - acp_prev) * _sqrt(alpha_t) / (1.0 - acp)
         ) * x_t
-        std = torch.sqrt(beta_t * (1.0 - acp_prev) / (1.0 - acp))
+        std = _sqrt(beta_t * (1.0 - acp_prev) / (1.0 - acp))
     else:
         mean = (beta_t / (1.0 - acp)) * x0
         std = 0.0
@@ -57,10 +68,10 @@ def ddpm_step_noclip(tb, x_t, t, noise, pred):
     acp = _g(tb["alphas_cumprod"], t, n)
     beta_t = _g(tb["betas"], t, n)
     s1m = _g(tb["sqrt_one_minus_alphas_cumprod"], t, n)
-    mean = (1.0 / torch.sqrt(alpha_t)) * (x_t - ((1.0 - alpha_t) / s1m) * pred)
+    mean = (1.0 / _sqrt(alpha_t)) * (x_t - ((1.0 - alpha_t) / s1m) * pred)
     if t.min() > 0:
         acp_prev = _g(tb["alphas_cumprod"], t - 1, n)
-        std = torch.sqrt(beta_t * (1.0 - acp_prev) / (1.0 - acp))
+        std = _sqrt(beta_t * (1.0 - acp_prev) / (1.0 - acp))
     else:
         std = 0.0
     return mean + std * noise
@@ -91,10 +102,10 @@ def ddim_step(x, e_t, a_t, a_prev, sigma_t, sqrt_1m_at, noise, temperature=1.0):
     a_prev = torch.full((b, 1, 1, 1), float(a_prev))
     sigma_t = torch.full((b, 1, 1, 1), float(sigma_t))
     sqrt_1m_at = torch.full((b, 1, 1, 1), float(sqrt_1m_at))
-    pred_x0 = (x - sqrt_1m_at * e_t) / a_t.sqrt()
-    dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
+    pred_x0 = (x - sqrt_1m_at * e_t) / _sqrt(a_t)
+    dir_xt = _sqrt(1.0 - a_prev - sigma_t ** 2) * e_t
     nz = sigma_t * noise * temperature
-    x_prev = a_prev.sqrt() * pred_x0 + dir_xt + nz
+    x_prev = _sqrt(a_prev) * pred_x0 + dir_xt + nz
     return x_prev, pred_x0
 
 

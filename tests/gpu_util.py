@@ -1,0 +1,31 @@
+"""Helpers for the -m gpu parity tests (HIP path vs CPU oracle / golden fixtures)."""
+import torch
+
+from eo_diffusion_amd import _lib
+from eo_diffusion_amd.engine import Program, round_up
+
+DEV = "cuda:0"
+# stated tolerances (rel-L2 vs the fp32 CPU oracle): SURVEY.md section 8c noise-floor measurements
+TOL = {"fp32": 1e-5, "fp16": 5e-3}
+
+
+def run_program(prec, x_nchw, emit):
+    """x NCHW fp32 (cpu) -> NHWC storage -> emit(prog, act) -> NCHW fp32 (cpu)."""
+    x = x_nchw.to(DEV).float().contiguous()
+    N, C, H, W = x.shape
+    prog = Program(DEV, prec)
+    cp = round_up(C, prog.epc)
+    a, idx = prog.to_nhwc(N, C, 0, H, W, cp)
+    prog.ops[idx].u.small.p[0] = x.data_ptr()
+    y = emit(prog, a)
+    out = torch.empty((y.N, y.C, y.H, y.W), dtype=torch.float32, device=DEV)
+    i2 = prog.to_nchw(y)
+    prog.ops[i2].u.small.p[1] = out.data_ptr()
+    prog.run()
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def load_into(module, sd):
+    missing = module.load_state_dict(sd, strict=True)
+    return module.to(DEV).eval()

@@ -38,3 +38,13 @@ def bits_equal(a, b):
     a = a.contiguous()
     b = b.contiguous()
     return a.shape == b.shape and a.dtype == b.dtype and bool((a.view(torch.int32) == b.view(torch.int32)).all())
+
+
+def close_ulp(a, b, rel=4e-7):
+    """|a-b| <= rel * max(|b|, tiny) elementwise scaled by the tensor's magnitude: a few fp32 ulps.
+    Used where the reference's own bits are machine-dependent (torch's AVX512 CPU sqrt is not correctly
+    rounded, see oracle/sampler_ref.py:_sqrt)."""
+    a = a.double()
+    b = b.double()
+    scale = b.abs().max().clamp_min(1e-30)
+    return bool(((a - b).abs() <= rel * torch.maximum(b.abs(), 1e-3 * scale) * 4).all())
