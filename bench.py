@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- denoising steps/s of the EODiffusion hot path on MI355X.
+
+One *step* = one pass of the hot path over one synthetic batch: Philox noise generation ->
+UNetModel forward (eps prediction) -> fused DDPM reverse update, i.e. one iteration of
+EODiffusion.sampling (model.py:54-69).  Workload at N=1 is the shape BASELINE.json's metric is quoted on:
+256x256x3, batch 16, UNet base 128 / mults [1,2,3,4] / 1 res-block / no extra attention (train.py:50).
+With --gpus N each rank runs the same per-GPU batch (config 4: 8 x 16 = 128 images; weak scaling), no
+per-step communication; the final images are all-gathered once over RCCL.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp16|fp32] [--arch A0|A1] [--size 256] [--batch 16]
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (MFMA implicit-GEMM conv kernel, per-launch
+HIP-event timing on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on the
+host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+ARCHS = {
+    "A0": dict(model_channels=128, channel_mult=[1, 2, 3, 4], attention_resolutions=[], num_res_blocks=1, num_heads=1),
+    "A1": dict(model_channels=128, channel_mult=[1, 2, 3, 4], attention_resolutions=[4, 8], num_res_blocks=2, num_heads=8),
+}
+# algorithmic GFLOP per denoising step, whole batch (conv 2*N*Cout*Ho*Wo*Cin*k*k, linear 2*N*in*out,
+# attention 4*N*T^2*C): A0@256/16 = 10303.7
+PEAK = {"fp16": 2.5e15, "fp32": 157.3e12}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def build_model(arch, size, precision, dev, timesteps=1000, in_ch=3):
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    torch.manual_seed(0)
+    u = UNetModel(size, in_channels=in_ch, out_channels=in_ch, **ARCHS[arch]).set_precision(precision)
+    # the reference zero-initialises every ResBlock's second conv, proj_out and the out conv (zero_module):
+    # re-draw them so the benchmark does real arithmetic end to end (values do not change the work done)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in u.parameters():
+            if p.dim() > 1 and float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    m = EODiffusion(u, timesteps=timesteps, image_size=size, in_channels=in_ch, device=str(dev)).to(dev).eval()
+    return m
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the GPU box
+    gives one GPU's share of the host, 16 cores, while sched_getaffinity still reports all 256)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return min(n, int(os.environ.get("EOD_CPU_THREADS", "16")))
+
+
+def cpu_baseline(arch, size, batch, seconds_budget=25.0):
+    """Oracle (CPU restatement of the reference, oracle/) timed on the host cores: bounded sample."""
+    from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
+    from oracle import sampler_ref, schedule, unet_ref
+    from tests.synth import synth_state_dict
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    cfg = dict(image_size=size, in_channels=3, out_channels=3, **ARCHS[arch])
+    sd = synth_state_dict(unet_param_shapes(**cfg), 7)
+    tb = schedule.eo_cosine_tables(1000)
+    bs = min(batch, 2)
+    x = torch.randn(bs, 3, size, size)
+    t = torch.full((bs,), 500, dtype=torch.int64)
+
+    def step(x):
+        noise = torch.randn_like(x)
+        eps = unet_ref.unet_forward(sd, cfg, x, t)
+        return sampler_ref.ddpm_step_clip(tb, x, t, noise, eps)
+
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        x = step(x)  # warm-up (also a first estimate)
+        warm = time.perf_counter() - t0
+        n = max(1, min(4, int(seconds_budget / max(warm, 1e-3)) - 1))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            x = step(x)
+        dt = (time.perf_counter() - t0) / n
+    steps_per_s_bs = 1.0 / dt
+    return {"value": steps_per_s_bs * bs / batch, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed step(s) of the CPU oracle (UNet fwd + randn + DDPM update) at batch {bs} "
+                      f"({size}x{size}, arch {arch}, {dt:.2f} s/step), scaled by {bs}/{batch} to batch {batch}; torch CPU fp32, "
+                      f"{cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--arch", default="A0", choices=list(ARCHS))
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-timing", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (JSON) here")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")  # RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    m = build_model(args.arch, args.size, args.precision, dev)
+    N, S = args.batch, args.size
+    shape = (N, 3, S, S)
+    seed, sample0 = 3, rank * N
+    x_t = m._philox(shape, dev, 2, sample0, m.timesteps, 0)
+
+    def one_step(x_t, i):
+        noise = m._philox(shape, dev, seed, sample0, i, 1)
+        t = torch.full((N,), i, dtype=torch.int64, device=dev)
+        pred = m.model(x_t, t)
+        return m._ddpm_update(x_t, pred, noise, t, clip=True)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        i = m.timesteps - 1
+        for _ in range(args.warmup):
+            x_t = one_step(x_t, i)
+            i -= 1
+        prog = m.model.program_for(N, 3, 0, S, S, dev, False)
+        timing = not args.no_op_timing
+        if timing:
+            prog.enable_timing(args.steps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            x_t = one_step(x_t, i)
+            i = i - 1 if i > 0 else m.timesteps - 1
+        if world > 1:  # the one collective of the path: gather the final images
+            out = torch.empty((world * N, 3, S, S), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(out, x_t.contiguous())
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    finite = bool(torch.isfinite(x_t).all())
+
+    roof = None
+    if timing:
+        runs, ms = prog.read_timing()
+        stats = prog.op_stats()
+        prog.disable_timing()
+        conv = [(s, t) for s, t in zip(stats, ms) if s["kind"] == "conv" and s["flops"] > 1e9]
+        fl = sum(s["flops"] for s, _ in conv)            # algorithmic flops of the MFMA conv launches, per step
+        tsec = sum(t for _, t in conv) / runs * 1e-3     # their summed duration per step (HIP events)
+        nl = len(conv)
+        roof = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv, all launches of one UNet forward)",
+                "achieved": fl / tsec / 1e12, "peak": PEAK[args.precision] / 1e12, "unit": "TFLOP/s",
+                "frac": fl / tsec / PEAK[args.precision], "traffic": None,
+                "launches_per_step": nl, "avg_launch_ms": tsec * 1e3 / nl, "algorithmic_gflop_per_launch_avg": fl / nl / 1e9,
+                "conv_ms_per_step": tsec * 1e3, "all_ops_ms_per_step": sum(ms) / runs}
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                roof["traffic"] = json.load(open(tf)).get(f"{args.arch}_{args.size}_{args.batch}_{args.precision}")
+            except Exception:
+                pass
+        if args.dump_ops and rank == 0:
+            rows = [dict(s, ms=t / runs) for s, t in zip(stats, ms)]
+            with open(args.dump_ops, "w") as f:
+                json.dump(rows, f, indent=1)
+
+    if rank == 0:
+        steps_per_s = world * args.steps / dt
+        res = {
+            "metric": "denoising steps/sec (UNet fwd + DDPM update) at 256x256 bs=16",
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": f"DDPM sampling step, {S}x{S}x3, batch {N} per GPU, UNet arch {args.arch} "
+                                   f"(base 128, mults [1,2,3,4], {ARCHS[args.arch]['num_res_blocks']} res-block(s), "
+                                   f"attn_res {ARCHS[args.arch]['attention_resolutions']}), Philox noise, x0-clipped update",
+                       "global_batch": world * N, "image_size": S, "parallelism": f"batch-sharded x{world}",
+                       "accumulate": "fp32"},
+            "images_per_sec_1000step_ddpm": world * N / (1000.0 * dt / args.steps),
+            "outputs_finite": finite,
+        }
+        if roof:
+            res["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.arch, S, N)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

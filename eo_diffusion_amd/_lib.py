@@ -70,6 +70,10 @@ SYMBOLS = {
     "eod_ddim_step": (i32, [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]),
     "eod_randn_philox": (i32, [vp, i32, i64, C.c_uint64, i64, i32, i32, vp]),
     "eod_program_run": (i32, [C.POINTER(Op), i32, vp]),
+    "eod_timer_create": (vp, [i32, i32]),
+    "eod_timer_destroy": (None, [vp]),
+    "eod_timer_read": (i32, [vp, C.POINTER(f32)]),
+    "eod_program_run_timed": (i32, [C.POINTER(Op), i32, vp, vp]),
     "eod_resample2x": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
 }
 

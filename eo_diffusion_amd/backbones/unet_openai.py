@@ -591,7 +591,8 @@ class UNetModel(_Emitter):
         # ---- encoder ----
         hs = []
         conv0 = self.input_blocks[0][0]
-        h, _ = prog.conv(a0, prog.pack_conv(conv0.weight, cin_pad=c_pad), prog.f32(conv0.bias), conv0.out_channels)
+        h, i0 = prog.conv(a0, prog.pack_conv(conv0.weight, cin_pad=c_pad), prog.f32(conv0.bias), conv0.out_channels)
+        prog.ops[i0]._cin_alg = cx + ccond  # algorithmic K excludes the zero padding (bench accounting only)
         hs.append(h)
         for blk in list(self.input_blocks)[1:]:
             h = blk._emit(prog, h, ctx)

@@ -41,10 +41,63 @@ extern "C" int eod_struct_size(int kind) {
     }
 }
 
-extern "C" int eod_program_run(const eod_op* ops, int n_ops, void* stream) {
+// ---- per-op HIP-event timer (measurement only; used by bench.py for the roofline numbers) ----
+struct eod_timer {
+    int n_ops, max_runs, runs;
+    hipEvent_t* ev;  // [max_runs][n_ops][2]
+};
+
+extern "C" void* eod_timer_create(int n_ops, int max_runs) {
+    if (n_ops <= 0 || max_runs <= 0) return nullptr;
+    eod_timer* t = new eod_timer{n_ops, max_runs, 0, nullptr};
+    const size_t n = (size_t)n_ops * max_runs * 2;
+    t->ev = new hipEvent_t[n];
+    for (size_t i = 0; i < n; ++i)
+        if (hipEventCreate(&t->ev[i]) != hipSuccess) return nullptr;
+    return t;
+}
+
+extern "C" void eod_timer_destroy(void* h) {
+    eod_timer* t = (eod_timer*)h;
+    if (!t) return;
+    const size_t n = (size_t)t->n_ops * t->max_runs * 2;
+    for (size_t i = 0; i < n; ++i) (void)hipEventDestroy(t->ev[i]);
+    delete[] t->ev;
+    delete t;
+}
+
+// after the stream has been synchronised: ms[k] = SUM over recorded runs of op k's duration; returns #runs
+extern "C" int eod_timer_read(void* h, float* ms) {
+    eod_timer* t = (eod_timer*)h;
+    EOD_REQUIRE(t && ms, "timer_read: bad args");
+    for (int k = 0; k < t->n_ops; ++k) ms[k] = 0.0f;
+    for (int r = 0; r < t->runs; ++r)
+        for (int k = 0; k < t->n_ops; ++k) {
+            float e = 0.0f;
+            hipEvent_t* p = t->ev + ((size_t)r * t->n_ops + k) * 2;
+            if (hipEventElapsedTime(&e, p[0], p[1]) != hipSuccess) {
+                eod_set_error("timer_read: hipEventElapsedTime failed (run %d op %d)", r, k);
+                return EOD_ELAUNCH;
+            }
+            ms[k] += e;
+        }
+    const int runs = t->runs;
+    t->runs = 0;
+    return runs;
+}
+
+static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
     EOD_REQUIRE(ops && n_ops >= 0, "program_run: bad args");
+    hipEvent_t* ev = nullptr;
+    if (tm) {
+        EOD_REQUIRE(tm->n_ops == n_ops, "program_run_timed: timer was created for %d ops, program has %d", tm->n_ops, n_ops);
+        EOD_REQUIRE(tm->runs < tm->max_runs, "program_run_timed: timer full (%d runs)", tm->max_runs);
+        ev = tm->ev + (size_t)tm->runs * n_ops * 2;
+        tm->runs++;
+    }
     for (int k = 0; k < n_ops; ++k) {
         const eod_op& o = ops[k];
+        if (ev) (void)hipEventRecord(ev[2 * k], (hipStream_t)stream);
         const eod_small_desc& s = o.u.small;
         int rc;
         switch (o.kind) {
@@ -77,6 +130,7 @@ extern "C" int eod_program_run(const eod_op* ops, int n_ops, void* stream) {
                 eod_set_error("program_run: op %d has unknown kind %d", k, o.kind);
                 return EOD_EINVAL;
         }
+        if (ev) (void)hipEventRecord(ev[2 * k + 1], (hipStream_t)stream);
         if (rc != EOD_OK) {
             char tmp[400];
             strncpy(tmp, g_err, sizeof(tmp) - 1);
@@ -86,4 +140,10 @@ extern "C" int eod_program_run(const eod_op* ops, int n_ops, void* stream) {
         }
     }
     return EOD_OK;
+}
+
+extern "C" int eod_program_run(const eod_op* ops, int n_ops, void* stream) { return run_impl(ops, n_ops, stream, nullptr); }
+extern "C" int eod_program_run_timed(const eod_op* ops, int n_ops, void* stream, void* timer) {
+    EOD_REQUIRE(timer, "program_run_timed: null timer");
+    return run_impl(ops, n_ops, stream, (eod_timer*)timer);
 }

@@ -56,6 +56,7 @@ class Program:
         self.keep = []       # tensors owned by the program
         self.bindings = {}   # name -> list[(op_index, setter)]
         self._arr = None
+        self._timer = None
         self.L = _lib.lib()
         self.nbytes = 0
 
@@ -244,7 +245,68 @@ class Program:
         if self._arr is None:
             self.finalize()
         st = stream if stream is not None else current_stream_ptr(self.device)
-        check(self.L.eod_program_run(self._arr, len(self.ops), st), "eod_program_run")
+        if self._timer:
+            check(self.L.eod_program_run_timed(self._arr, len(self.ops), st, self._timer), "eod_program_run_timed")
+        else:
+            check(self.L.eod_program_run(self._arr, len(self.ops), st), "eod_program_run")
+
+    # ------------------------------------------------------------------ measurement (bench.py)
+    def enable_timing(self, max_runs):
+        """bracket every op with HIP events on the launch stream for the next `max_runs` runs"""
+        self.disable_timing()
+        self._timer = self.L.eod_timer_create(len(self.ops), max_runs)
+        if not self._timer:
+            raise _lib.EodError("eod_timer_create failed")
+
+    def read_timing(self):
+        """(runs, [ms summed over runs] per op); call after synchronising the stream"""
+        buf = (C.c_float * len(self.ops))()
+        runs = self.L.eod_timer_read(self._timer, buf)
+        if runs < 0:
+            check(runs, "eod_timer_read")
+        return runs, list(buf)
+
+    def disable_timing(self):
+        if getattr(self, "_timer", None):
+            self.L.eod_timer_destroy(self._timer)
+        self._timer = None
+
+    def op_stats(self):
+        """algorithmic work per op: list of dicts(kind, flops, bytes, label) from the descriptors"""
+        es = self.tdtype.itemsize
+        out = []
+        for op in self.ops:
+            k = op.kind
+            if k == OP_CONV:
+                d = op.u.conv
+                cin = d.C0 + d.C1
+                m = d.N * d.Ho * d.Wo
+                cin_alg = getattr(op, "_cin_alg", cin)
+                fl = 2.0 * m * d.Cout * cin_alg * d.ksize * d.ksize
+                by = es * (d.N * d.H * d.W * cin + d.ksize * d.ksize * d.Cout * cin + (0 if d.out_nchw_f32 else m * d.Cout)) \
+                    + (4 * m * d.Cout if d.out_nchw_f32 else 0) + (es * m * d.Cout if d.res else 0)
+                out.append(dict(kind="conv", flops=fl, bytes=by,
+                                label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"))
+            elif k == OP_GEMM:
+                d = op.u.gemm
+                nb = d.nb0 * d.nb1
+                out.append(dict(kind="gemm", flops=2.0 * nb * d.M * d.N * d.K,
+                                bytes=es * nb * (d.M * d.K + d.N * d.K) + (4 if d.c_f32 else es) * nb * d.M * d.N,
+                                label=f"gemm {nb}x[{d.M}x{d.N}x{d.K}]"))
+            elif k in (OP_GN_PARTIAL, OP_GN_APPLY):
+                s = op.u.small
+                n, hw, c = (s.i[1], s.i[2], s.i[3])
+                by = es * n * hw * c * (1 if k == OP_GN_PARTIAL else 2)
+                out.append(dict(kind="gn_partial" if k == OP_GN_PARTIAL else "gn_apply", flops=0.0, bytes=by,
+                                label=f"gn {hw}px {c}ch"))
+            elif k == OP_SOFTMAX:
+                s = op.u.small
+                out.append(dict(kind="softmax", flops=0.0, bytes=s.l[2] * (4 * s.i[1] + es * s.l[1]), label="softmax"))
+            else:
+                out.append(dict(kind={OP_GN_FINALIZE: "gn_finalize", OP_TEMB: "temb", OP_TO_NHWC: "to_nhwc",
+                                      OP_TO_NCHW: "to_nchw", OP_POOL: "resample"}.get(k, str(k)), flops=0.0, bytes=0.0,
+                                label=""))
+        return out
 
 
 def round_up(v, m):

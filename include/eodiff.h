@@ -198,6 +198,13 @@ typedef struct {
     } u;
 } eod_op;
 int eod_program_run(const eod_op* ops, int n_ops, void* stream);
+/* Measurement variant: brackets every op with HIP events recorded on `stream` (the stream the kernels run
+ * on).  timer = eod_timer_create(n_ops, max_runs); after a stream sync, eod_timer_read() returns the number
+ * of recorded runs and fills ms[n_ops] with each op's duration summed over those runs. */
+void* eod_timer_create(int n_ops, int max_runs);
+void eod_timer_destroy(void* timer);
+int eod_timer_read(void* timer, float* ms);
+int eod_program_run_timed(const eod_op* ops, int n_ops, void* stream, void* timer);
 /* resblock_updown helpers (unet_openai.py:320-325): mode 0 = 2x2 average pool, 1 = nearest 2x */
 int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y,
                    void* stream);
