@@ -10,18 +10,31 @@
 //  * 256 threads = 4 waves per workgroup, one BM x BN output tile, 32x32 MFMA sub-tiles per wave:
 //      fp16 storage : v_mfma_f32_32x32x16_f16  (8 halves / lane / operand, fp32 accumulate)
 //      fp32 storage : v_mfma_f32_32x32x2_f32   (exact fp32, 4 instructions per 16-byte chunk)
-//    Both consume the SAME 16-byte-chunk LDS image: lane (r = lane&31, h = lane>>5) reads chunk 2s+h of
-//    row r for k-substep s, so the kernel body is byte-oriented and the dtype only appears in mma().
-//  * global -> registers -> LDS staging, double-buffered, one barrier per K-step; next tile's global
-//    loads are issued before the MFMAs of the current one (guide T14).  LDS rows are padded by 16 B
-//    (row stride 80 / 144 B), which makes every ds_read_b128 lane group bank-conflict-free.
+//    Both consume the SAME 16-byte-chunk LDS image (K-step = 128 bytes per row = 8 chunks): lane
+//    (r = lane&31, h = lane>>5) reads chunk 2s+h of row r for k-substep s, so the kernel body is
+//    byte-oriented and the dtype only appears in Mma<T>.
+//  * Staging is LDS-DMA: `global_load_lds_dwordx4` writes 64 lanes x 16 B = 8 rows x 128 B straight into
+//    LDS with no VGPR round trip and no ds_write.  The LDS destination of that instruction is lane-linear,
+//    so the bank-conflict swizzle lives on the SOURCE address (guide rule 21): lane (row r, slot j) fetches
+//    global chunk j ^ ((r>>1)&7); readers apply the same XOR.  With 128-byte rows every ds_read_b128 lane
+//    group then touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+//    Masked elements (image border = conv zero padding, K / M / N tails) are fetched from a 16-byte zero
+//    page in global memory, so no lane ever branches around its load.
+//  * 2-stage LDS ring, ONE barrier per K-step: the DMA of K-step t+1 is in flight while the MFMAs of step
+//    t run; 64-70 KiB of LDS per workgroup leaves two workgroups per CU to cover each other's waits.
 //  * K loop order is channel-chunk OUTER, filter tap INNER: the 9 taps of one channel chunk re-read the
-//    same (BM + halo) x BK input bytes, which stay in the CU's 32 KiB L1.
+//    same (BM + halo) x 128 B of input, which stays in the CU's L1.  Per-slot state is a 32-bit pixel
+//    offset and a 9-bit tap-validity mask: no 64-bit multiply or divide in the loop.
 //  * M tiles are TH x TW pixel patches when the feature map allows it (halo reuse in L1), linear runs
 //    of BM pixels otherwise (ragged shapes: 28x28, 7x7, 3x3...).
+//  * Epilogue: per-column bias / timestep bias are added in the MFMA C layout (lane = output column), the
+//    tile is transposed through LDS (fp32) and written as full 16-byte chunks along the channel axis with
+//    the residual added on the way: whole 128/256-byte lines per row instead of 2-byte scattered stores.
 //  * workgroup -> tile mapping is XCD-aware (bijective remap, guide T1): the N-tiles of one M-tile and
 //    neighbouring M-tiles land on the same XCD's L2.
 #include "common.h"
+
+__device__ __attribute__((aligned(16))) int g_eod_zero_page[4] = {0, 0, 0, 0};
 
 struct IgemmP {
     const char* a0;
@@ -59,30 +72,33 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T> __device__ __forceinline__ float ld_elem(const char* p, long long idx) {
-    return (float)reinterpret_cast<const T*>(p)[idx];
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst_wave_uniform) {
+    // 64 lanes x 16 B -> lds_dst + lane*16 (the destination is wave-uniform base + lane*16 by hardware)
+    __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_dst_wave_uniform, 16, 0, 0);
 }
 
-template <typename T, bool CONV, int BM, int BN, int BKB, int WAVES_M, int WAVES_N>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     constexpr int ES = sizeof(T);
-    constexpr int EPC = 16 / ES;      // elements per 16-byte chunk
-    constexpr int BK = BKB / ES;      // elements per K-step
-    constexpr int CH = BKB / 16;      // chunks per row per K-step
-    constexpr int ROWB = BKB + 16;    // padded LDS row stride
+    constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
+    constexpr int BKB = 128;       // bytes of K per row per K-step
+    constexpr int BK = BKB / ES;   // elements per K-step
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int LA = BM * CH / 256, LB = (BN * CH + 255) / 256;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    static_assert(BM * CH % 256 == 0, "A staging");
+    constexpr int GA = BM / 8, GB = BN / 8;              // 8-row groups (one glds instruction each)
+    constexpr int LA = GA / 4, LB = (GB + 3) / 4;        // groups per wave
+    constexpr int STAGE_A = BM * BKB, STAGE = (BM + BN) * BKB;
+    constexpr int EP_LD = WN + 4;                        // fp32 epilogue row stride (floats)
+    static_assert(WAVES_M * WAVES_N == 4 && GA % 4 == 0, "layout");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;
-    char* sB = smem + 2 * BM * ROWB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     // ---- XCD-aware tile mapping (bijective) ----
@@ -96,67 +112,113 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     }
     const int n0 = tile_n * BN;
 
-    // gemm-mode batch offsets (elements)
-    long long offA = 0, offB = 0, offC = 0;
-    if constexpr (!CONV) {
+    // ---- tile origin (wave-uniform) ----
+    // conv: image index of the tile's first row and that row's linear pixel index inside the image; all
+    // per-lane offsets are taken relative to that image so they fit 32 bits.
+    long long offA = 0, offB = 0, offC = 0;  // gemm batch offsets (elements)
+    int n_first = 0, rem_first = 0, ty0 = 0, tx0 = 0;
+    if constexpr (CONV) {
+        if (p.tw_log2 >= 0) {
+            n_first = tile_m / p.tiles_pi;
+            const int t = tile_m - n_first * p.tiles_pi;
+            const int ty = t / p.tiles_pw;
+            ty0 = ty * p.th;
+            tx0 = (t - ty * p.tiles_pw) << p.tw_log2;
+        } else {
+            const long long m0 = (long long)tile_m * BM;
+            n_first = (int)(m0 / p.HoWo);
+            rem_first = (int)(m0 - (long long)n_first * p.HoWo);
+        }
+    } else {
         const int z = blockIdx.y;
-        const int b0 = z / p.nb1, b1 = z % p.nb1;
+        const int b0 = z / p.nb1, b1 = z - b0 * p.nb1;
         offA = b0 * p.sa0 + b1 * p.sa1;
         offB = b0 * p.sb0 + b1 * p.sb1;
         offC = b0 * p.sc0 + b1 * p.sc1;
     }
 
-    auto decode_row = [&](int r, int& n, int& ho, int& wo, long long& m) -> bool {
+    // row r of the tile -> (image index relative to n_first, ho, wo); false if past the end
+    auto decode_row = [&](int r, int& nrel, int& ho, int& wo) -> bool {
         if (p.tw_log2 >= 0) {
-            n = tile_m / p.tiles_pi;
-            const int t = tile_m - n * p.tiles_pi;
-            const int ty = t / p.tiles_pw, tx = t - ty * p.tiles_pw;
-            ho = ty * p.th + (r >> p.tw_log2);
-            wo = (tx << p.tw_log2) + (r & ((1 << p.tw_log2) - 1));
-            m = ((long long)n * p.Ho + ho) * p.Wo + wo;
-            return n < p.N;
+            nrel = 0;
+            ho = ty0 + (r >> p.tw_log2);
+            wo = tx0 + (r & ((1 << p.tw_log2) - 1));
+            return true;
         }
-        m = (long long)tile_m * BM + r;
-        n = (int)(m / p.HoWo);
-        const int rem = (int)(m - (long long)n * p.HoWo);
+        int rem = rem_first + r;
+        nrel = 0;
+        if (rem >= p.HoWo) {  // a tile may straddle images (or span several when the map is tiny)
+            nrel = rem / p.HoWo;
+            rem -= nrel * p.HoWo;
+        }
         ho = rem / p.Wo;
         wo = rem - ho * p.Wo;
-        return m < p.M;
+        return (long long)tile_m * BM + r < p.M;
     };
 
-    // ---- per-thread staging slots ----
-    int a_n[LA], a_bh[LA], a_bw[LA];
-    bool a_ok[LA];
-    long long a_row[LA];  // gemm: row element offset
+    // ---- per-thread staging slots: group g = wave + 4*i, row = g*8 + (lane>>3), slot = lane&7 ----
+    const int srow = lane >> 3, sslot = lane & 7;
+    unsigned a_off[LA];       // conv: pixel index (relative to image n_first) of tap (0,0); upsample: row base
+    unsigned a_mask[LA];      // conv: bit t set <=> tap t reads inside the image (and the row exists)
+    int a_bh[LA], a_bw[LA];   // conv + upsample only
+    long long a_rowoff[LA];   // gemm: element offset of the row
+    int a_chunk[LA];          // swizzled chunk index this lane fetches
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int c = tid + i * 256, row = c / CH;
+        const int row = (wave + 4 * i) * 8 + srow;
+        a_chunk[i] = sslot ^ ((row >> 1) & 7);
+        a_off[i] = 0;
+        a_mask[i] = 0;
+        a_bh[i] = a_bw[i] = 0;
+        a_rowoff[i] = 0;
         if constexpr (CONV) {
-            int n, ho, wo;
-            long long m;
-            a_ok[i] = decode_row(row, n, ho, wo, m);
-            a_n[i] = n;
-            a_bh[i] = ho * p.stride - p.pad - p.pad_tl;
-            a_bw[i] = wo * p.stride - p.pad - p.pad_tl;
+            int nrel, ho, wo;
+            const bool ok = decode_row(row, nrel, ho, wo);
+            const int bh = ho * p.stride - p.pad - p.pad_tl, bw = wo * p.stride - p.pad - p.pad_tl;
+            a_bh[i] = bh;
+            a_bw[i] = bw;
+            unsigned mask = 0;
+            if (ok) {
+                for (int t = 0; t < p.taps; ++t) {
+                    const int dy = (p.KS == 3) ? t / 3 : 0, dx = (p.KS == 3) ? t - dy * 3 : 0;
+                    if ((unsigned)(bh + dy) < (unsigned)p.Heff && (unsigned)(bw + dx) < (unsigned)p.Weff) mask |= 1u << t;
+                }
+            }
+            a_mask[i] = mask;
+            // unsigned wrap-around is intended: border rows have bh/bw = -1 and only valid taps are dereferenced
+            a_off[i] = p.ups ? (unsigned)(nrel * p.H) : (unsigned)((nrel * p.H + bh) * p.W + bw);
         } else {
             const long long m = (long long)tile_m * BM + row;
-            a_ok[i] = m < p.M;
-            a_row[i] = offA + m * p.lda;
+            a_mask[i] = m < p.M ? 1u : 0u;
+            a_rowoff[i] = offA + m * p.lda;
         }
     }
+    long long b_rowoff[LB];  // element offset of the B row (without the per-step uniform part)
     bool b_ok[LB];
-    int b_co[LB];
+    int b_chunk[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int c = tid + i * 256, row = c / CH;
-        b_co[i] = n0 + row;
-        b_ok[i] = (row < BN) && (b_co[i] < p.Ncols);
+        const int g = wave + 4 * i;
+        const int row = g * 8 + srow;
+        const int co = n0 + row;
+        b_chunk[i] = sslot ^ ((row >> 1) & 7);
+        b_ok[i] = (g < GB) && (co < p.Ncols);
+        if constexpr (CONV)
+            b_rowoff[i] = (long long)co * p.Cin;
+        else
+            b_rowoff[i] = offB + (long long)co * p.ldb;
     }
 
-    i32x4 ra[LA], rb[LB];
-    const i32x4 zero4 = {0, 0, 0, 0};
+    const char* zero_page = reinterpret_cast<const char*>(g_eod_zero_page);
+    const char* a0_img = p.a0;
+    const char* a1_img = p.a1;
+    if constexpr (CONV) {
+        a0_img = p.a0 + (long long)n_first * p.H * p.W * p.C0 * ES;
+        if (p.a1) a1_img = p.a1 + (long long)n_first * p.H * p.W * p.C1 * ES;
+    }
 
-    auto load_tile = [&](int kt) {
+    auto issue_loads = [&](int kt, int stage) {
+        char* sbase = smem + stage * STAGE;
         int tap = 0, c0;
         if constexpr (CONV) {
             const int cc = kt / p.taps;
@@ -172,57 +234,45 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
                 dx = tap - dy * 3;
             }
         }
+        const int tapoff = dy * p.W + dx;  // conv, no upsample
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int c = tid + i * 256, ch = c % CH;
-            const int k = c0 + ch * EPC;
-            // always issue the load (from a safe address when masked) and select afterwards: a
-            // branch around each load would serialise them behind per-load vmcnt(0) waits
-            const char* src = p.a0;
-            bool ok;
+            const int k = c0 + a_chunk[i] * EPC;
+            const char* src = zero_page;
             if constexpr (CONV) {
-                int hi = a_bh[i] + dy, wi = a_bw[i] + dx;
-                ok = a_ok[i] && (k < p.Cin) && ((unsigned)hi < (unsigned)p.Heff) && ((unsigned)wi < (unsigned)p.Weff);
+                const bool ok = ((a_mask[i] >> tap) & 1u) && (k < p.Cin);
+                unsigned pix;
                 if (p.ups) {
-                    hi >>= 1;
-                    wi >>= 1;
+                    pix = (a_off[i] + (unsigned)((a_bh[i] + dy) >> 1)) * (unsigned)p.W + (unsigned)((a_bw[i] + dx) >> 1);
+                } else {
+                    pix = a_off[i] + (unsigned)tapoff;
                 }
-                const long long pix = ((long long)a_n[i] * p.H + hi) * p.W + wi;
-                if (ok) src = (k < p.C0) ? p.a0 + (pix * p.C0 + k) * ES : p.a1 + (pix * p.C1 + (k - p.C0)) * ES;
+                const bool s0 = k < p.C0;
+                const char* base = s0 ? a0_img : a1_img;
+                const unsigned cw = s0 ? (unsigned)p.C0 : (unsigned)p.C1;
+                const unsigned kk = s0 ? (unsigned)k : (unsigned)(k - p.C0);
+                const unsigned long long boff = ((unsigned long long)pix * cw + kk) * ES;
+                if (ok) src = base + boff;
             } else {
-                ok = a_ok[i] && k < p.K;
-                if (ok) src = p.a0 + (a_row[i] + k) * ES;
+                const bool ok = a_mask[i] && (k < p.K);
+                if (ok) src = p.a0 + (a_rowoff[i] + k) * ES;
             }
-            const i32x4 v = *reinterpret_cast<const i32x4*>(src);
-            ra[i] = ok ? v : zero4;
+            glds16(src, sbase + (wave + 4 * i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int c = tid + i * 256, ch = c % CH;
-            const int k = c0 + ch * EPC;
-            const char* src = p.b;
-            bool ok;
-            if constexpr (CONV) {
-                ok = b_ok[i] && k < p.Cin;
-                if (ok) src = p.b + (((long long)tap * p.Cout + b_co[i]) * p.Cin + k) * ES;
-            } else {
-                ok = b_ok[i] && k < p.K;
-                if (ok) src = p.b + (offB + (long long)b_co[i] * p.ldb + k) * ES;
+            if ((wave + 4 * i) < GB) {  // wave-uniform
+                const int k = c0 + b_chunk[i] * EPC;
+                const char* src = zero_page;
+                if constexpr (CONV) {
+                    const bool ok = b_ok[i] && (k < p.Cin);
+                    if (ok) src = p.b + ((long long)tap * p.Cout * p.Cin + b_rowoff[i] + k) * ES;
+                } else {
+                    const bool ok = b_ok[i] && (k < p.K);
+                    if (ok) src = p.b + (b_rowoff[i] + k) * ES;
+                }
+                glds16(src, sbase + STAGE_A + (wave + 4 * i) * 1024);
             }
-            const i32x4 v = *reinterpret_cast<const i32x4*>(src);
-            rb[i] = ok ? v : zero4;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int c = tid + i * 256, row = c / CH, ch = c % CH;
-            *reinterpret_cast<i32x4*>(sA + buf * BM * ROWB + row * ROWB + ch * 16) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int c = tid + i * 256, row = c / CH, ch = c % CH;
-            if (row < BN) *reinterpret_cast<i32x4*>(sB + buf * BN * ROWB + row * ROWB + ch * 16) = rb[i];
         }
     };
 
@@ -234,34 +284,42 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // ---- fragment read offsets: row (wm*WM + i*32 + lr), chunk (2s + lh) ^ ((row>>1)&7) ----
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (lr >> 1) & 7;  // (row>>1)&7 == (lr>>1)&7: the wave / tile row offsets are multiples of 16
+    int coff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) coff[s] = ((2 * s + lh) ^ sw) * 16;
+    const int a_rd = (wm * WM + lr) * BKB;
+    const int b_rd = STAGE_A + (wn * WN + lr) * BKB;
+
     const int KT = p.KT;
-    load_tile(0);
-    store_tile(0);
+    issue_loads(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int lr = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
-        const char* bA = sA + buf * BM * ROWB + (wm * WM + lr) * ROWB + lh * 16;
-        const char* bB = sB + buf * BN * ROWB + (wn * WN + lr) * ROWB + lh * 16;
+        const int stage = kt & 1;
+        if (kt + 1 < KT) issue_loads(kt + 1, stage ^ 1);
+        const char* sb = smem + stage * STAGE;
 #pragma unroll
-        for (int s = 0; s < BKB / 32; ++s) {
+        for (int s = 0; s < 4; ++s) {
             i32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const i32x4*>(bA + i * 32 * ROWB + s * 32);
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + coff[s]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const i32x4*>(bB + j * 32 * ROWB + s * 32);
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + coff[s]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
-        if (kt + 1 < KT) store_tile(buf ^ 1);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed ...
+        __syncthreads();                                   // ... and every wave is done reading this one
     }
 
-    // ---- epilogue: lane = output column, registers = 16 rows of the 32x32 tile ----
+    // =========================== epilogue ===========================
+    // 1) C layout (lane = column): alpha, per-column bias; conv: per-sample bias needs the row's image.
     int col[TN];
     bool cok[TN];
     float bcol[TN];
@@ -271,42 +329,120 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
         cok[j] = col[j] < p.Ncols;
         bcol[j] = (cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f;
     }
+
+    if (CONV && p.out_nchw) {
+        // tiny-Cout head writing the API layout (NCHW fp32) directly: scalar stores, negligible bytes
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if constexpr (CONV) {
-                int n, ho, wo;
-                long long m;
-                if (!decode_row(row, n, ho, wo, m)) continue;
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int nrel, ho, wo;
+                if (!decode_row(row, nrel, ho, wo)) continue;
+                const int n = n_first + nrel;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (!cok[j]) continue;
                     float v = acc[i][j][r] * p.alpha + bcol[j];
                     if (p.cbias) v += p.cbias[(long long)n * p.cbias_stride + col[j]];
-                    if (p.out_nchw) {
-                        reinterpret_cast<float*>(p.y)[((long long)n * p.Cout + col[j]) * p.HoWo + (long long)ho * p.Wo + wo] = v;
-                    } else {
-                        const long long o = m * p.Cout + col[j];
-                        if (p.res) v += ld_elem<T>(p.res, o);
-                        reinterpret_cast<T*>(p.y)[o] = (T)v;
-                    }
+                    reinterpret_cast<float*>(p.y)[((long long)n * p.Cout + col[j]) * p.HoWo + (long long)ho * p.Wo + wo] = v;
+                }
+            }
+        return;
+    }
+
+    // 2) transpose through LDS: each wave owns a [WM][EP_LD] fp32 slab (the ring is free after the last barrier)
+    float* slab = reinterpret_cast<float*>(smem) + wave * (WM * EP_LD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rw = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside the wave's slab
+            float cb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) cb[j] = 0.0f;
+            if constexpr (CONV) {
+                if (p.cbias) {
+                    int nrel, ho, wo;
+                    decode_row(wm * WM + rw, nrel, ho, wo);
+                    const float* cbp = p.cbias + (long long)(n_first + nrel) * p.cbias_stride;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) cb[j] = cok[j] ? cbp[col[j]] : 0.0f;
                 }
             } else {
-                const long long m = (long long)tile_m * BM + row;
-                if (m >= p.M) continue;
-                const float brow = (p.bias && p.bias_mode == 2) ? p.bias[m] : 0.0f;
+                if (p.bias && p.bias_mode == 2) {
+                    const long long m = (long long)tile_m * BM + wm * WM + rw;
+                    const float br = m < p.M ? p.bias[m] : 0.0f;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (!cok[j]) continue;
-                    float v = acc[i][j][r] * p.alpha + bcol[j] + brow;
-                    const long long o = offC + m * p.ldc + col[j];
-                    if (p.res) v += p.c_f32 ? reinterpret_cast<const float*>(p.res)[o] : ld_elem<T>(p.res, o);
-                    if (p.c_f32)
-                        reinterpret_cast<float*>(p.y)[o] = v;
-                    else
-                        reinterpret_cast<T*>(p.y)[o] = (T)v;
+                    for (int j = 0; j < TN; ++j) cb[j] = br;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * 32 + lr] = acc[i][j][r] * p.alpha + bcol[j] + cb[j];
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
+    __builtin_amdgcn_wave_barrier();
+
+    // 3) row-major read-back: each lane handles 16-byte output chunks of one row
+    const bool out_f32 = (!CONV && p.c_f32) || ES == 4;
+    const int epo = out_f32 ? 4 : 8;           // elements per 16-byte output chunk
+    const int cpr = WN / epo;                  // chunks per row of the wave's slab
+    const int total = WM * cpr;
+    const int ncol0 = n0 + wn * WN;
+    for (int f = lane; f < total; f += 64) {
+        const int rw = f / cpr, cj = (f - rw * cpr) * epo;
+        const int c = ncol0 + cj;
+        if (c >= p.Ncols) continue;
+        long long o;  // element offset of (row, c) in the output
+        if constexpr (CONV) {
+            int nrel, ho, wo;
+            if (!decode_row(wm * WM + rw, nrel, ho, wo)) continue;
+            o = ((((long long)(n_first + nrel) * p.Ho + ho) * p.Wo + wo)) * p.Cout + c;
+        } else {
+            const long long m = (long long)tile_m * BM + wm * WM + rw;
+            if (m >= p.M) continue;
+            o = offC + m * p.ldc + c;
+        }
+        const float* sp = slab + rw * EP_LD + cj;
+        const bool full = (c + epo <= p.Ncols) && (((o * (out_f32 ? 4 : 2)) & 15) == 0);
+        if (out_f32) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+            float* yo = reinterpret_cast<float*>(p.y) + o;
+            const float* ro = p.res ? reinterpret_cast<const float*>(p.res) + o : nullptr;
+            if (full) {
+                if (ro) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(ro);
+                    v += rv;
+                }
+                *reinterpret_cast<f32x4*>(yo) = v;
+            } else {
+                for (int e = 0; e < 4 && c + e < p.Ncols; ++e) yo[e] = v[e] + (ro ? ro[e] : 0.0f);
+            }
+        } else {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            half_t* yo = reinterpret_cast<half_t*>(p.y) + o;
+            const half_t* ro = p.res ? reinterpret_cast<const half_t*>(p.res) + o : nullptr;
+            if (full) {
+                half8 h;
+                if (ro) {
+                    const half8 rv = *reinterpret_cast<const half8*>(ro);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = (half_t)(v0[e] + (float)rv[e]);
+                        h[e + 4] = (half_t)(v1[e] + (float)rv[e + 4]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = (half_t)v0[e];
+                        h[e + 4] = (half_t)v1[e];
+                    }
+                }
+                *reinterpret_cast<half8*>(yo) = h;
+            } else {
+                for (int e = 0; e < 8 && c + e < p.Ncols; ++e) {
+                    const float x = (e < 4 ? v0[e] : v1[e - 4]) + (ro ? (float)ro[e] : 0.0f);
+                    yo[e] = (half_t)x;
                 }
             }
         }
@@ -314,12 +450,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------ host side
-template <typename T, bool CONV, int BM, int BN, int BKB, int WAVES_M, int WAVES_N>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
-    constexpr int ROWB = BKB + 16;
-    constexpr int BK = BKB / (int)sizeof(T);
-    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    auto kern = igemm_kernel<T, CONV, BM, BN, BKB, WAVES_M, WAVES_N>;
+    constexpr int BK = 128 / (int)sizeof(T);
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    const size_t ring = 2 * (size_t)(BM + BN) * 128;
+    const size_t epi = 4 * (size_t)WM * (WN + 4) * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N>;
     static bool attr_done = false;  // >64 KiB dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -329,9 +467,9 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     const int kc = (kdim + BK - 1) / BK;
     p.KT = kc * p.taps;
     p.tiles_n = (p.Ncols + BN - 1) / BN;
+    p.tw_log2 = -1;
     if (CONV) {
         // patch mode: TW = min(16, Wo) if it is a power of two dividing Wo and TH = BM/TW divides Ho
-        p.tw_log2 = -1;
         int tw = 16;
         while (tw > p.Wo) tw >>= 1;
         if (tw >= 4 && p.Wo % tw == 0 && (BM % tw) == 0 && p.Ho % (BM / tw) == 0) {
@@ -346,7 +484,6 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
             p.tiles_m = (int)((p.M + BM - 1) / BM);
         }
     } else {
-        p.tw_log2 = -1;
         p.tiles_m = (int)((p.M + BM - 1) / BM);
     }
     const long long nblk = (long long)p.tiles_m * p.tiles_n;
@@ -360,14 +497,9 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
 }
 
 template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipStream_t st) {
-    const int kdim_bytes = (CONV ? p.Cin : p.K) * (int)sizeof(T);
-    const bool small_k = kdim_bytes <= 64;
-    if (p.Ncols <= 32) {
-        return small_k ? launch_cfg<T, CONV, 128, 32, 64, 4, 1>(p, batch, st) : launch_cfg<T, CONV, 128, 32, 128, 4, 1>(p, batch, st);
-    } else if (p.Ncols <= 64) {
-        return small_k ? launch_cfg<T, CONV, 128, 64, 64, 4, 1>(p, batch, st) : launch_cfg<T, CONV, 128, 64, 128, 4, 1>(p, batch, st);
-    }
-    return small_k ? launch_cfg<T, CONV, 128, 128, 64, 2, 2>(p, batch, st) : launch_cfg<T, CONV, 128, 128, 128, 2, 2>(p, batch, st);
+    if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1>(p, batch, st);
+    if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1>(p, batch, st);
+    return launch_cfg<T, CONV, 128, 128, 2, 2>(p, batch, st);
 }
 
 extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
@@ -386,6 +518,9 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     EOD_REQUIRE(Ho == d->Ho && Wo == d->Wo, "conv: Ho/Wo mismatch: got %dx%d, geometry gives %dx%d", d->Ho, d->Wo, Ho, Wo);
     EOD_REQUIRE(!(d->out_nchw_f32 && d->res), "conv: residual not supported with NCHW output");
+    // per-lane source offsets are 32-bit pixel indices relative to the tile's first image; a 128-row tile spans
+    // at most 129 images (1x1 maps), so bound the pixel index range conservatively
+    EOD_REQUIRE((long long)d->H * d->W * 130 < 0x7fffffffLL, "conv: feature map too large for 32-bit tile-relative indexing");
     IgemmP p = {};
     p.a0 = (const char*)d->x;
     p.a1 = (const char*)d->x2;
