@@ -18,13 +18,17 @@
 //    so the bank-conflict swizzle lives on the SOURCE address (guide rule 21): lane (row r, slot j) fetches
 //    global chunk j ^ ((r>>1)&7); readers apply the same XOR.  With 128-byte rows every ds_read_b128 lane
 //    group then touches 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
-//    Masked elements (image border = conv zero padding, K / M / N tails) are fetched from a 16-byte zero
-//    page in global memory, so no lane ever branches around its load.
+//    The DMA goes through buffer descriptors (`buffer_load_dwordx4 ... lds`): the per-lane part of the address
+//    is one 32-bit byte offset relative to the tile's first image / row, the per-K-step part (filter tap,
+//    channel chunk) is a wave-uniform SGPR offset, and masked elements (image border = conv zero padding,
+//    K / M / N tails) simply use an out-of-range offset: the hardware range check then writes ZEROS into LDS
+//    (verified on gfx950), so no lane branches around its load and there is no pointer select.
 //  * 2-stage LDS ring, ONE barrier per K-step: the DMA of K-step t+1 is in flight while the MFMAs of step
 //    t run; 64-70 KiB of LDS per workgroup leaves two workgroups per CU to cover each other's waits.
-//  * K loop order is channel-chunk OUTER, filter tap INNER: the 9 taps of one channel chunk re-read the
-//    same (BM + halo) x 128 B of input, which stays in the CU's L1.  Per-slot state is a 32-bit pixel
-//    offset and a 9-bit tap-validity mask: no 64-bit multiply or divide in the loop.
+//  * K loop order is (concat source, channel chunk) OUTER, filter tap INNER: the 9 taps of one channel
+//    chunk re-read the same (BM + halo) x 128 B of input, which stays in the CU's L1.  Per-slot state is a
+//    32-bit byte offset and a 9-bit tap-validity mask; (tap, chunk, source) are scalar counters: no 64-bit
+//    arithmetic and no division in the loop (the first version spent 8 VALU + 9 SALU per MFMA there).
 //  * M tiles are TH x TW pixel patches when the feature map allows it (halo reuse in L1), linear runs
 //    of BM pixels otherwise (ragged shapes: 28x28, 7x7, 3x3...).
 //  * Epilogue: per-column bias / timestep bias are added in the MFMA C layout (lane = output column), the
@@ -33,8 +37,6 @@
 //  * workgroup -> tile mapping is XCD-aware (bijective remap, guide T1): the N-tiles of one M-tile and
 //    neighbouring M-tiles land on the same XCD's L2.
 #include "common.h"
-
-__device__ __attribute__((aligned(16))) int g_eod_zero_page[4] = {0, 0, 0, 0};
 
 struct IgemmP {
     const char* a0;
@@ -55,6 +57,7 @@ struct IgemmP {
     // common
     long long M;
     int Ncols, K, taps, KT, tiles_m, tiles_n, out_nchw;
+    int kc0, kc1;  // conv: channel chunks of source 0 / source 1 (K-steps = taps * (kc0 + kc1))
     float alpha;
 };
 
@@ -73,11 +76,16 @@ template <> struct Mma<float> {
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
 
-__device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst_wave_uniform) {
+#define EOD_OOB 0x80000000u   // per-lane offset == num_records (out of range even if soffset were added without wrap): zeros
+#define EOD_WINDOW 0x80000000u  // num_records of every descriptor: 2 GiB window behind its base
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)EOD_WINDOW, 0x00020000);
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, char* lds_dst_wave_uniform) {
     // 64 lanes x 16 B -> lds_dst + lane*16 (the destination is wave-uniform base + lane*16 by hardware)
-    __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_dst_wave_uniform, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst_wave_uniform, 16, voff, soff, 0, 0);
 }
 
 template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -157,26 +165,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     };
 
     // ---- per-thread staging slots: group g = wave + 4*i, row = g*8 + (lane>>3), slot = lane&7 ----
+    // a_v0 / a_v1: byte offset of this lane's 16-byte chunk for K-step (tap 0, chunk 0) of source 0 / 1, relative
+    // to the descriptor base (conv: first image of the tile; gemm: first row of the tile).  Border rows hold a
+    // wrapped "negative" value: only taps whose mask bit is set are ever dereferenced.
     const int srow = lane >> 3, sslot = lane & 7;
-    unsigned a_off[LA];       // conv: pixel index (relative to image n_first) of tap (0,0); upsample: row base
-    unsigned a_mask[LA];      // conv: bit t set <=> tap t reads inside the image (and the row exists)
-    int a_bh[LA], a_bw[LA];   // conv + upsample only
-    long long a_rowoff[LA];   // gemm: element offset of the row
-    int a_chunk[LA];          // swizzled chunk index this lane fetches
+    unsigned a_v0[LA], a_v1[LA], a_mask[LA];
+    int a_bh[LA], a_bw[LA], a_nh[LA];   // upsample only
+    int a_chunk[LA];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int row = (wave + 4 * i) * 8 + srow;
         a_chunk[i] = sslot ^ ((row >> 1) & 7);
-        a_off[i] = 0;
+        a_v0[i] = a_v1[i] = 0;
         a_mask[i] = 0;
-        a_bh[i] = a_bw[i] = 0;
-        a_rowoff[i] = 0;
+        a_bh[i] = a_bw[i] = a_nh[i] = 0;
         if constexpr (CONV) {
             int nrel, ho, wo;
             const bool ok = decode_row(row, nrel, ho, wo);
             const int bh = ho * p.stride - p.pad - p.pad_tl, bw = wo * p.stride - p.pad - p.pad_tl;
             a_bh[i] = bh;
             a_bw[i] = bw;
+            a_nh[i] = nrel * p.H;
             unsigned mask = 0;
             if (ok) {
                 for (int t = 0; t < p.taps; ++t) {
@@ -185,94 +194,109 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
                 }
             }
             a_mask[i] = mask;
-            // unsigned wrap-around is intended: border rows have bh/bw = -1 and only valid taps are dereferenced
-            a_off[i] = p.ups ? (unsigned)(nrel * p.H) : (unsigned)((nrel * p.H + bh) * p.W + bw);
+            const unsigned pix = (unsigned)((nrel * p.H + bh) * p.W + bw);  // wraps for border rows (see above)
+            a_v0[i] = pix * (unsigned)(p.C0 * ES) + a_chunk[i] * 16;
+            a_v1[i] = pix * (unsigned)(p.C1 * ES) + a_chunk[i] * 16;
         } else {
             const long long m = (long long)tile_m * BM + row;
             a_mask[i] = m < p.M ? 1u : 0u;
-            a_rowoff[i] = offA + m * p.lda;
+            a_v0[i] = (unsigned)(row * (int)p.lda * ES) + a_chunk[i] * 16;
         }
     }
-    long long b_rowoff[LB];  // element offset of the B row (without the per-step uniform part)
-    bool b_ok[LB];
+    unsigned b_v[LB];
     int b_chunk[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int g = wave + 4 * i;
         const int row = g * 8 + srow;
-        const int co = n0 + row;
         b_chunk[i] = sslot ^ ((row >> 1) & 7);
-        b_ok[i] = (g < GB) && (co < p.Ncols);
-        if constexpr (CONV)
-            b_rowoff[i] = (long long)co * p.Cin;
-        else
-            b_rowoff[i] = offB + (long long)co * p.ldb;
+        const bool ok = (g < GB) && (n0 + row < p.Ncols);
+        const int ldb = CONV ? p.Cin : (int)p.ldb;
+        b_v[i] = ok ? (unsigned)(row * ldb * ES) + b_chunk[i] * 16 : EOD_OOB;
     }
 
-    const char* zero_page = reinterpret_cast<const char*>(g_eod_zero_page);
-    const char* a0_img = p.a0;
-    const char* a1_img = p.a1;
+    // ---- descriptors (wave-uniform): base of the tile's first image / first row ----
+    __amdgpu_buffer_rsrc_t rsA0, rsA1, rsB;
     if constexpr (CONV) {
-        a0_img = p.a0 + (long long)n_first * p.H * p.W * p.C0 * ES;
-        if (p.a1) a1_img = p.a1 + (long long)n_first * p.H * p.W * p.C1 * ES;
+        rsA0 = make_rsrc(p.a0 + (long long)n_first * p.H * p.W * p.C0 * ES);
+        rsA1 = make_rsrc(p.a1 ? p.a1 + (long long)n_first * p.H * p.W * p.C1 * ES : p.a0);
+        rsB = make_rsrc(p.b + (long long)n0 * p.Cin * ES);
+    } else {
+        rsA0 = make_rsrc(p.a0 + (offA + (long long)tile_m * BM * p.lda) * ES);
+        rsA1 = rsA0;
+        rsB = make_rsrc(p.b + (offB + (long long)n0 * p.ldb) * ES);
     }
 
-    auto issue_loads = [&](int kt, int stage) {
+    // ---- scalar K-step state: (src, cc, tap) counters, no division in the loop ----
+    int st_tap = 0, st_cc = 0, st_src = 0;
+    const int tapstride = p.Cout * p.Cin * ES;  // bytes between two taps of the packed weights
+
+    auto issue_loads = [&](int stage) {
         char* sbase = smem + stage * STAGE;
-        int tap = 0, c0;
         if constexpr (CONV) {
-            const int cc = kt / p.taps;
-            tap = kt - cc * p.taps;
-            c0 = cc * BK;
-        } else {
-            c0 = kt * BK;
-        }
-        int dy = 0, dx = 0;
-        if constexpr (CONV) {
-            if (p.KS == 3) {
-                dy = tap / 3;
-                dx = tap - dy * 3;
-            }
-        }
-        const int tapoff = dy * p.W + dx;  // conv, no upsample
+            const int cw = st_src ? p.C1 : p.C0;               // channels of the current source
+            const int kin = st_cc * BK;                        // first channel of this chunk inside the source
+            const int dy = (p.KS == 3) ? (st_tap * 11) >> 5 : 0;  // tap / 3 for tap < 9
+            const int dx = (p.KS == 3) ? st_tap - dy * 3 : 0;
+            // the tap displacement goes into the per-lane offset (border rows hold a wrapped negative base that only
+            // becomes a valid in-window offset after this add); the channel chunk goes into the SGPR offset
+            const unsigned tapbytes = (unsigned)((dy * p.W + dx) * cw * ES);
+            const unsigned soffA = (unsigned)(kin * ES);
+            const unsigned soffB = (unsigned)(st_tap * tapstride + ((st_src ? p.C0 : 0) + kin) * ES);
+            const bool ktail = kin + BK > cw;                  // uniform: only the last chunk of a source
+            const unsigned tapbit = 1u << st_tap;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int k = c0 + a_chunk[i] * EPC;
-            const char* src = zero_page;
-            if constexpr (CONV) {
-                const bool ok = ((a_mask[i] >> tap) & 1u) && (k < p.Cin);
-                unsigned pix;
+            for (int i = 0; i < LA; ++i) {
+                unsigned v;
                 if (p.ups) {
-                    pix = (a_off[i] + (unsigned)((a_bh[i] + dy) >> 1)) * (unsigned)p.W + (unsigned)((a_bw[i] + dx) >> 1);
+                    const unsigned pix = (unsigned)((a_nh[i] + ((a_bh[i] + dy) >> 1)) * p.W + ((a_bw[i] + dx) >> 1));
+                    v = pix * (unsigned)(cw * ES) + a_chunk[i] * 16;
                 } else {
-                    pix = a_off[i] + (unsigned)tapoff;
+                    v = (st_src ? a_v1[i] : a_v0[i]) + tapbytes;
                 }
-                const bool s0 = k < p.C0;
-                const char* base = s0 ? a0_img : a1_img;
-                const unsigned cw = s0 ? (unsigned)p.C0 : (unsigned)p.C1;
-                const unsigned kk = s0 ? (unsigned)k : (unsigned)(k - p.C0);
-                const unsigned long long boff = ((unsigned long long)pix * cw + kk) * ES;
-                if (ok) src = base + boff;
-            } else {
-                const bool ok = a_mask[i] && (k < p.K);
-                if (ok) src = p.a0 + (a_rowoff[i] + k) * ES;
+                bool ok = (a_mask[i] & tapbit) != 0;
+                if (ktail) ok = ok && (kin + a_chunk[i] * EPC < cw);
+                v = ok ? v : EOD_OOB;
+                if (st_src)
+                    blds16(rsA1, v, soffA, sbase + (wave + 4 * i) * 1024);
+                else
+                    blds16(rsA0, v, soffA, sbase + (wave + 4 * i) * 1024);
             }
-            glds16(src, sbase + (wave + 4 * i) * 1024);
-        }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            if ((wave + 4 * i) < GB) {  // wave-uniform
-                const int k = c0 + b_chunk[i] * EPC;
-                const char* src = zero_page;
-                if constexpr (CONV) {
-                    const bool ok = b_ok[i] && (k < p.Cin);
-                    if (ok) src = p.b + ((long long)tap * p.Cout * p.Cin + b_rowoff[i] + k) * ES;
-                } else {
-                    const bool ok = b_ok[i] && (k < p.K);
-                    if (ok) src = p.b + (b_rowoff[i] + k) * ES;
+            for (int i = 0; i < LB; ++i) {
+                if ((wave + 4 * i) < GB) {  // wave-uniform
+                    unsigned v = b_v[i];
+                    if (ktail) v = (kin + b_chunk[i] * EPC < cw) ? v : EOD_OOB;
+                    blds16(rsB, v, soffB, sbase + STAGE_A + (wave + 4 * i) * 1024);
                 }
-                glds16(src, sbase + STAGE_A + (wave + 4 * i) * 1024);
             }
+            // advance (tap inner, chunk, source outer)
+            if (++st_tap == p.taps) {
+                st_tap = 0;
+                if (++st_cc == (st_src ? p.kc1 : p.kc0)) {
+                    st_cc = 0;
+                    ++st_src;
+                }
+            }
+        } else {
+            const int kin = st_cc * BK;
+            const unsigned soff = (unsigned)(kin * ES);
+            const bool ktail = kin + BK > p.K;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                bool ok = a_mask[i] != 0;
+                if (ktail) ok = ok && (kin + a_chunk[i] * EPC < p.K);
+                blds16(rsA0, ok ? a_v0[i] : EOD_OOB, soff, sbase + (wave + 4 * i) * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                if ((wave + 4 * i) < GB) {
+                    unsigned v = b_v[i];
+                    if (ktail) v = (kin + b_chunk[i] * EPC < p.K) ? v : EOD_OOB;
+                    blds16(rsB, v, soff, sbase + STAGE_A + (wave + 4 * i) * 1024);
+                }
+            }
+            ++st_cc;
         }
     };
 
@@ -294,13 +318,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     const int b_rd = STAGE_A + (wn * WN + lr) * BKB;
 
     const int KT = p.KT;
-    issue_loads(0, 0);
+    issue_loads(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int stage = kt & 1;
-        if (kt + 1 < KT) issue_loads(kt + 1, stage ^ 1);
+        if (kt + 1 < KT) issue_loads(stage ^ 1);
         const char* sb = smem + stage * STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -463,9 +487,13 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    const int kdim = CONV ? p.Cin : p.K;
-    const int kc = (kdim + BK - 1) / BK;
-    p.KT = kc * p.taps;
+    if (CONV) {
+        p.kc0 = (p.C0 + BK - 1) / BK;
+        p.kc1 = (p.C1 + BK - 1) / BK;
+        p.KT = (p.kc0 + p.kc1) * p.taps;
+    } else {
+        p.KT = (p.K + BK - 1) / BK;
+    }
     p.tiles_n = (p.Ncols + BN - 1) / BN;
     p.tw_log2 = -1;
     if (CONV) {
@@ -520,7 +548,14 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     EOD_REQUIRE(!(d->out_nchw_f32 && d->res), "conv: residual not supported with NCHW output");
     // per-lane source offsets are 32-bit pixel indices relative to the tile's first image; a 128-row tile spans
     // at most 129 images (1x1 maps), so bound the pixel index range conservatively
-    EOD_REQUIRE((long long)d->H * d->W * 130 < 0x7fffffffLL, "conv: feature map too large for 32-bit tile-relative indexing");
+    // per-lane source offsets are 32-bit BYTE offsets inside a 2 GiB window that starts at the tile's first image; a
+    // 128-row tile touches at most 2 images once Ho*Wo >= 128 and at most 129 otherwise
+    {
+        const long long img_bytes = (long long)d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) * es;
+        const long long span = ((long long)Ho * Wo >= 128) ? 2 : 130;
+        EOD_REQUIRE(img_bytes * span < 0x7fffffffLL, "conv: one image (%lld bytes) is too large for the 2 GiB tile window", img_bytes);
+        EOD_REQUIRE((long long)d->ksize * d->ksize * d->Cout * (d->C0 + d->C1) * es < 0x7fffffffLL, "conv: weights exceed the 2 GiB window");
+    }
     IgemmP p = {};
     p.a0 = (const char*)d->x;
     p.a1 = (const char*)d->x2;
@@ -555,6 +590,8 @@ extern "C" int eod_gemm_nt(const eod_gemm_desc* d, void* stream) {
     EOD_REQUIRE(d->a && d->b && d->c, "gemm: null pointer");
     EOD_REQUIRE(eod_aligned16(d->a) && eod_aligned16(d->b), "gemm: a/b must be 16-byte aligned");
     EOD_REQUIRE((long long)d->nb0 * d->nb1 <= 65535, "gemm: batch too large");
+    EOD_REQUIRE(128 * d->lda * es + (long long)d->K * es < 0x7fffffffLL && 128 * d->ldb * es + (long long)d->K * es < 0x7fffffffLL,
+                "gemm: leading dimension too large for the 2 GiB tile window");
     IgemmP p = {};
     p.a0 = (const char*)d->a;
     p.b = (const char*)d->b;

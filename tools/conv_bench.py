@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Single-shape conv micro-benchmark (kernel iteration / rocprofv3 target).
+   python tools/conv_bench.py [--prec fp16] [--shapes name,...] [--iters 20]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from eo_diffusion_amd.engine import Program
+
+SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, upsample)
+    "l0_128": (16, 256, 256, 128, 128, 3, 1, False),
+    "l0_384": (16, 256, 256, 384, 128, 3, 1, False),
+    "l1_256": (16, 128, 128, 256, 256, 3, 1, False),
+    "l1_640": (16, 128, 128, 640, 256, 3, 1, False),
+    "l2_384": (16, 64, 64, 384, 384, 3, 1, False),
+    "l3_512": (16, 32, 32, 512, 512, 3, 1, False),
+    "up_256": (16, 128, 128, 256, 256, 3, 1, True),
+    "sk_384": (16, 256, 256, 384, 128, 1, 1, False),
+}
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prec", default="fp16")
+    ap.add_argument("--shapes", default="l0_128,l0_384,l1_256,l1_640,l2_384,l3_512,up_256,sk_384")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = "cuda:0"
+    for name in a.shapes.split(","):
+        N, H, W, Cin, Cout, k, stride, ups = SHAPES[name]
+        prog = Program(dev, a.prec)
+        x = prog.act(N, H, W, Cin)
+        x.t.normal_()
+        w = prog.empty((k * k, Cout, Cin)); w.normal_(std=0.02)
+        b = prog.empty((Cout,), torch.float32); b.normal_()
+        y, _ = prog.conv(x, w, b, Cout, ksize=k, stride=stride, pad=k // 2, upsample=ups)
+        prog.finalize()
+        for _ in range(3): prog.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters): prog.run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.iters
+        fl = 2.0 * N * y.H * y.W * Cout * Cin * k * k
+        print(f"{name:8s} {a.prec} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
+
+if __name__ == "__main__":
+    main()
