@@ -58,6 +58,7 @@ struct IgemmP {
     long long M;
     int Ncols, K, taps, KT, tiles_m, tiles_n, out_nchw;
     int kc0, kc1;  // conv: channel chunks of source 0 / source 1 (K-steps = taps * (kc0 + kc1))
+    int force_cfg; // 0 auto, 1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage (EOD_IGEMM_CFG, tuning only)
     float alpha;
 };
 
@@ -88,19 +89,21 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst_wave_uniform, 16, voff, soff, 0, 0);
 }
 
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmP p) {
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
     constexpr int BKB = 128;       // bytes of K per row per K-step
     constexpr int BK = BKB / ES;   // elements per K-step
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int GA = BM / 8, GB = BN / 8;              // 8-row groups (one glds instruction each)
-    constexpr int LA = GA / 4, LB = (GB + 3) / 4;        // groups per wave
+    constexpr int NW = WAVES_M * WAVES_N;                // waves per workgroup (4 or 8)
+    constexpr int GA = BM / 8, GB = BN / 8;              // 8-row groups (one LDS-DMA instruction each)
+    constexpr int LA = GA / NW, LB = GB / NW;            // groups per wave
+    constexpr int LPW = LA + LB;                         // DMA instructions per wave per K-step
     constexpr int STAGE_A = BM * BKB, STAGE = (BM + BN) * BKB;
     constexpr int EP_LD = WN + 4;                        // fp32 epilogue row stride (floats)
-    static_assert(WAVES_M * WAVES_N == 4 && GA % 4 == 0, "layout");
+    static_assert(GA % NW == 0 && GB % NW == 0 && (STAGES == 2 || STAGES == 3), "layout");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
         return (long long)tile_m * BM + r < p.M;
     };
 
-    // ---- per-thread staging slots: group g = wave + 4*i, row = g*8 + (lane>>3), slot = lane&7 ----
+    // ---- per-thread staging slots: group g = wave + NW*i, row = g*8 + (lane>>3), slot = lane&7 ----
     // a_v0 / a_v1: byte offset of this lane's 16-byte chunk for K-step (tap 0, chunk 0) of source 0 / 1, relative
     // to the descriptor base (conv: first image of the tile; gemm: first row of the tile).  Border rows hold a
     // wrapped "negative" value: only taps whose mask bit is set are ever dereferenced.
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     int a_chunk[LA];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int row = (wave + 4 * i) * 8 + srow;
+        const int row = (wave + NW * i) * 8 + srow;
         a_chunk[i] = sslot ^ ((row >> 1) & 7);
         a_v0[i] = a_v1[i] = 0;
         a_mask[i] = 0;
@@ -207,10 +210,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     int b_chunk[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int g = wave + 4 * i;
-        const int row = g * 8 + srow;
+        const int row = (wave + NW * i) * 8 + srow;
         b_chunk[i] = sslot ^ ((row >> 1) & 7);
-        const bool ok = (g < GB) && (n0 + row < p.Ncols);
+        const bool ok = n0 + row < p.Ncols;
         const int ldb = CONV ? p.Cin : (int)p.ldb;
         b_v[i] = ok ? (unsigned)(row * ldb * ES) + b_chunk[i] * 16 : EOD_OOB;
     }
@@ -231,45 +233,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     int st_tap = 0, st_cc = 0, st_src = 0;
     const int tapstride = p.Cout * p.Cin * ES;  // bytes between two taps of the packed weights
 
-    auto issue_loads = [&](int stage) {
-        char* sbase = smem + stage * STAGE;
+    // K-step DMA = LA + LB instructions per wave.  They are issued one or two at a time BETWEEN the MFMA sub-steps
+    // of the current K-step (an LDS-DMA instruction holds the wave's issue port for ~60-180 cycles; behind a group
+    // of MFMAs that time overlaps matrix-pipe execution instead of delaying it).
+    struct StepState {
+        unsigned tapbytes, soffA, soffB, tapbit;
+        int cw, kin, dy, dx, src;
+        bool ktail;
+    } ss;
+    auto prep_step = [&]() {
         if constexpr (CONV) {
-            const int cw = st_src ? p.C1 : p.C0;               // channels of the current source
-            const int kin = st_cc * BK;                        // first channel of this chunk inside the source
-            const int dy = (p.KS == 3) ? (st_tap * 11) >> 5 : 0;  // tap / 3 for tap < 9
-            const int dx = (p.KS == 3) ? st_tap - dy * 3 : 0;
+            ss.src = st_src;
+            ss.cw = st_src ? p.C1 : p.C0;                         // channels of the current source
+            ss.kin = st_cc * BK;                                  // first channel of this chunk inside the source
+            ss.dy = (p.KS == 3) ? (st_tap * 11) >> 5 : 0;         // tap / 3 for tap < 9
+            ss.dx = (p.KS == 3) ? st_tap - ss.dy * 3 : 0;
             // the tap displacement goes into the per-lane offset (border rows hold a wrapped negative base that only
             // becomes a valid in-window offset after this add); the channel chunk goes into the SGPR offset
-            const unsigned tapbytes = (unsigned)((dy * p.W + dx) * cw * ES);
-            const unsigned soffA = (unsigned)(kin * ES);
-            const unsigned soffB = (unsigned)(st_tap * tapstride + ((st_src ? p.C0 : 0) + kin) * ES);
-            const bool ktail = kin + BK > cw;                  // uniform: only the last chunk of a source
-            const unsigned tapbit = 1u << st_tap;
-#pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                unsigned v;
-                if (p.ups) {
-                    const unsigned pix = (unsigned)((a_nh[i] + ((a_bh[i] + dy) >> 1)) * p.W + ((a_bw[i] + dx) >> 1));
-                    v = pix * (unsigned)(cw * ES) + a_chunk[i] * 16;
-                } else {
-                    v = (st_src ? a_v1[i] : a_v0[i]) + tapbytes;
-                }
-                bool ok = (a_mask[i] & tapbit) != 0;
-                if (ktail) ok = ok && (kin + a_chunk[i] * EPC < cw);
-                v = ok ? v : EOD_OOB;
-                if (st_src)
-                    blds16(rsA1, v, soffA, sbase + (wave + 4 * i) * 1024);
-                else
-                    blds16(rsA0, v, soffA, sbase + (wave + 4 * i) * 1024);
-            }
-#pragma unroll
-            for (int i = 0; i < LB; ++i) {
-                if ((wave + 4 * i) < GB) {  // wave-uniform
-                    unsigned v = b_v[i];
-                    if (ktail) v = (kin + b_chunk[i] * EPC < cw) ? v : EOD_OOB;
-                    blds16(rsB, v, soffB, sbase + STAGE_A + (wave + 4 * i) * 1024);
-                }
-            }
+            ss.tapbytes = (unsigned)((ss.dy * p.W + ss.dx) * ss.cw * ES);
+            ss.soffA = (unsigned)(ss.kin * ES);
+            ss.soffB = (unsigned)(st_tap * tapstride + ((st_src ? p.C0 : 0) + ss.kin) * ES);
+            ss.ktail = ss.kin + BK > ss.cw;                       // uniform: only the last chunk of a source
+            ss.tapbit = 1u << st_tap;
             // advance (tap inner, chunk, source outer)
             if (++st_tap == p.taps) {
                 st_tap = 0;
@@ -279,25 +264,47 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
                 }
             }
         } else {
-            const int kin = st_cc * BK;
-            const unsigned soff = (unsigned)(kin * ES);
-            const bool ktail = kin + BK > p.K;
-#pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                bool ok = a_mask[i] != 0;
-                if (ktail) ok = ok && (kin + a_chunk[i] * EPC < p.K);
-                blds16(rsA0, ok ? a_v0[i] : EOD_OOB, soff, sbase + (wave + 4 * i) * 1024);
-            }
-#pragma unroll
-            for (int i = 0; i < LB; ++i) {
-                if ((wave + 4 * i) < GB) {
-                    unsigned v = b_v[i];
-                    if (ktail) v = (kin + b_chunk[i] * EPC < p.K) ? v : EOD_OOB;
-                    blds16(rsB, v, soff, sbase + STAGE_A + (wave + 4 * i) * 1024);
-                }
-            }
+            ss.kin = st_cc * BK;
+            ss.soffA = ss.soffB = (unsigned)(ss.kin * ES);
+            ss.ktail = ss.kin + BK > p.K;
+            ss.cw = p.K;
             ++st_cc;
         }
+    };
+    auto issue_a = [&](int i, char* sbase) {
+        unsigned v;
+        bool ok;
+        if constexpr (CONV) {
+            if (p.ups) {
+                const unsigned pix = (unsigned)((a_nh[i] + ((a_bh[i] + ss.dy) >> 1)) * p.W + ((a_bw[i] + ss.dx) >> 1));
+                v = pix * (unsigned)(ss.cw * ES) + a_chunk[i] * 16;
+            } else {
+                v = (ss.src ? a_v1[i] : a_v0[i]) + ss.tapbytes;
+            }
+            ok = (a_mask[i] & ss.tapbit) != 0;
+        } else {
+            v = a_v0[i];
+            ok = a_mask[i] != 0;
+        }
+        if (ss.ktail) ok = ok && (ss.kin + a_chunk[i] * EPC < ss.cw);
+        v = ok ? v : EOD_OOB;
+        if (CONV && ss.src)
+            blds16(rsA1, v, ss.soffA, sbase + (wave + NW * i) * 1024);
+        else
+            blds16(rsA0, v, ss.soffA, sbase + (wave + NW * i) * 1024);
+    };
+    auto issue_b = [&](int i, char* sbase) {
+        unsigned v = b_v[i];
+        if (ss.ktail) v = (ss.kin + b_chunk[i] * EPC < ss.cw) ? v : EOD_OOB;
+        blds16(rsB, v, ss.soffB, sbase + STAGE_A + (wave + NW * i) * 1024);
+    };
+    auto issue_loads = [&](int stage) {  // all DMA instructions of one K-step
+        char* sbase = smem + stage * STAGE;
+        prep_step();
+#pragma unroll
+        for (int i = 0; i < LA; ++i) issue_a(i, sbase);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) issue_b(i, sbase);
     };
 
     f32x16 acc[TM][TN];
@@ -317,15 +324,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
     const int a_rd = (wm * WM + lr) * BKB;
     const int b_rd = STAGE_A + (wn * WN + lr) * BKB;
 
+    // ---- main loop: STAGES-deep LDS ring, ONE raw barrier per K-step ----
+    //   iteration t:  wait until this wave's DMA for step t has landed (counted vmcnt: the DMA of the next
+    //                 STAGES-2 steps stays in flight)  ->  s_barrier (every wave's part of step t landed, and every
+    //                 wave finished reading step t-1)  ->  issue the DMA of step t+STAGES-1 into the stage that
+    //                 step t-1 just vacated  ->  ds_read + MFMA on stage t.
+    // __syncthreads() is avoided on purpose: with LDS-DMA in flight it would drain vmcnt to 0 (guide 5.4).
     const int KT = p.KT;
-    issue_loads(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < STAGES - 1; ++ps)
+        if (ps < KT) issue_loads(ps);
 
     for (int kt = 0; kt < KT; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < KT) issue_loads(stage ^ 1);
-        const char* sb = smem + stage * STAGE;
+        if (STAGES == 3 && kt + 1 < KT) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // (issuing the DMA instructions one by one between the MFMA sub-steps was measured: no gain, -5..10 %)
+        if (kt + STAGES - 1 < KT) issue_loads((kt + STAGES - 1) % STAGES);
+        const char* sb = smem + (kt % STAGES) * STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             i32x4 fa[TM], fb[TN];
@@ -338,9 +357,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next stage landed ...
-        __syncthreads();                                   // ... and every wave is done reading this one
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my fragment reads are done ...
+    __builtin_amdgcn_s_barrier();        // ... and so are everybody else's: the ring can be reused by the epilogue
 
     // =========================== epilogue ===========================
     // 1) C layout (lane = column): alpha, per-column bias; conv: per-sample bias needs the row's image.
@@ -352,6 +371,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
         col[j] = n0 + wn * WN + j * 32 + lr;
         cok[j] = col[j] < p.Ncols;
         bcol[j] = (cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f;
+    }
+    // per-sample (timestep) bias: one value per (image, column).  A tile almost always lies inside one image
+    // (always in patch mode); then it is folded into bcol once instead of being fetched per row.
+    bool cb_per_row = false;
+    if constexpr (CONV) {
+        if (p.cbias) {
+            const bool one_image = (p.tw_log2 >= 0) || (rem_first + BM <= p.HoWo);
+            if (one_image) {
+                const float* cbp = p.cbias + (long long)n_first * p.cbias_stride;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (cok[j]) bcol[j] += cbp[col[j]];
+            } else {
+                cb_per_row = true;
+            }
+        }
     }
 
     if (CONV && p.out_nchw) {
@@ -368,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
                 for (int j = 0; j < TN; ++j) {
                     if (!cok[j]) continue;
                     float v = acc[i][j][r] * p.alpha + bcol[j];
-                    if (p.cbias) v += p.cbias[(long long)n * p.cbias_stride + col[j]];
+                    if (cb_per_row) v += p.cbias[(long long)n * p.cbias_stride + col[j]];
                     reinterpret_cast<float*>(p.y)[((long long)n * p.Cout + col[j]) * p.HoWo + (long long)ho * p.Wo + wo] = v;
                 }
             }
@@ -386,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) cb[j] = 0.0f;
             if constexpr (CONV) {
-                if (p.cbias) {
+                if (cb_per_row) {
                     int nrel, ho, wo;
                     decode_row(wm * WM + rw, nrel, ho, wo);
                     const float* cbp = p.cbias + (long long)(n_first + nrel) * p.cbias_stride;
@@ -474,14 +509,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------ host side
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N>
+#include <stdlib.h>
+static int igemm_forced_cfg() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("EOD_IGEMM_CFG");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    const size_t ring = 2 * (size_t)(BM + BN) * 128;
-    const size_t epi = 4 * (size_t)WM * (WN + 4) * sizeof(float);
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, NW = WAVES_M * WAVES_N;
+    const size_t ring = STAGES * (size_t)(BM + BN) * 128;
+    const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N>;
+    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES>;
     static bool attr_done = false;  // >64 KiB dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -519,15 +564,18 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
         eod_set_error("igemm: bad grid %lld", nblk);
         return EOD_EINVAL;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)batch), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)batch), dim3(64 * NW), lds, st, p);
     EOD_CHECK_LAUNCH("igemm");
     return EOD_OK;
 }
 
 template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipStream_t st) {
-    if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1>(p, batch, st);
-    if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1>(p, batch, st);
-    return launch_cfg<T, CONV, 128, 128, 2, 2>(p, batch, st);
+    if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2>(p, batch, st);
+    if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2>(p, batch, st);
+    // 256x128 tile / 8 waves / 3-stage ring (144 KiB LDS, one workgroup per CU, DMA prefetched 2 K-steps deep) is kept
+    // as a tuning variant (EOD_IGEMM_CFG=2): measured 0-5 % SLOWER than two co-resident 128x128 workgroups per CU.
+    if (p.force_cfg == 2) return launch_cfg<T, CONV, 256, 128, 4, 2, 3>(p, batch, st);
+    return launch_cfg<T, CONV, 128, 128, 2, 2, 2>(p, batch, st);
 }
 
 extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
@@ -575,6 +623,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     p.out_nchw = d->out_nchw_f32;
     p.alpha = d->alpha;
     p.nb1 = 1;
+    p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }
@@ -606,6 +655,7 @@ extern "C" int eod_gemm_nt(const eod_gemm_desc* d, void* stream) {
     p.M = d->M; p.Ncols = d->N; p.K = d->K;
     p.taps = 1;
     p.alpha = d->alpha;
+    p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
     const int batch = d->nb0 * d->nb1;
     return d->dtype == EOD_F16 ? launch_T<half_t, false>(p, batch, st) : launch_T<float, false>(p, batch, st);
