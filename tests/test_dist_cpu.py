@@ -1,0 +1,56 @@
+"""CPU (gloo, world_size 2) tests of the sharding / gather logic of eo_diffusion_amd.dist and of the rank
+invariance of the Philox noise source (via its numpy oracle)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from eo_diffusion_amd.dist import gather_samples, shard_bounds
+
+
+def test_shard_bounds_cover_and_disjoint():
+    for n in (0, 1, 7, 16, 128, 129):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.philox_ref import philox_randn
+        lo, hi = shard_bounds(n_total, world, rank)
+        # each rank "samples" its shard with noise keyed by the GLOBAL sample index
+        local = torch.from_numpy(philox_randn(hi - lo, 3 * 4 * 4, 11, lo, 5, 1)).reshape(hi - lo, 3, 4, 4)
+        full = gather_samples(local, n_total)
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4, 5])
+def test_gloo_world2_gather_matches_single_rank(n_total):
+    from oracle.philox_ref import philox_randn
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_total
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = philox_randn(n_total, 48, 11, 0, 5, 1).reshape(n_total, 3, 4, 4)  # what ONE rank would have produced
+    for r in range(2):
+        assert np.array_equal(res[r], ref)

@@ -1,0 +1,123 @@
+"""CPU suite: host-side contract of the drop-in API -- state_dict key layout vs the reference's, module graph,
+deep-copy / pickle safety, C-ABI library loads and exports every declared symbol, loud failure off-GPU."""
+import copy
+import ctypes
+import os
+import pickle
+import re
+
+import pytest
+import torch
+
+from tests.helpers import key_contracts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", list(key_contracts()))
+def test_state_dict_keys_match_reference(name):
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    kc = key_contracts()[name]
+    shapes = unet_param_shapes(**kc["cfg"])
+    assert list(shapes.keys()) == list(kc["unet"].keys())  # same keys in the same order
+    assert {k: list(v) for k, v in shapes.items()} == kc["unet"]
+    with torch.device("meta"):
+        u = UNetModel(**kc["cfg"])
+    m = EODiffusion(u, timesteps=1000, image_size=kc["cfg"]["image_size"], in_channels=3)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == kc["eodiffusion"]
+
+
+def test_default_init_matches_reference_conventions():
+    """zero_module convs are zero, GroupNorm affine is (1, 0) -- what a freshly constructed reference model has."""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel
+    u = UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[2],
+                  channel_mult=[1, 2])
+    sd = u.state_dict()
+    for k in ("out.2.weight", "out.2.bias", "conv_out.weight", "middle_block.1.proj_out.weight",
+              "input_blocks.1.0.out_layers.3.weight"):
+        assert float(sd[k].abs().max()) == 0.0, k
+    assert torch.all(sd["out.0.weight"] == 1) and torch.all(sd["out.0.bias"] == 0)
+    assert float(sd["input_blocks.1.0.in_layers.2.weight"].abs().max()) > 0
+
+
+def test_modules_are_deepcopy_and_pickle_safe():
+    """AveragedModel(model) deep-copies the whole EODiffusion (script_utils/utils.py:67, train.py:73)."""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    u = UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
+                  channel_mult=[1, 2])
+    u.__dict__["_eod_cache"] = {"fake": ctypes.c_void_p(1)}  # what a live program cache looks like: not copyable
+    m = EODiffusion(u, timesteps=10, image_size=16, in_channels=3)
+    m2 = copy.deepcopy(m)
+    assert "_eod_cache" not in m2.model.__dict__
+    m3 = pickle.loads(pickle.dumps(m))
+    assert list(m3.state_dict().keys()) == list(m.state_dict().keys())
+    ema = torch.optim.swa_utils.AveragedModel(m, multi_avg_fn=None, use_buffers=True)
+    assert any(k.startswith("module.model.") for k in ema.state_dict())
+
+
+def test_library_exports_every_declared_symbol():
+    from eo_diffusion_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "eodiff.h")).read()
+    declared = set(re.findall(r"\b(eod_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"eod_op", "eod_conv_desc", "eod_gemm_desc", "eod_temb_desc", "eod_small_desc"}
+    L = _lib.lib()  # binds SYMBOLS and cross-checks struct sizes against the compiled library
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/eodiff.h but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert L.eod_version() >= 100
+
+
+def test_product_fails_loudly_without_gpu():
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.backbones.unet_openai import ResBlock, UNetModel, normalization
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    u = UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
+                  channel_mult=[1, 2])
+    m = EODiffusion(u, timesteps=10, image_size=16, in_channels=3)
+    with torch.no_grad():
+        with pytest.raises(_lib.EodError):
+            u(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long))
+        with pytest.raises(_lib.EodError):
+            m.sampling(1, device="cpu")
+        with pytest.raises(_lib.EodError):
+            m._forward_diffusion(torch.zeros(1, 3, 16, 16), torch.zeros(1, dtype=torch.long), torch.zeros(1, 3, 16, 16))
+        with pytest.raises(_lib.EodError):
+            normalization(32)(torch.zeros(1, 32, 4, 4))  # parameter containers never run torch arithmetic
+        with pytest.raises(_lib.EodError):
+            ResBlock(32, 128, 0.0)(torch.zeros(1, 32, 4, 4), torch.zeros(1, 128))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "eo_diffusion_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
+
+
+def test_ddim_schedule_host_tables_match_golden():
+    import numpy as np
+    from eo_diffusion_amd.diffusion.ddim import DDIMSampler
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    from tests.helpers import gload
+    m = EODiffusion(torch.nn.Identity(), timesteps=1000, image_size=8, in_channels=3)
+    for S in (50, 250, 600, 1000):
+        for eta in (0.0, 0.5):
+            s = DDIMSampler(m)
+            s.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
+            g = gload(f"ddim_S{S}_T1000_eta{eta}")
+            assert np.array_equal(np.asarray(s.ddim_timesteps, np.int64), g["steps"])  # integer schedule: bit-exact
+            assert np.array_equal(np.asarray(s.ddim_alphas), g["a"])
+            assert np.array_equal(np.asarray(s.ddim_alphas_prev, np.float64), g["a_prev"])
+
+
+def test_dropin_module_paths():
+    import subprocess
+    import sys
+    code = ("from backbones.unet_openai import UNetModel, ResBlock, AttentionBlock; from diffusion.model import EODiffusion; "
+            "from diffusion.ddim import DDIMSampler; from diffusion.util import make_ddim_timesteps; print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "eo_diffusion_amd", "dropin") + os.pathsep + ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
