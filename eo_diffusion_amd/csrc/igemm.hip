@@ -89,6 +89,228 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst_wave_uniform, 16, voff, soff, 0, 0);
 }
 
+// tile origin (wave-uniform): conv tiles are addressed relative to the tile's first image
+struct TileGeom {
+    int tile_m, n_first, rem_first, ty0, tx0;
+    long long offA, offB, offC;  // gemm batch offsets (elements)
+};
+
+// row r of the tile -> (image index relative to n_first, ho, wo); false if past the end
+template <int BM>
+__device__ __forceinline__ bool decode_row(const IgemmP& p, const TileGeom& g, int r, int& nrel, int& ho, int& wo) {
+    if (p.tw_log2 >= 0) {
+        nrel = 0;
+        ho = g.ty0 + (r >> p.tw_log2);
+        wo = g.tx0 + (r & ((1 << p.tw_log2) - 1));
+        return true;
+    }
+    int rem = g.rem_first + r;
+    nrel = 0;
+    if (rem >= p.HoWo) {  // a tile may straddle images (or span several when the map is tiny)
+        nrel = rem / p.HoWo;
+        rem -= nrel * p.HoWo;
+    }
+    ho = rem / p.Wo;
+    wo = rem - ho * p.Wo;
+    return (long long)g.tile_m * BM + r < p.M;
+}
+
+template <bool CONV, int BM>
+__device__ __forceinline__ TileGeom make_geom(const IgemmP& p, int tile_m) {
+    TileGeom g = {};
+    g.tile_m = tile_m;
+    if constexpr (CONV) {
+        if (p.tw_log2 >= 0) {
+            g.n_first = tile_m / p.tiles_pi;
+            const int t = tile_m - g.n_first * p.tiles_pi;
+            const int ty = t / p.tiles_pw;
+            g.ty0 = ty * p.th;
+            g.tx0 = (t - ty * p.tiles_pw) << p.tw_log2;
+        } else {
+            const long long m0 = (long long)tile_m * BM;
+            g.n_first = (int)(m0 / p.HoWo);
+            g.rem_first = (int)(m0 - (long long)g.n_first * p.HoWo);
+        }
+    } else {
+        const int z = blockIdx.y;
+        const int b0 = z / p.nb1, b1 = z - b0 * p.nb1;
+        g.offA = b0 * p.sa0 + b1 * p.sa1;
+        g.offB = b0 * p.sb0 + b1 * p.sb1;
+        g.offC = b0 * p.sc0 + b1 * p.sc1;
+    }
+    return g;
+}
+
+// XCD-aware tile mapping (bijective remap, guide T1)
+__device__ __forceinline__ void map_tile(const IgemmP& p, int& tile_m, int& tile_n) {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile_n = swz % p.tiles_n;
+    tile_m = swz / p.tiles_n;
+}
+
+// =============================================================================================
+// Shared epilogue: bias / per-sample (timestep) bias in the MFMA C layout (lane = column), transpose through LDS
+// (fp32, wave-private slab), 16-byte stores along the channel axis with the residual added on the way.
+// Precondition: every wave has passed a barrier after its last LDS read of the operand ring.
+// =============================================================================================
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                               char* smem, int wave, int lane, int n0) {
+    constexpr int ES = sizeof(T);
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int EP_LD = WN + 4;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 31, lh = lane >> 5;
+    // =========================== epilogue ===========================
+    // 1) C layout (lane = column): alpha, per-column bias; conv: per-sample bias needs the row's image.
+    int col[TN];
+    bool cok[TN];
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        col[j] = n0 + wn * WN + j * 32 + lr;
+        cok[j] = col[j] < p.Ncols;
+        bcol[j] = (cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f;
+    }
+    // per-sample (timestep) bias: one value per (image, column).  A tile almost always lies inside one image
+    // (always in patch mode); then it is folded into bcol once instead of being fetched per row.
+    bool cb_per_row = false;
+    if constexpr (CONV) {
+        if (p.cbias) {
+            const bool one_image = (p.tw_log2 >= 0) || (g.rem_first + BM <= p.HoWo);
+            if (one_image) {
+                const float* cbp = p.cbias + (long long)g.n_first * p.cbias_stride;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (cok[j]) bcol[j] += cbp[col[j]];
+            } else {
+                cb_per_row = true;
+            }
+        }
+    }
+
+    if (CONV && p.out_nchw) {
+        // tiny-Cout head writing the API layout (NCHW fp32) directly: scalar stores, negligible bytes
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int nrel, ho, wo;
+                if (!decode_row<BM>(p, g, row, nrel, ho, wo)) continue;
+                const int n = g.n_first + nrel;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!cok[j]) continue;
+                    float v = acc[i][j][r] * p.alpha + bcol[j];
+                    if (cb_per_row) v += p.cbias[(long long)n * p.cbias_stride + col[j]];
+                    reinterpret_cast<float*>(p.y)[((long long)n * p.Cout + col[j]) * p.HoWo + (long long)ho * p.Wo + wo] = v;
+                }
+            }
+        return;
+    }
+
+    // 2) transpose through LDS: each wave owns a [WM][EP_LD] fp32 slab (the ring is free after the last barrier)
+    float* slab = reinterpret_cast<float*>(smem) + wave * (WM * EP_LD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rw = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside the wave's slab
+            float cb[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) cb[j] = 0.0f;
+            if constexpr (CONV) {
+                if (cb_per_row) {
+                    int nrel, ho, wo;
+                    decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo);
+                    const float* cbp = p.cbias + (long long)(g.n_first + nrel) * p.cbias_stride;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) cb[j] = cok[j] ? cbp[col[j]] : 0.0f;
+                }
+            } else {
+                if (p.bias && p.bias_mode == 2) {
+                    const long long m = (long long)g.tile_m * BM + wm * WM + rw;
+                    const float br = m < p.M ? p.bias[m] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) cb[j] = br;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * 32 + lr] = acc[i][j][r] * p.alpha + bcol[j] + cb[j];
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
+    __builtin_amdgcn_wave_barrier();
+
+    // 3) row-major read-back: each lane handles 16-byte output chunks of one row
+    const bool out_f32 = (!CONV && p.c_f32) || ES == 4;
+    const int epo = out_f32 ? 4 : 8;           // elements per 16-byte output chunk
+    const int cpr = WN / epo;                  // chunks per row of the wave's slab
+    const int total = WM * cpr;
+    const int ncol0 = n0 + wn * WN;
+    for (int f = lane; f < total; f += 64) {
+        const int rw = f / cpr, cj = (f - rw * cpr) * epo;
+        const int c = ncol0 + cj;
+        if (c >= p.Ncols) continue;
+        long long o;  // element offset of (row, c) in the output
+        if constexpr (CONV) {
+            int nrel, ho, wo;
+            if (!decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo)) continue;
+            o = ((((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo)) * p.Cout + c;
+        } else {
+            const long long m = (long long)g.tile_m * BM + wm * WM + rw;
+            if (m >= p.M) continue;
+            o = g.offC + m * p.ldc + c;
+        }
+        const float* sp = slab + rw * EP_LD + cj;
+        const bool full = (c + epo <= p.Ncols) && (((o * (out_f32 ? 4 : 2)) & 15) == 0);
+        if (out_f32) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+            float* yo = reinterpret_cast<float*>(p.y) + o;
+            const float* ro = p.res ? reinterpret_cast<const float*>(p.res) + o : nullptr;
+            if (full) {
+                if (ro) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(ro);
+                    v += rv;
+                }
+                *reinterpret_cast<f32x4*>(yo) = v;
+            } else {
+                for (int e = 0; e < 4 && c + e < p.Ncols; ++e) yo[e] = v[e] + (ro ? ro[e] : 0.0f);
+            }
+        } else {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            half_t* yo = reinterpret_cast<half_t*>(p.y) + o;
+            const half_t* ro = p.res ? reinterpret_cast<const half_t*>(p.res) + o : nullptr;
+            if (full) {
+                half8 h;
+                if (ro) {
+                    const half8 rv = *reinterpret_cast<const half8*>(ro);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = (half_t)(v0[e] + (float)rv[e]);
+                        h[e + 4] = (half_t)(v1[e] + (float)rv[e + 4]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = (half_t)v0[e];
+                        h[e + 4] = (half_t)v1[e];
+                    }
+                }
+                *reinterpret_cast<half8*>(yo) = h;
+            } else {
+                for (int e = 0; e < 8 && c + e < p.Ncols; ++e) {
+                    const float x = (e < 4 ? v0[e] : v1[e - 4]) + (ro ? (float)ro[e] : 0.0f);
+                    yo[e] = (half_t)x;
+                }
+            }
+        }
+    }
+}
+
 template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmP p) {
     constexpr int ES = sizeof(T);
@@ -112,60 +334,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // ---- XCD-aware tile mapping (bijective) ----
     int tile_m, tile_n;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        tile_n = swz % p.tiles_n;
-        tile_m = swz / p.tiles_n;
-    }
+    map_tile(p, tile_m, tile_n);
     const int n0 = tile_n * BN;
-
-    // ---- tile origin (wave-uniform) ----
-    // conv: image index of the tile's first row and that row's linear pixel index inside the image; all
-    // per-lane offsets are taken relative to that image so they fit 32 bits.
-    long long offA = 0, offB = 0, offC = 0;  // gemm batch offsets (elements)
-    int n_first = 0, rem_first = 0, ty0 = 0, tx0 = 0;
-    if constexpr (CONV) {
-        if (p.tw_log2 >= 0) {
-            n_first = tile_m / p.tiles_pi;
-            const int t = tile_m - n_first * p.tiles_pi;
-            const int ty = t / p.tiles_pw;
-            ty0 = ty * p.th;
-            tx0 = (t - ty * p.tiles_pw) << p.tw_log2;
-        } else {
-            const long long m0 = (long long)tile_m * BM;
-            n_first = (int)(m0 / p.HoWo);
-            rem_first = (int)(m0 - (long long)n_first * p.HoWo);
-        }
-    } else {
-        const int z = blockIdx.y;
-        const int b0 = z / p.nb1, b1 = z - b0 * p.nb1;
-        offA = b0 * p.sa0 + b1 * p.sa1;
-        offB = b0 * p.sb0 + b1 * p.sb1;
-        offC = b0 * p.sc0 + b1 * p.sc1;
-    }
-
-    // row r of the tile -> (image index relative to n_first, ho, wo); false if past the end
-    auto decode_row = [&](int r, int& nrel, int& ho, int& wo) -> bool {
-        if (p.tw_log2 >= 0) {
-            nrel = 0;
-            ho = ty0 + (r >> p.tw_log2);
-            wo = tx0 + (r & ((1 << p.tw_log2) - 1));
-            return true;
-        }
-        int rem = rem_first + r;
-        nrel = 0;
-        if (rem >= p.HoWo) {  // a tile may straddle images (or span several when the map is tiny)
-            nrel = rem / p.HoWo;
-            rem -= nrel * p.HoWo;
-        }
-        ho = rem / p.Wo;
-        wo = rem - ho * p.Wo;
-        return (long long)tile_m * BM + r < p.M;
-    };
+    const TileGeom g = make_geom<CONV, BM>(p, tile_m);
+    const int n_first = g.n_first;
+    const long long offA = g.offA, offB = g.offB;
 
     // ---- per-thread staging slots: group g = wave + NW*i, row = g*8 + (lane>>3), slot = lane&7 ----
     // a_v0 / a_v1: byte offset of this lane's 16-byte chunk for K-step (tap 0, chunk 0) of source 0 / 1, relative
@@ -184,7 +358,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         a_bh[i] = a_bw[i] = a_nh[i] = 0;
         if constexpr (CONV) {
             int nrel, ho, wo;
-            const bool ok = decode_row(row, nrel, ho, wo);
+            const bool ok = decode_row<BM>(p, g, row, nrel, ho, wo);
             const int bh = ho * p.stride - p.pad - p.pad_tl, bw = wo * p.stride - p.pad - p.pad_tl;
             a_bh[i] = bh;
             a_bw[i] = bw;
@@ -361,151 +535,197 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my fragment reads are done ...
     __builtin_amdgcn_s_barrier();        // ... and so are everybody else's: the ring can be reused by the epilogue
 
-    // =========================== epilogue ===========================
-    // 1) C layout (lane = column): alpha, per-column bias; conv: per-sample bias needs the row's image.
-    int col[TN];
-    bool cok[TN];
-    float bcol[TN];
+    igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N>(p, g, acc, smem, wave, lane, n0);
+}
+
+// =============================================================================================
+// conv3x3_halo_kernel: 3x3 / stride 1 / pad 1 convolution (the ResBlock convs = ~85 % of the step's FLOPs).
+//
+// The generic kernel above fetches every input line 9 times (once per filter tap); ablation on MI355X showed that this
+// A-operand gather is what limits it (858 -> 1062 TFLOP/s with the A DMA removed).  Here a workgroup stages the
+// (8+2) x (16+2) pixel HALO PATCH of its 8x16 output tile ONCE per 64-channel chunk (180 rows x 128 B, double
+// buffered) and the 9 taps read shifted windows of that patch from LDS: A traffic drops ~7x, the per-tap DMA is only
+// the 128 x 128 B weight tile (L2 resident, shared by all workgroups).
+//   * patch rows are swizzled exactly like GEMM rows (chunk ^ ((prow>>1)&7)); a 32-pixel MFMA row fragment is two
+//     16-pixel patch rows, so ds_read_b128 groups still hit distinct 16-byte slots except for one 2-way pair.
+//   * DMA schedule per K-step (chunk cc, tap t), per wave: [4 weight-tile pieces for step+1][1 patch piece of chunk cc+1
+//     (taps 0..5)].  vmcnt retires in order, so the wait for step s's weights is vmcnt(1) when a patch piece was
+//     issued after them and vmcnt(0) otherwise: every patch piece gets two full K-steps to land.
+//   * everything else (MFMA tiling, buffer-descriptor OOB zero fill, concat sources, epilogue) is shared with igemm.
+// Requirements (checked by the launcher, otherwise the generic kernel runs): ksize 3, stride 1, pad 1, no upsample,
+// Wo % 16 == 0, Ho % 8 == 0.
+// =============================================================================================
+template <typename T, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
+    constexpr int BM = 128, TH = 8, TW = 16, PW = TW + 2, PR = (TH + 2) * PW;  // 180 patch rows
+    constexpr int PG = (PR + 7) / 8;                                             // 23 DMA groups of 8 rows
+    constexpr int LAH = (PG + 3) / 4;                                            // 6 patch pieces per wave
+    constexpr int ES = sizeof(T), EPC = 16 / ES, BKB = 128, BK = BKB / ES;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int GB = BN / 8, LB = GB / 4;
+    constexpr int ABUF = PG * 1024, BSTAGE = BN * BKB;
+    static_assert(WAVES_M * WAVES_N == 4 && GB % 4 == 0 && LAH <= 6, "layout");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sA = smem;              // [2][ABUF]
+    char* const sB = smem + 2 * ABUF;   // [2][BSTAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    int tile_m, tile_n;
+    map_tile(p, tile_m, tile_n);
+    const int n0 = tile_n * BN;
+    const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode: ty0, tx0, n_first
+
+    // ---- patch pieces of this wave: group gi = wave + 4*i, patch row = gi*8 + (lane>>3), slot = lane&7 ----
+    const int srow = lane >> 3, sslot = lane & 7;
+    unsigned pv0[LAH], pv1[LAH];
+    int pchunk[LAH];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        col[j] = n0 + wn * WN + j * 32 + lr;
-        cok[j] = col[j] < p.Ncols;
-        bcol[j] = (cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f;
+    for (int i = 0; i < LAH; ++i) {
+        const int prow = (wave + 4 * i) * 8 + srow;
+        const int py = prow / PW, px = prow - py * PW;
+        const int hi = g.ty0 - 1 + py, wi = g.tx0 - 1 + px;
+        const bool ok = (wave + 4 * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        pchunk[i] = sslot ^ ((prow >> 1) & 7);
+        const unsigned pix = (unsigned)(hi * p.W + wi);
+        pv0[i] = ok ? pix * (unsigned)(p.C0 * ES) + pchunk[i] * 16 : EOD_OOB;
+        pv1[i] = ok ? pix * (unsigned)(p.C1 * ES) + pchunk[i] * 16 : EOD_OOB;
     }
-    // per-sample (timestep) bias: one value per (image, column).  A tile almost always lies inside one image
-    // (always in patch mode); then it is folded into bcol once instead of being fetched per row.
-    bool cb_per_row = false;
-    if constexpr (CONV) {
-        if (p.cbias) {
-            const bool one_image = (p.tw_log2 >= 0) || (rem_first + BM <= p.HoWo);
-            if (one_image) {
-                const float* cbp = p.cbias + (long long)n_first * p.cbias_stride;
+    unsigned b_v[LB];
+    int b_chunk[LB];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (cok[j]) bcol[j] += cbp[col[j]];
-            } else {
-                cb_per_row = true;
-            }
+    for (int i = 0; i < LB; ++i) {
+        const int row = (wave + 4 * i) * 8 + srow;
+        b_chunk[i] = sslot ^ ((row >> 1) & 7);
+        b_v[i] = (n0 + row < p.Ncols) ? (unsigned)(row * p.Cin * ES) + b_chunk[i] * 16 : EOD_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsA0 = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES);
+    const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(p.a1 ? p.a1 + (long long)g.n_first * p.H * p.W * p.C1 * ES : p.a0);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.b + (long long)n0 * p.Cin * ES);
+    const int tapstride = p.Cout * p.Cin * ES;
+
+    // chunk state (wave-uniform): source, channel offset inside the source, tail flag, weight K offset (bytes)
+    struct Chunk {
+        int src, kin, cw;
+        unsigned bk;
+        bool ktail;
+    };
+    auto chunk_of = [&](int cc) {
+        Chunk c;
+        c.src = cc >= p.kc0 ? 1 : 0;
+        const int ci = c.src ? cc - p.kc0 : cc;
+        c.kin = ci * BK;
+        c.cw = c.src ? p.C1 : p.C0;
+        c.bk = (unsigned)(((c.src ? p.C0 : 0) + c.kin) * ES);
+        c.ktail = c.kin + BK > c.cw;
+        return c;
+    };
+    auto issue_patch_piece = [&](int i, const Chunk& c, char* abuf) {
+        unsigned v = c.src ? pv1[i] : pv0[i];
+        if (c.ktail) v = (c.kin + pchunk[i] * EPC < c.cw) ? v : EOD_OOB;
+        if (c.src)
+            blds16(rsA1, v, (unsigned)(c.kin * ES), abuf + (wave + 4 * i) * 1024);
+        else
+            blds16(rsA0, v, (unsigned)(c.kin * ES), abuf + (wave + 4 * i) * 1024);
+    };
+    auto issue_weights = [&](int tap, const Chunk& c, char* bst) {
+        const unsigned soff = (unsigned)(tap * tapstride) + c.bk;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            unsigned v = b_v[i];
+            if (c.ktail) v = (c.kin + b_chunk[i] * EPC < c.cw) ? v : EOD_OOB;
+            blds16(rsB, v, soff, bst + (wave + 4 * i) * 1024);
         }
-    }
+    };
 
-    if (CONV && p.out_nchw) {
-        // tiny-Cout head writing the API layout (NCHW fp32) directly: scalar stores, negligible bytes
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                int nrel, ho, wo;
-                if (!decode_row(row, nrel, ho, wo)) continue;
-                const int n = n_first + nrel;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (!cok[j]) continue;
-                    float v = acc[i][j][r] * p.alpha + bcol[j];
-                    if (cb_per_row) v += p.cbias[(long long)n * p.cbias_stride + col[j]];
-                    reinterpret_cast<float*>(p.y)[((long long)n * p.Cout + col[j]) * p.HoWo + (long long)ho * p.Wo + wo] = v;
-                }
-            }
-        return;
-    }
-
-    // 2) transpose through LDS: each wave owns a [WM][EP_LD] fp32 slab (the ring is free after the last barrier)
-    float* slab = reinterpret_cast<float*>(smem) + wave * (WM * EP_LD);
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rw = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside the wave's slab
-            float cb[TN];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) cb[j] = 0.0f;
-            if constexpr (CONV) {
-                if (cb_per_row) {
-                    int nrel, ho, wo;
-                    decode_row(wm * WM + rw, nrel, ho, wo);
-                    const float* cbp = p.cbias + (long long)(n_first + nrel) * p.cbias_stride;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) cb[j] = cok[j] ? cbp[col[j]] : 0.0f;
-                }
-            } else {
-                if (p.bias && p.bias_mode == 2) {
-                    const long long m = (long long)tile_m * BM + wm * WM + rw;
-                    const float br = m < p.M ? p.bias[m] : 0.0f;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) cb[j] = br;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * 32 + lr] = acc[i][j][r] * p.alpha + bcol[j] + cb[j];
-        }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
-    __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // 3) row-major read-back: each lane handles 16-byte output chunks of one row
-    const bool out_f32 = (!CONV && p.c_f32) || ES == 4;
-    const int epo = out_f32 ? 4 : 8;           // elements per 16-byte output chunk
-    const int cpr = WN / epo;                  // chunks per row of the wave's slab
-    const int total = WM * cpr;
-    const int ncol0 = n0 + wn * WN;
-    for (int f = lane; f < total; f += 64) {
-        const int rw = f / cpr, cj = (f - rw * cpr) * epo;
-        const int c = ncol0 + cj;
-        if (c >= p.Ncols) continue;
-        long long o;  // element offset of (row, c) in the output
-        if constexpr (CONV) {
-            int nrel, ho, wo;
-            if (!decode_row(wm * WM + rw, nrel, ho, wo)) continue;
-            o = ((((long long)(n_first + nrel) * p.Ho + ho) * p.Wo + wo)) * p.Cout + c;
-        } else {
-            const long long m = (long long)tile_m * BM + wm * WM + rw;
-            if (m >= p.M) continue;
-            o = offC + m * p.ldc + c;
-        }
-        const float* sp = slab + rw * EP_LD + cj;
-        const bool full = (c + epo <= p.Ncols) && (((o * (out_f32 ? 4 : 2)) & 15) == 0);
-        if (out_f32) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(sp);
-            float* yo = reinterpret_cast<float*>(p.y) + o;
-            const float* ro = p.res ? reinterpret_cast<const float*>(p.res) + o : nullptr;
-            if (full) {
-                if (ro) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(ro);
-                    v += rv;
-                }
-                *reinterpret_cast<f32x4*>(yo) = v;
+    // ---- fragment addressing ----
+    const int lr = lane & 31, lh = lane >> 5;
+    int prow0[TM];  // patch row of this lane's output pixel for tap (0,0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + lr;
+        prow0[i] = (r >> 4) * PW + (r & 15);
+    }
+    const int bsw = (lr >> 1) & 7;
+    int bcoff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bcoff[s] = ((2 * s + lh) ^ bsw) * 16;
+    const int b_rd = (wn * WN + lr) * BKB;
+
+    const int KC = p.kc0 + p.kc1;
+    // ---- prologue: whole patch of chunk 0 + weights of step 0 ----
+    {
+        const Chunk c0 = chunk_of(0);
+#pragma unroll
+        for (int i = 0; i < LAH; ++i)
+            if ((wave + 4 * i) < PG) issue_patch_piece(i, c0, sA);
+        issue_weights(0, c0, sB);
+    }
+    bool prev_piece = false;  // did the previous K-step issue a patch piece AFTER its weight pieces?
+    int step = 0;
+    for (int cc = 0; cc < KC; ++cc) {
+        const Chunk cur = chunk_of(cc);
+        const bool has_next = cc + 1 < KC;
+        const Chunk nxt = chunk_of(has_next ? cc + 1 : cc);
+        const char* abuf = sA + (cc & 1) * ABUF;
+        char* abuf_next = sA + ((cc + 1) & 1) * ABUF;
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++step) {
+            if (step == 0 || !prev_piece) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                for (int e = 0; e < 4 && c + e < p.Ncols; ++e) yo[e] = v[e] + (ro ? ro[e] : 0.0f);
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             }
-        } else {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-            half_t* yo = reinterpret_cast<half_t*>(p.y) + o;
-            const half_t* ro = p.res ? reinterpret_cast<const half_t*>(p.res) + o : nullptr;
-            if (full) {
-                half8 h;
-                if (ro) {
-                    const half8 rv = *reinterpret_cast<const half8*>(ro);
+            __builtin_amdgcn_s_barrier();
+            // DMA for the next K-step: weights first, then (taps 0..5) one piece of the next chunk's patch
+            if (t < 8) {
+                issue_weights(t + 1, cur, sB + ((step + 1) & 1) * BSTAGE);
+            } else if (has_next) {
+                issue_weights(0, nxt, sB + ((step + 1) & 1) * BSTAGE);
+            }
+            prev_piece = false;
+            if (t < LAH && has_next && (wave + 4 * t) < PG) {
+                issue_patch_piece(t, nxt, abuf_next);
+                prev_piece = true;
+            }
+            // ---- MFMAs of tap t: A fragments = patch rows shifted by (dy, dx) ----
+            const int dy = t / 3, dx = t - dy * 3;
+            const char* bst = sB + (step & 1) * BSTAGE;
+            int arow[TM], asw[TM];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = (half_t)(v0[e] + (float)rv[e]);
-                        h[e + 4] = (half_t)(v1[e] + (float)rv[e + 4]);
-                    }
-                } else {
+            for (int i = 0; i < TM; ++i) {
+                const int prow = prow0[i] + dy * PW + dx;
+                arow[i] = prow * BKB;
+                asw[i] = (prow >> 1) & 7;
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = (half_t)v0[e];
-                        h[e + 4] = (half_t)v1[e];
-                    }
-                }
-                *reinterpret_cast<half8*>(yo) = h;
-            } else {
-                for (int e = 0; e < 8 && c + e < p.Ncols; ++e) {
-                    const float x = (e < 4 ? v0[e] : v1[e - 4]) + (ro ? (float)ro[e] : 0.0f);
-                    yo[e] = (half_t)x;
-                }
+            for (int s = 0; s < 4; ++s) {
+                i32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((2 * s + lh) ^ asw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + bcoff[s]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
+    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N>(p, g, acc, smem, wave, lane, n0);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -569,6 +789,38 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
+template <typename T, int BN, int WAVES_M, int WAVES_N>
+static int launch_halo(IgemmP& p, hipStream_t st) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    constexpr int WM = 128 / WAVES_M, WN = BN / WAVES_N;
+    const size_t ring = 2 * (size_t)(23 * 1024) + 2 * (size_t)BN * 128;
+    const size_t epi = 4 * (size_t)WM * (WN + 4) * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    p.kc0 = (p.C0 + BK - 1) / BK;
+    p.kc1 = (p.C1 + BK - 1) / BK;
+    p.KT = (p.kc0 + p.kc1) * 9;
+    p.tiles_n = (p.Ncols + BN - 1) / BN;
+    p.tw_log2 = 4;  // 8 x 16 pixel patches
+    p.th = 8;
+    p.tiles_pw = p.Wo / 16;
+    p.tiles_pi = p.tiles_pw * (p.Ho / 8);
+    p.tiles_m = p.tiles_pi * p.N;
+    const long long nblk = (long long)p.tiles_m * p.tiles_n;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        eod_set_error("conv_halo: bad grid %lld", nblk);
+        return EOD_EINVAL;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    EOD_CHECK_LAUNCH("conv3x3_halo");
+    return EOD_OK;
+}
+
 template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipStream_t st) {
     if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2>(p, batch, st);
     if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2>(p, batch, st);
@@ -625,6 +877,11 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     p.nb1 = 1;
     p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
+    // 3x3 / stride 1 / pad 1 on maps that tile into 8x16 patches: halo-patch kernel (EOD_IGEMM_CFG=3 disables it)
+    const bool halo_ok = d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->upsample && !d->pad_tl && Wo % 16 == 0 &&
+                         Ho % 8 == 0 && d->Cout > 64 && !d->out_nchw_f32 && p.force_cfg != 3 && p.force_cfg != 2 && p.force_cfg != 1;
+    if (halo_ok)
+        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2>(p, st) : launch_halo<float, 128, 2, 2>(p, st);
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }
 

@@ -26,6 +26,9 @@ CONV_CASES = [
     (1, 128, 16, 16, 3, 3, 1, 1, False),        # tiny Cout (BN=32 tiles)
     (1, 8, 16, 16, 128, 3, 1, 1, False),        # tiny Cin (first conv, padded)
     (1, 384, 16, 16, 384, 3, 1, 1, False),
+    (2, 96, 16, 32, 128, 3, 1, 1, False),       # halo-patch kernel, K tail (96 % 64), non-square map
+    (3, 128, 8, 16, 192, 3, 1, 1, False),       # halo-patch kernel, one patch per image, N tail (192 % 128)
+    (1, 640, 32, 32, 256, 3, 1, 1, False),      # halo-patch kernel, 10 channel chunks
 ]
 
 
@@ -54,9 +57,11 @@ def test_conv_vs_torch(prec, case):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-def test_conv_fused_epilogue_concat_residual_temb(prec):
-    """two A sources (virtual concat), per-sample bias (timestep embedding) and residual in one launch"""
-    N, C0, C1, H, W, Cout = 2, 64, 32, 8, 8, 64
+@pytest.mark.parametrize("dims", [(2, 64, 32, 8, 8, 64), (2, 64, 32, 16, 16, 128), (1, 128, 96, 32, 16, 256)])
+def test_conv_fused_epilogue_concat_residual_temb(prec, dims):
+    """two A sources (virtual concat), per-sample bias (timestep embedding) and residual in one launch
+    (second / third shape: the halo-patch kernel with a K tail in the second source)"""
+    N, C0, C1, H, W, Cout = dims
     x0 = synth_input("fx0", (N, C0, H, W), 32)
     x1 = synth_input("fx1", (N, C1, H, W), 32)
     r = synth_input("fr", (N, Cout, H, W), 32)
