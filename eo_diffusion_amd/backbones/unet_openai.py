@@ -192,7 +192,7 @@ class Upsample(_Emitter):
         if not self.use_conv:
             return prog.resample2x(h, 1, pad_tl)
         y, _ = prog.conv(h, prog.pack_conv(self.conv.weight), prog.f32(self.conv.bias), self.out_channels,
-                         ksize=3, stride=1, pad=1, upsample=True, pad_tl=pad_tl)
+                         ksize=3, stride=1, pad=1, upsample=True, pad_tl=pad_tl, stats=True)
         return y
 
     def forward(self, x):
@@ -220,7 +220,7 @@ class Downsample(_Emitter):
         if not self.use_conv:
             return prog.resample2x(h, 0)
         y, _ = prog.conv(h, prog.pack_conv(self.op.weight), prog.f32(self.op.bias), self.out_channels,
-                         ksize=3, stride=2, pad=1)
+                         ksize=3, stride=2, pad=1, stats=True)
         return y
 
     def forward(self, x):
@@ -298,14 +298,14 @@ class ResBlock(TimestepBlock):
         off = ctx.offsets[id(self)]
         emb_ptr_off = ctx.out[:, off:]  # view: pointer to column `off`, row stride J
         if self.use_scale_shift_norm:
-            h1, _ = prog.conv(hn, prog.pack_conv(conv1.weight), prog.f32(conv1.bias), cout)
+            h1, _ = prog.conv(hn, prog.pack_conv(conv1.weight), prog.f32(conv1.bias), cout, stats=True)
             h2 = prog.group_norm([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), silu=True, eps=gn2.eps,
                                  film=emb_ptr_off, film_stride=ctx.J)
             # FiLM layout: emb_out[:, :cout] = scale, [:, cout:] = shift (th.chunk, :379); the finalize kernel
             # reads shift at +Ctot (= cout)
         else:
             h1, _ = prog.conv(hn, prog.pack_conv(conv1.weight), prog.f32(conv1.bias), cout, cbias=emb_ptr_off,
-                              cbias_stride=ctx.J)
+                              cbias_stride=ctx.J, stats=True)
             h2 = prog.group_norm([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), silu=True, eps=gn2.eps)
         if isinstance(self.skip_connection, nn.Identity):
             if len(srcs) != 1:
@@ -316,7 +316,8 @@ class ResBlock(TimestepBlock):
             k = sc.kernel_size[0]
             skip, _ = prog.conv(srcs[0], prog.pack_conv(sc.weight), prog.f32(sc.bias), cout,
                                 x2=srcs[1] if len(srcs) > 1 else None, ksize=k, stride=1, pad=k // 2)
-        out, _ = prog.conv(h2, prog.pack_conv(conv2.weight), prog.f32(conv2.bias), cout, res=skip)
+        # every block output feeds a GroupNorm next (in_layers / attention norm / out head): emit its partial sums here
+        out, _ = prog.conv(h2, prog.pack_conv(conv2.weight), prog.f32(conv2.bias), cout, res=skip, stats=True)
         return out
 
     def forward(self, x, emb):
@@ -591,7 +592,8 @@ class UNetModel(_Emitter):
         # ---- encoder ----
         hs = []
         conv0 = self.input_blocks[0][0]
-        h, i0 = prog.conv(a0, prog.pack_conv(conv0.weight, cin_pad=c_pad), prog.f32(conv0.bias), conv0.out_channels)
+        h, i0 = prog.conv(a0, prog.pack_conv(conv0.weight, cin_pad=c_pad), prog.f32(conv0.bias), conv0.out_channels,
+                          stats=True)
         prog.ops[i0]._cin_alg = cx + ccond  # algorithmic K excludes the zero padding (bench accounting only)
         hs.append(h)
         for blk in list(self.input_blocks)[1:]:

@@ -58,6 +58,8 @@ struct IgemmP {
     long long M;
     int Ncols, K, taps, KT, tiles_m, tiles_n, out_nchw;
     int kc0, kc1;  // conv: channel chunks of source 0 / source 1 (K-steps = taps * (kc0 + kc1))
+    float* stats;  // optional GroupNorm partial sums of the output: [N][stats_P][Cout][2]
+    int stats_P, tiles_per_image;
     int force_cfg; // 0 auto, 1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage (EOD_IGEMM_CFG, tuning only)
     float alpha;
 };
@@ -251,6 +253,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     const int cpr = WN / epo;                  // chunks per row of the wave's slab
     const int total = WM * cpr;
     const int ncol0 = n0 + wn * WN;
+    // optional GroupNorm partial statistics of the STORED values (sum, sum of squares per output channel over the
+    // wave's WM rows).  A lane always owns the same 16-byte column chunk (64 % cpr == 0), so it accumulates `epo`
+    // columns in registers; lanes that share a chunk are combined with wave shuffles at the end (fixed order).
+    const bool want_stats = CONV && p.stats != nullptr;
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.0f;
     for (int f = lane; f < total; f += 64) {
         const int rw = f / cpr, cj = (f - rw * cpr) * epo;
         const int c = ncol0 + cj;
@@ -277,6 +286,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                     v += rv;
                 }
                 *reinterpret_cast<f32x4*>(yo) = v;
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        st_s[e] += v[e];
+                        st_q[e] += v[e] * v[e];
+                    }
+                }
             } else {
                 for (int e = 0; e < 4 && c + e < p.Ncols; ++e) yo[e] = v[e] + (ro ? ro[e] : 0.0f);
             }
@@ -301,10 +317,41 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                     }
                 }
                 *reinterpret_cast<half8*>(yo) = h;
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (float)h[e];
+                        st_s[e] += x;
+                        st_q[e] += x * x;
+                    }
+                }
             } else {
                 for (int e = 0; e < 8 && c + e < p.Ncols; ++e) {
                     const float x = (e < 4 ? v0[e] : v1[e - 4]) + (ro ? (float)ro[e] : 0.0f);
                     yo[e] = (half_t)x;
+                }
+            }
+        }
+    }
+    if constexpr (CONV) {
+        if (want_stats) {
+            // lanes l, l+cpr, l+2cpr, ... own the same columns: butterfly over the lane bits above log2(cpr)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                for (int o = 32; o >= cpr; o >>= 1) {
+                    st_s[e] += __shfl_xor(st_s[e], o);
+                    st_q[e] += __shfl_xor(st_q[e], o);
+                }
+            }
+            if (lane < cpr) {
+                const int tile_in_img = (p.tw_log2 >= 0) ? (g.tile_m - g.n_first * p.tiles_per_image) : (g.rem_first / BM);
+                const int slot = tile_in_img * WAVES_M + wm;
+                float* dst = p.stats + (((long long)g.n_first * p.stats_P + slot) * p.Cout + ncol0 + lane * epo) * 2;
+                for (int e = 0; e < epo; ++e) {
+                    if (ncol0 + lane * epo + e < p.Ncols) {
+                        dst[2 * e] = st_s[e];
+                        dst[2 * e + 1] = st_q[e];
+                    }
                 }
             }
         }
@@ -830,6 +877,31 @@ template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipSt
     return launch_cfg<T, CONV, 128, 128, 2, 2, 2>(p, batch, st);
 }
 
+// which kernel configuration a conv descriptor gets (shared by the launcher and eod_conv_stats_slots)
+static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo, int force) {
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->upsample && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 &&
+           d->Cout > 64 && !d->out_nchw_f32 && force != 3 && force != 2 && force != 1;
+}
+static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
+    if (halo) return 2;
+    if (d->Cout <= 64) return 4;
+    return force == 2 ? 4 : 2;
+}
+static int conv_bm(const eod_conv_desc* d, bool halo, int force) { return (!halo && d->Cout > 64 && force == 2) ? 256 : 128; }
+
+extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
+    if (!d || d->out_nchw_f32) return 0;
+    if (d->Cout % (16 / eod_esize(d->dtype))) return 0;  // statistics are accumulated on full 16-byte output chunks only
+    const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
+    const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    const int force = igemm_forced_cfg();
+    const bool halo = conv_uses_halo(d, Ho, Wo, force);
+    const int bm = conv_bm(d, halo, force);
+    if ((Ho * Wo) % bm != 0) return 0;  // tiles must not straddle images
+    return (Ho * Wo / bm) * conv_waves_m(d, halo, force);
+}
+
 extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     EOD_REQUIRE(d, "conv: null desc");
     EOD_REQUIRE(d->dtype == EOD_F32 || d->dtype == EOD_F16, "conv: bad dtype %d", d->dtype);
@@ -878,8 +950,14 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
     // 3x3 / stride 1 / pad 1 on maps that tile into 8x16 patches: halo-patch kernel (EOD_IGEMM_CFG=3 disables it)
-    const bool halo_ok = d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->upsample && !d->pad_tl && Wo % 16 == 0 &&
-                         Ho % 8 == 0 && d->Cout > 64 && !d->out_nchw_f32 && p.force_cfg != 3 && p.force_cfg != 2 && p.force_cfg != 1;
+    const bool halo_ok = conv_uses_halo(d, Ho, Wo, p.force_cfg);
+    if (d->stats) {
+        const int slots = eod_conv_stats_slots(d);
+        EOD_REQUIRE(slots > 0 && slots == d->stats_slots, "conv: stats_slots=%d but this geometry provides %d", d->stats_slots, slots);
+        p.stats = d->stats;
+        p.stats_P = slots;
+        p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
+    }
     if (halo_ok)
         return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2>(p, st) : launch_halo<float, 128, 2, 2>(p, st);
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);

@@ -86,20 +86,33 @@ extern "C" int eod_gn_partial(const void* x, int dtype, int N, int HW, int C, fl
 //     y = x*scale + shift,  scale = rstd*gamma,  shift = beta - mean*rstd*gamma
 // FiLM (use_scale_shift_norm, unet_openai.py:377-381): y' = y*(1+s) + t with film[n] = [s(0..C) | t(0..C)].
 // ---------------------------------------------------------------------------------------------
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int P, int Ctot, long long HW, int groups, float eps,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ film, long long film_stride, float* __restrict__ ss) {
+__global__ void gn_finalize_kernel(const float* __restrict__ part0, int P0, int C0, const float* __restrict__ part1, int P1,
+                                   int C1, long long HW, int groups, float eps, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ film, long long film_stride,
+                                   float* __restrict__ ss) {
     __shared__ double rs[256], rq[256];
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int Ctot = C0 + C1;
     const int cpg = Ctot / groups;
     const int c0 = g * cpg;
     double s = 0.0, q = 0.0;
-    const int total = P * cpg;
-    for (int i = tid; i < total; i += 256) {
-        const int p = i / cpg, c = c0 + (i - p * cpg);
-        const float* pp = part + (((long long)n * P + p) * Ctot + c) * 2;
+    // channels of this group living in source 0 / source 1 (a group may straddle the concat seam)
+    const int a0 = min(c0, C0), a1 = min(c0 + cpg, C0);  // [a0, a1) in source 0
+    const int n0c = a1 - a0, n1c = cpg - n0c;
+    for (int i = tid; i < P0 * n0c; i += 256) {
+        const int p = i / n0c, c = a0 + (i - p * n0c);
+        const float* pp = part0 + (((long long)n * P0 + p) * C0 + c) * 2;
         s += (double)pp[0];
         q += (double)pp[1];
+    }
+    if (n1c > 0) {
+        const int b0 = max(c0, C0) - C0;  // first channel inside source 1
+        for (int i = tid; i < P1 * n1c; i += 256) {
+            const int p = i / n1c, c = b0 + (i - p * n1c);
+            const float* pp = part1 + (((long long)n * P1 + p) * C1 + c) * 2;
+            s += (double)pp[0];
+            q += (double)pp[1];
+        }
     }
     rs[tid] = s;
     rq[tid] = q;
@@ -131,13 +144,14 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, int P, int Ct
     }
 }
 
-extern "C" int eod_gn_finalize(const float* part, int N, int P, int Ctot, int64_t HW, int groups, float eps,
-                               const float* gamma, const float* beta, const float* film, int64_t film_stride,
-                               float* scale_shift, void* stream) {
-    EOD_REQUIRE(part && gamma && beta && scale_shift, "gn_finalize: null pointer");
-    EOD_REQUIRE(N > 0 && P > 0 && groups > 0 && Ctot % groups == 0, "gn_finalize: Ctot=%d groups=%d", Ctot, groups);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part, P, Ctot, (long long)HW,
-                       groups, eps, gamma, beta, film, (long long)film_stride, scale_shift);
+extern "C" int eod_gn_finalize(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW,
+                               int groups, float eps, const float* gamma, const float* beta, const float* film,
+                               int64_t film_stride, float* scale_shift, void* stream) {
+    EOD_REQUIRE(part0 && gamma && beta && scale_shift, "gn_finalize: null pointer");
+    EOD_REQUIRE(N > 0 && P0 > 0 && C0 > 0 && C1 >= 0 && (C1 == 0 || (part1 && P1 > 0)) && groups > 0 && (C0 + C1) % groups == 0,
+                "gn_finalize: C0=%d C1=%d groups=%d", C0, C1, groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part0, P0, C0, part1, P1, C1,
+                       (long long)HW, groups, eps, gamma, beta, film, (long long)film_stride, scale_shift);
     EOD_CHECK_LAUNCH("gn_finalize");
     return EOD_OK;
 }

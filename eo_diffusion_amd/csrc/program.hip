@@ -7,8 +7,8 @@
 //
 // eod_small_desc field use per op kind:
 //   GN_PARTIAL : p[0]=x p[1]=part            i = {dtype, N, HW, C, P, Ctot, coff}
-//   GN_FINALIZE: p[0]=part p[1]=gamma p[2]=beta p[3]=film p[4]=scale_shift   l = {HW, film_stride}
-//                i = {N, P, Ctot, groups}    f = {eps}
+//   GN_FINALIZE: p[0]=part0 p[1]=gamma p[2]=beta p[3]=film p[4]=scale_shift p[5]=part1   l = {HW, film_stride}
+//                i = {N, P0, C0, groups, P1, C1}    f = {eps}
 //   GN_APPLY   : p[0]=x p[1]=scale_shift p[2]=y   i = {dtype, N, HW, C, Ctot, coff, silu}
 //   SOFTMAX    : p[0]=s p[1]=p               l = {lds, ldp, rows}   i = {dtype, n}
 //   TO_NHWC    : p[0]=src0 p[1]=src1 p[2]=dst     i = {C0, C1, dtype, N, H, W, c_pad}
@@ -108,8 +108,9 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
                 rc = eod_gn_partial(s.p[0], s.i[0], s.i[1], s.i[2], s.i[3], (float*)s.p[1], s.i[4], s.i[5], s.i[6], stream);
                 break;
             case EOD_OP_GN_FINALIZE:
-                rc = eod_gn_finalize((const float*)s.p[0], s.i[0], s.i[1], s.i[2], s.l[0], s.i[3], s.f[0], (const float*)s.p[1],
-                                     (const float*)s.p[2], (const float*)s.p[3], s.l[1], (float*)s.p[4], stream);
+                rc = eod_gn_finalize((const float*)s.p[0], s.i[1], s.i[2], (const float*)s.p[5], s.i[4], s.i[5], s.i[0], s.l[0],
+                                     s.i[3], s.f[0], (const float*)s.p[1], (const float*)s.p[2], (const float*)s.p[3], s.l[1],
+                                     (float*)s.p[4], stream);
                 break;
             case EOD_OP_GN_APPLY:
                 rc = eod_gn_apply(s.p[0], s.i[0], s.i[1], s.i[2], s.i[3], (const float*)s.p[1], s.i[4], s.i[5], s.i[6], (void*)s.p[2], stream);

@@ -33,10 +33,11 @@ def require_gpu(t, what):
 
 class Act:
     """Channels-last activation handle: tensor of shape [N, H, W, C] in the storage dtype."""
-    __slots__ = ("t", "N", "H", "W", "C")
+    __slots__ = ("t", "N", "H", "W", "C", "stats")
 
-    def __init__(self, t, N, H, W, C):
+    def __init__(self, t, N, H, W, C, stats=None):
         self.t, self.N, self.H, self.W, self.C = t, N, H, W, C
+        self.stats = stats  # (fp32 tensor [N][P][C][2], P): GroupNorm partial sums emitted by the producing conv
 
     @property
     def HW(self):
@@ -120,7 +121,7 @@ class Program:
         self.bindings.setdefault(name, []).append((op_index, setter))
 
     def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
-             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None):
+             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False):
         ups = 2 if upsample else 1
         heff, weff = x.H * ups + int(pad_tl), x.W * ups + int(pad_tl)
         ho = (heff + 2 * pad - ksize) // stride + 1
@@ -139,6 +140,12 @@ class Program:
         else:
             y = out if out is not None else self.act(x.N, ho, wo, cout)
             d.y = ptr(y.t)
+            if stats:
+                slots = self.L.eod_conv_stats_slots(C.byref(d))
+                if slots > 0:  # the epilogue emits the next GroupNorm's per-channel partial sums for free
+                    st = self.empty((x.N, slots, cout, 2), torch.float32)
+                    d.stats, d.stats_slots = ptr(st), slots
+                    y.stats = (st, slots)
         if x2 is not None:
             assert (x2.N, x2.H, x2.W) == (x.N, x.H, x.W)
         if res is not None:
@@ -184,15 +191,22 @@ class Program:
         ctot = sum(s.C for s in srcs)
         if ctot % groups:
             raise ValueError(f"GroupNorm: {ctot} channels not divisible by {groups} groups")
-        P = max(1, min(256, HW // 64))
-        part = self.empty((N, P, ctot, 2), torch.float32)
-        ss = self.empty((N, ctot, 2), torch.float32)
-        coff = 0
+        parts = []
         for s in srcs:
-            self._small(OP_GN_PARTIAL, p=(ptr(s.t), ptr(part)), i=(self.dt, N, HW, s.C, P, ctot, coff))
-            coff += s.C
-        self._small(OP_GN_FINALIZE, p=(ptr(part), ptr(gamma), ptr(beta), ptr(film) if film is not None else 0, ptr(ss)),
-                    l=(HW, film_stride), i=(N, P, ctot, groups), f=(eps,))
+            if s.stats is not None:       # emitted by the producing conv's epilogue
+                parts.append((s.stats[0], s.stats[1], s.C))
+            else:
+                P = max(1, min(256, HW // 64))
+                part = self.empty((N, P, s.C, 2), torch.float32)
+                self._small(OP_GN_PARTIAL, p=(ptr(s.t), ptr(part)), i=(self.dt, N, HW, s.C, P, s.C, 0))
+                parts.append((part, P, s.C))
+        if len(parts) > 2:
+            raise ValueError("GroupNorm over more than two concatenated sources is not supported")
+        ss = self.empty((N, ctot, 2), torch.float32)
+        p1 = parts[1] if len(parts) == 2 else (None, 0, 0)
+        self._small(OP_GN_FINALIZE,
+                    p=(ptr(parts[0][0]), ptr(gamma), ptr(beta), ptr(film) if film is not None else 0, ptr(ss), ptr(p1[0])),
+                    l=(HW, film_stride), i=(N, parts[0][1], parts[0][2], groups, p1[1], p1[2]), f=(eps,))
         y = self.act(N, H, W, ctot)
         coff = 0
         for s in srcs:

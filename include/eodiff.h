@@ -65,8 +65,15 @@ typedef struct {
     int32_t Ho, Wo;      /* output spatial dims */
     int32_t out_nchw_f32;
     float alpha;
+    float* stats;        /* optional OUT: per-channel GroupNorm partial sums of y, [N][stats_slots][Cout][2] (sum, sumsq),
+                            produced by the epilogue (saves the statistics read pass of the next GroupNorm); NULL = off */
+    int32_t stats_slots; /* must equal eod_conv_stats_slots(d) when stats != NULL */
+    int32_t _pad;
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
+/* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
+ * images, NCHW output): the caller sizes `stats` with it. */
+int eod_conv_stats_slots(const eod_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * k3/k7/k8: batched GEMM on MFMA,  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] (+bias)(+res)
@@ -109,15 +116,17 @@ int eod_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, int H, int W
  * k5: GroupNorm32(32, C) [+ SiLU]  (unet_openai.py:11-13, 71-78, 312-316, 336-343, 739-743)
  * three stream-ordered phases, deterministic (no atomics):
  *   partial : per (n, pixel-chunk p, channel) sum / sum-of-squares       -> part[N][P][Ctot][2]
- *   finalize: per (n, group) mean/rstd over BOTH concat sources, folded with gamma/beta (and the
+ *             (skipped when the producing conv already emitted them: eod_conv_desc.stats)
+ *   finalize: per (n, group) mean/rstd over BOTH concat sources (part0 [N][P0][C0][2] | part1 [N][P1][C1][2],
+ *             part1 may be NULL), folded with gamma/beta (and the
  *             FiLM scale/shift of use_scale_shift_norm :377-381) into scale/shift[N][Ctot]
  *   apply   : y = act(x * scale + shift), written at channel offset `coff` of a Ctot-wide tensor
  * ------------------------------------------------------------------------------------------ */
 int eod_gn_partial(const void* x, int dtype, int N, int HW, int C, float* part, int P, int Ctot,
                    int coff, void* stream);
-int eod_gn_finalize(const float* part, int N, int P, int Ctot, int64_t HW, int groups, float eps,
-                    const float* gamma, const float* beta, const float* film, int64_t film_stride,
-                    float* scale_shift, void* stream);
+int eod_gn_finalize(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW,
+                    int groups, float eps, const float* gamma, const float* beta, const float* film,
+                    int64_t film_stride, float* scale_shift, void* stream);
 int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot,
                  int coff, int silu, void* y, void* stream);
 
