@@ -36,6 +36,8 @@
 //    the residual added on the way: whole 128/256-byte lines per row instead of 2-byte scattered stores.
 //  * workgroup -> tile mapping is XCD-aware (bijective remap, guide T1): the N-tiles of one M-tile and
 //    neighbouring M-tiles land on the same XCD's L2.
+#include <type_traits>
+
 #include "common.h"
 
 struct IgemmP {
@@ -157,7 +159,7 @@ __device__ __forceinline__ void map_tile(const IgemmP& p, int& tile_m, int& tile
 // (fp32, wave-private slab), 16-byte stores along the channel axis with the residual added on the way.
 // Precondition: every wave has passed a barrier after its last LDS read of the operand ring.
 // =============================================================================================
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, bool OUTF32>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                char* smem, int wave, int lane, int n0) {
     constexpr int ES = sizeof(T);
@@ -215,6 +217,54 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
         return;
     }
 
+    // 3) row-major read-back: each lane handles ITER 16-byte output chunks (one row each)
+    constexpr int EPO = OUTF32 ? 4 : 8;          // elements per 16-byte output chunk
+    constexpr int CPR = WN / EPO;                // chunks per row of the wave's slab
+    constexpr int ITER = WM * CPR / 64;          // chunks per lane
+    static_assert(64 % CPR == 0 && (WM * CPR) % 64 == 0, "epilogue mapping");
+    typedef typename std::conditional<OUTF32, float, half_t>::type OT;
+    const int ncol0 = n0 + wn * WN;
+    const int cj = (lane % CPR) * EPO;           // a lane always owns the same column chunk
+    const int c = ncol0 + cj;
+    const bool c_ok = c < p.Ncols;
+    const bool c_full = c + EPO <= p.Ncols;
+    long long off[ITER];
+    bool ok[ITER];
+    i32x4 rv[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int rw = it * (64 / CPR) + lane / CPR;
+        ok[it] = c_ok;
+        if constexpr (CONV) {
+            int nrel, ho, wo;
+            ok[it] = ok[it] && decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo);
+            off[it] = ((((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo)) * p.Cout + c;
+        } else {
+            const long long m = (long long)g.tile_m * BM + wm * WM + rw;
+            ok[it] = ok[it] && m < p.M;
+            off[it] = g.offC + m * p.ldc + c;
+        }
+        rv[it] = i32x4{0, 0, 0, 0};
+    }
+    // residual: issue ALL loads now, so that their latency overlaps the LDS transpose below (a rolled loop would
+    // expose one HBM round trip per chunk)
+    const bool vec = c_full && ((p.Cout * (int)sizeof(OT)) % 16 == 0 || !CONV);
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const OT* ro = reinterpret_cast<const OT*>(p.res) + off[it];
+            if (ok[it]) {
+                if (vec && ((reinterpret_cast<uintptr_t>(ro) & 15) == 0)) {
+                    rv[it] = *reinterpret_cast<const i32x4*>(ro);
+                } else {
+                    OT tmp[EPO];
+                    for (int e = 0; e < EPO; ++e) tmp[e] = (c + e < p.Ncols) ? ro[e] : (OT)0.0f;
+                    rv[it] = *reinterpret_cast<const i32x4*>(tmp);
+                }
+            }
+        }
+    }
+
     // 2) transpose through LDS: each wave owns a [WM][EP_LD] fp32 slab (the ring is free after the last barrier)
     float* slab = reinterpret_cast<float*>(smem) + wave * (WM * EP_LD);
 #pragma unroll
@@ -247,108 +297,68 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
     __builtin_amdgcn_wave_barrier();
 
-    // 3) row-major read-back: each lane handles 16-byte output chunks of one row
-    const bool out_f32 = (!CONV && p.c_f32) || ES == 4;
-    const int epo = out_f32 ? 4 : 8;           // elements per 16-byte output chunk
-    const int cpr = WN / epo;                  // chunks per row of the wave's slab
-    const int total = WM * cpr;
-    const int ncol0 = n0 + wn * WN;
-    // optional GroupNorm partial statistics of the STORED values (sum, sum of squares per output channel over the
-    // wave's WM rows).  A lane always owns the same 16-byte column chunk (64 % cpr == 0), so it accumulates `epo`
-    // columns in registers; lanes that share a chunk are combined with wave shuffles at the end (fixed order).
+    // optional GroupNorm partial statistics of the STORED values (sum / sum of squares per output channel over the
+    // wave's WM rows): accumulated per lane over its ITER rows, combined across the lanes that share a column chunk.
     const bool want_stats = CONV && p.stats != nullptr;
-    float st_s[8], st_q[8];
+    float st_s[EPO], st_q[EPO];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.0f;
-    for (int f = lane; f < total; f += 64) {
-        const int rw = f / cpr, cj = (f - rw * cpr) * epo;
-        const int c = ncol0 + cj;
-        if (c >= p.Ncols) continue;
-        long long o;  // element offset of (row, c) in the output
-        if constexpr (CONV) {
-            int nrel, ho, wo;
-            if (!decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo)) continue;
-            o = ((((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo)) * p.Cout + c;
-        } else {
-            const long long m = (long long)g.tile_m * BM + wm * WM + rw;
-            if (m >= p.M) continue;
-            o = g.offC + m * p.ldc + c;
-        }
+    for (int e = 0; e < EPO; ++e) st_s[e] = st_q[e] = 0.0f;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int rw = it * (64 / CPR) + lane / CPR;
         const float* sp = slab + rw * EP_LD + cj;
-        const bool full = (c + epo <= p.Ncols) && (((o * (out_f32 ? 4 : 2)) & 15) == 0);
-        if (out_f32) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(sp);
-            float* yo = reinterpret_cast<float*>(p.y) + o;
-            const float* ro = p.res ? reinterpret_cast<const float*>(p.res) + o : nullptr;
-            if (full) {
-                if (ro) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(ro);
-                    v += rv;
-                }
-                *reinterpret_cast<f32x4*>(yo) = v;
-                if (want_stats) {
+        float v[EPO];
+        {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        st_s[e] += v[e];
-                        st_q[e] += v[e] * v[e];
-                    }
-                }
-            } else {
-                for (int e = 0; e < 4 && c + e < p.Ncols; ++e) yo[e] = v[e] + (ro ? ro[e] : 0.0f);
+            for (int e = 0; e < 4; ++e) v[e] = v0[e];
+            if constexpr (EPO == 8) {
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 + e] = v1[e];
             }
+        }
+        OT o_[EPO];
+        {
+            OT rr[EPO];
+            *reinterpret_cast<i32x4*>(rr) = rv[it];
+#pragma unroll
+            for (int e = 0; e < EPO; ++e) o_[e] = (OT)(v[e] + (float)rr[e]);
+        }
+        if (!ok[it]) continue;
+        OT* yo = reinterpret_cast<OT*>(p.y) + off[it];
+        if (vec && ((reinterpret_cast<uintptr_t>(yo) & 15) == 0)) {
+            *reinterpret_cast<i32x4*>(yo) = *reinterpret_cast<const i32x4*>(o_);
         } else {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-            half_t* yo = reinterpret_cast<half_t*>(p.y) + o;
-            const half_t* ro = p.res ? reinterpret_cast<const half_t*>(p.res) + o : nullptr;
-            if (full) {
-                half8 h;
-                if (ro) {
-                    const half8 rv = *reinterpret_cast<const half8*>(ro);
+            for (int e = 0; e < EPO && c + e < p.Ncols; ++e) yo[e] = o_[e];
+        }
+        if (want_stats) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = (half_t)(v0[e] + (float)rv[e]);
-                        h[e + 4] = (half_t)(v1[e] + (float)rv[e + 4]);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        h[e] = (half_t)v0[e];
-                        h[e + 4] = (half_t)v1[e];
-                    }
-                }
-                *reinterpret_cast<half8*>(yo) = h;
-                if (want_stats) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float x = (float)h[e];
-                        st_s[e] += x;
-                        st_q[e] += x * x;
-                    }
-                }
-            } else {
-                for (int e = 0; e < 8 && c + e < p.Ncols; ++e) {
-                    const float x = (e < 4 ? v0[e] : v1[e - 4]) + (ro ? (float)ro[e] : 0.0f);
-                    yo[e] = (half_t)x;
-                }
+            for (int e = 0; e < EPO; ++e) {
+                const float x = (float)o_[e];
+                st_s[e] += x;
+                st_q[e] += x * x;
             }
         }
     }
     if constexpr (CONV) {
         if (want_stats) {
-            // lanes l, l+cpr, l+2cpr, ... own the same columns: butterfly over the lane bits above log2(cpr)
+            // lanes l, l+CPR, l+2CPR, ... own the same columns: butterfly over the lane bits above log2(CPR)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                for (int o = 32; o >= cpr; o >>= 1) {
+            for (int e = 0; e < EPO; ++e) {
+#pragma unroll
+                for (int o = 32; o >= CPR; o >>= 1) {
                     st_s[e] += __shfl_xor(st_s[e], o);
                     st_q[e] += __shfl_xor(st_q[e], o);
                 }
             }
-            if (lane < cpr) {
+            if (lane < CPR && c_ok) {
                 const int tile_in_img = (p.tw_log2 >= 0) ? (g.tile_m - g.n_first * p.tiles_per_image) : (g.rem_first / BM);
                 const int slot = tile_in_img * WAVES_M + wm;
-                float* dst = p.stats + (((long long)g.n_first * p.stats_P + slot) * p.Cout + ncol0 + lane * epo) * 2;
-                for (int e = 0; e < epo; ++e) {
-                    if (ncol0 + lane * epo + e < p.Ncols) {
+                float* dst = p.stats + (((long long)g.n_first * p.stats_P + slot) * p.Cout + c) * 2;
+#pragma unroll
+                for (int e = 0; e < EPO; ++e) {
+                    if (c + e < p.Ncols) {
                         dst[2 * e] = st_s[e];
                         dst[2 * e + 1] = st_q[e];
                     }
@@ -582,7 +592,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my fragment reads are done ...
     __builtin_amdgcn_s_barrier();        // ... and so are everybody else's: the ring can be reused by the epilogue
 
-    igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N>(p, g, acc, smem, wave, lane, n0);
+    if constexpr (sizeof(T) == 4) {
+        igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(p, g, acc, smem, wave, lane, n0);
+    } else {
+        if (!CONV && p.c_f32)
+            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(p, g, acc, smem, wave, lane, n0);
+        else
+            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, false>(p, g, acc, smem, wave, lane, n0);
+    }
 }
 
 // =============================================================================================
@@ -599,14 +616,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 //     (taps 0..5)].  vmcnt retires in order, so the wait for step s's weights is vmcnt(1) when a patch piece was
 //     issued after them and vmcnt(0) otherwise: every patch piece gets two full K-steps to land.
 //   * everything else (MFMA tiling, buffer-descriptor OOB zero fill, concat sources, epilogue) is shared with igemm.
-// Requirements (checked by the launcher, otherwise the generic kernel runs): ksize 3, stride 1, pad 1, no upsample,
-// Wo % 16 == 0, Ho % 8 == 0.
+// Requirements (checked by the launcher, otherwise the generic kernel runs): ksize 3, stride 1, pad 1, Wo % 16 == 0,
+// Ho % 8 == 0 (with or without the virtual nearest-2x upsampling of the input).
 // =============================================================================================
-template <typename T, int BN, int WAVES_M, int WAVES_N>
+// UPS = true: the conv input is the nearest-2x upsampling of x (Upsample.conv, unet_openai.py:236-241).  The 8x16
+// output tile then reads only a (8/2+2) x (16/2+2) = 6 x 10 patch of the STORED half-resolution tensor: output pixel
+// (u, v) + tap reads patch row ((u+1)>>1, (v+1)>>1) -- the 2x image is never materialised and A traffic drops ~28x.
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
-    constexpr int BM = 128, TH = 8, TW = 16, PW = TW + 2, PR = (TH + 2) * PW;  // 180 patch rows
-    constexpr int PG = (PR + 7) / 8;                                             // 23 DMA groups of 8 rows
-    constexpr int LAH = (PG + 3) / 4;                                            // 6 patch pieces per wave
+    constexpr int BM = 128, TH = 8, TW = 16;
+    constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2, PR = PH * PW;  // 180 (60) patch rows
+    constexpr int PG = (PR + 7) / 8;                                             // 23 (8) DMA groups of 8 rows
+    constexpr int LAH = (PG + 3) / 4;                                            // 6 (2) patch pieces per wave
     constexpr int ES = sizeof(T), EPC = 16 / ES, BKB = 128, BK = BKB / ES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
     constexpr int GB = BN / 8, LB = GB / 4;
@@ -633,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
     for (int i = 0; i < LAH; ++i) {
         const int prow = (wave + 4 * i) * 8 + srow;
         const int py = prow / PW, px = prow - py * PW;
-        const int hi = g.ty0 - 1 + py, wi = g.tx0 - 1 + px;
+        const int hi = (UPS ? g.ty0 / 2 : g.ty0) - 1 + py, wi = (UPS ? g.tx0 / 2 : g.tx0) - 1 + px;
         const bool ok = (wave + 4 * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         pchunk[i] = sslot ^ ((prow >> 1) & 7);
         const unsigned pix = (unsigned)(hi * p.W + wi);
@@ -697,11 +718,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
 
     // ---- fragment addressing ----
     const int lr = lane & 31, lh = lane >> 5;
-    int prow0[TM];  // patch row of this lane's output pixel for tap (0,0)
+    int prow0[TM], pyo[TM], pxo[TM];  // patch row of this lane's output pixel for tap (0,0) / its tile coordinates
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + lr;
-        prow0[i] = (r >> 4) * PW + (r & 15);
+        pyo[i] = r >> 4;
+        pxo[i] = r & 15;
+        prow0[i] = pyo[i] * PW + pxo[i];
     }
     const int bsw = (lr >> 1) & 7;
     int bcoff[4];
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
             int arow[TM], asw[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int prow = prow0[i] + dy * PW + dx;
+                const int prow = UPS ? ((pyo[i] + dy + 1) >> 1) * PW + ((pxo[i] + dx + 1) >> 1) : prow0[i] + dy * PW + dx;
                 arow[i] = prow * BKB;
                 asw[i] = (prow >> 1) & 7;
             }
@@ -772,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
-    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N>(p, g, acc, smem, wave, lane, n0);
+    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4>(p, g, acc, smem, wave, lane, n0);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -836,14 +859,14 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int WM = 128 / WAVES_M, WN = BN / WAVES_N;
-    const size_t ring = 2 * (size_t)(23 * 1024) + 2 * (size_t)BN * 128;
+    const size_t ring = 2 * (size_t)((UPS ? 8 : 23) * 1024) + 2 * (size_t)BN * 128;
     const size_t epi = 4 * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -879,7 +902,7 @@ template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipSt
 
 // which kernel configuration a conv descriptor gets (shared by the launcher and eod_conv_stats_slots)
 static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo, int force) {
-    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->upsample && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 &&
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 &&
            d->Cout > 64 && !d->out_nchw_f32 && force != 3 && force != 2 && force != 1;
 }
 static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
@@ -958,8 +981,11 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.stats_P = slots;
         p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
     }
-    if (halo_ok)
-        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2>(p, st) : launch_halo<float, 128, 2, 2>(p, st);
+    if (halo_ok) {
+        if (d->upsample)
+            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, true>(p, st) : launch_halo<float, 128, 2, 2, true>(p, st);
+        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false>(p, st) : launch_halo<float, 128, 2, 2, false>(p, st);
+    }
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }
 

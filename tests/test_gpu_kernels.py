@@ -29,6 +29,8 @@ CONV_CASES = [
     (2, 96, 16, 32, 128, 3, 1, 1, False),       # halo-patch kernel, K tail (96 % 64), non-square map
     (3, 128, 8, 16, 192, 3, 1, 1, False),       # halo-patch kernel, one patch per image, N tail (192 % 128)
     (1, 640, 32, 32, 256, 3, 1, 1, False),      # halo-patch kernel, 10 channel chunks
+    (2, 128, 8, 8, 128, 3, 1, 1, True),         # upsample halo-patch kernel (6x10 input patch), 16x16 output
+    (1, 96, 16, 24, 192, 3, 1, 1, True),        # upsample halo, K tail, N tail, non-square
 ]
 
 
