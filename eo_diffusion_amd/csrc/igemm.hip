@@ -576,17 +576,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         // (issuing the DMA instructions one by one between the MFMA sub-steps was measured: no gain, -5..10 %)
         if (kt + STAGES - 1 < KT) issue_loads((kt + STAGES - 1) % STAGES);
         const char* sb = smem + (kt % STAGES) * STAGE;
+        // fragments are read one sub-step ahead of their MFMAs and the {ds_read group, MFMA group} order is pinned
+        // (see conv3x3_halo_kernel): +5 % over hipcc's own read-then-wait schedule
+        i32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + coff[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + coff[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            i32x4 fa[TM], fb[TN];
+            const int cur = s & 1, nx = cur ^ 1;
+            if (s < 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + coff[s]);
+                for (int i = 0; i < TM; ++i) fa[nx][i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + coff[s + 1]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + coff[s]);
+                for (int j = 0; j < TN; ++j) fb[nx][j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + coff[s + 1]);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) Mma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my fragment reads are done ...
@@ -778,18 +790,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
                 arow[i] = prow * BKB;
                 asw[i] = (prow >> 1) & 7;
             }
+            // fragments are read ONE sub-step ahead of the MFMAs that consume them (two register sets), and the order
+            // {4 ds_read of s+1, 4 MFMA of s} is pinned: left to itself hipcc reads each fragment right before its MFMA
+            // and waits lgkmcnt(0) ~6 times per K-step, exposing the LDS latency every time.
+            i32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[0][i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((0 + lh) ^ asw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + bcoff[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                i32x4 fa[TM], fb[TN];
+                const int cur = s & 1, nx = cur ^ 1;
+                if (s < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[nx][i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((2 * (s + 1) + lh) ^ asw[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[nx][j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + bcoff[s + 1]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((2 * s + lh) ^ asw[i]) << 4));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + bcoff[s]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) Mma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
             }
         }
     }
