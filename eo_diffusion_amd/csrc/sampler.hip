@@ -130,6 +130,44 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// classifier-free guidance (ddim.py:177-181): e = e_uncond + scale * (e_cond - e_uncond)
+__global__ void cfg_combine_kernel(const float* __restrict__ eu, const float* __restrict__ ec, float scale, float* __restrict__ out,
+                                   long long numel) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
+        const float d = ec[i] - eu[i];
+        const float m = scale * d;
+        out[i] = eu[i] + m;
+    }
+}
+
+// table-driven DDPM step of the LDM-derived sampler (ddpm.py:221-255): predict_start_from_noise, clamp, q_posterior,
+// noise scaled by exp(0.5 * posterior_log_variance_clipped) and masked out at t == 0 (per sample, not per batch).
+template <bool CLIP>
+__global__ void ldm_p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                    const long long* __restrict__ t, const float* __restrict__ sr, const float* __restrict__ srm1,
+                                    const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ lv,
+                                    float* __restrict__ out, long long chw) {
+    const int n = blockIdx.y;
+    const long long tn = t[n];
+    const float a = sr[tn], b = srm1[tn], k1 = c1[tn], k2 = c2[tn];
+    const float nonzero = 1.0f - (tn == 0 ? 1.0f : 0.0f);
+    const float sd = expf(0.5f * lv[tn]);
+    const float ns = nonzero * sd;
+    const long long base = (long long)n * chw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (long long)gridDim.x * blockDim.x) {
+        const float xv = x[base + i];
+        const float u = a * xv;
+        const float v = b * eps[base + i];
+        float x0 = u - v;
+        if (CLIP) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        const float p = k1 * x0;
+        const float q = k2 * xv;
+        const float mean = p + q;
+        const float z = ns * noise[base + i];
+        out[base + i] = mean + z;
+    }
+}
+
 static inline unsigned blocks_for(long long n, int cap) {
     long long b = (n + 255) / 256;
     if (b > cap) b = cap;
@@ -220,5 +258,26 @@ extern "C" int eod_randn_philox(float* out, int N, int64_t chw, uint64_t seed, i
     EOD_REQUIRE(out && N > 0 && chw > 0, "randn_philox: bad args");
     hipLaunchKernelGGL(randn_philox_kernel, dim3(blocks_for((chw + 3) / 4, 512), N), dim3(256), 0, (hipStream_t)stream, out, (long long)chw, (unsigned long long)seed, (long long)sample0, step, stream_id);
     EOD_CHECK_LAUNCH("randn_philox");
+    return EOD_OK;
+}
+
+extern "C" int eod_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, int64_t numel, void* stream) {
+    EOD_REQUIRE(e_uncond && e_cond && out && numel > 0, "cfg_combine: bad args");
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(blocks_for(numel, 4096)), dim3(256), 0, (hipStream_t)stream, e_uncond, e_cond, scale, out, (long long)numel);
+    EOD_CHECK_LAUNCH("cfg_combine");
+    return EOD_OK;
+}
+
+extern "C" int eod_ldm_p_sample(const float* x, const float* eps, const float* noise, const int64_t* t, const float* sqrt_recip_acp,
+                                const float* sqrt_recipm1_acp, const float* post_coef1, const float* post_coef2,
+                                const float* post_logvar, float* out, int N, int64_t chw, int clip, void* stream) {
+    EOD_REQUIRE(x && eps && noise && t && sqrt_recip_acp && sqrt_recipm1_acp && post_coef1 && post_coef2 && post_logvar && out && N > 0 && chw > 0,
+                "ldm_p_sample: bad args");
+    dim3 grid(blocks_for(chw, 512), N);
+    if (clip)
+        hipLaunchKernelGGL(ldm_p_sample_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, eps, noise, (const long long*)t, sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2, post_logvar, out, (long long)chw);
+    else
+        hipLaunchKernelGGL(ldm_p_sample_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, eps, noise, (const long long*)t, sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2, post_logvar, out, (long long)chw);
+    EOD_CHECK_LAUNCH("ldm_p_sample");
     return EOD_OK;
 }

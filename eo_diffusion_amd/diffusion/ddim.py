@@ -142,7 +142,15 @@ class DDIMSampler(object):
         if unconditional_conditioning is None or unconditional_guidance_scale == 1.0:
             e_t = self.model.model(x, t, cond=c)
         else:
-            raise NotImplementedError("classifier-free guidance branch (ddim.py:177-181) is not built yet")
+            # classifier-free guidance (ddim.py:177-181): one UNet call on the doubled batch, then a fused combine
+            x_in = torch.cat([x] * 2)
+            t_in = torch.cat([t] * 2)
+            c_in = torch.cat([unconditional_conditioning, c])
+            e_both = self.model.model(x_in, t_in, cond=c_in)
+            e_u, e_c = e_both[: x.shape[0]], e_both[x.shape[0]:]
+            e_t = torch.empty_like(e_c)
+            _lib.check(_lib.lib().eod_cfg_combine(e_u.data_ptr(), e_c.data_ptr(), float(unconditional_guidance_scale),
+                                                  e_t.data_ptr(), e_t.numel(), current_stream_ptr(device)), "eod_cfg_combine")
         a_t = float(self.ddim_alphas[index])
         a_prev = float(self.ddim_alphas_prev[index])
         sigma_t = float(self.ddim_sigmas[index])

@@ -175,6 +175,13 @@ int eod_ddpm_step(const float* x_t, const float* pred, const float* noise, const
 int eod_ddim_step(const float* x, const float* e_t, const float* noise, float a_t, float a_prev,
                   float sigma_t, float sqrt_1m_at, float temperature, float* x_prev, float* pred_x0,
                   int64_t numel, void* stream);
+/* classifier-free guidance of p_sample_ddim (ddim.py:177-181): out = e_uncond + scale * (e_cond - e_uncond) */
+int eod_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, int64_t numel, void* stream);
+/* table-driven DDPM step of the LDM-derived sampler: DDPM.p_sample ddpm.py:248-255 with predict_start_from_noise :221-225,
+ * q_posterior :227-234 (tables of register_schedule :122-162, fp32 [T]); noise masked per sample at t == 0. */
+int eod_ldm_p_sample(const float* x, const float* eps, const float* noise, const int64_t* t, const float* sqrt_recip_acp,
+                     const float* sqrt_recipm1_acp, const float* post_coef1, const float* post_coef2,
+                     const float* post_logvar, float* out, int N, int64_t chw, int clip, void* stream);
 /* k15: counter-based N(0,1): Philox4x32-10 keyed by seed, counter = (element/4, sample0+n, step, stream_id)
  * -> results are invariant to how samples are sharded over ranks. */
 int eod_randn_philox(float* out, int N, int64_t chw, uint64_t seed, int64_t sample0, int32_t step,

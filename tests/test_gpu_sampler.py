@@ -118,3 +118,41 @@ def test_philox_matches_numpy_reference_and_is_shard_invariant():
     assert np.abs(full.numpy() - ref).max() < 2e-5
     big = m._philox((4, 3, 64, 64), torch.device(DEV), 99, 0, 3, 1).cpu()
     assert abs(float(big.mean())) < 0.02 and abs(float(big.std()) - 1.0) < 0.02
+
+
+def test_ldm_ddpm_tables_and_step_vs_oracle():
+    """ddpm.py-flavoured sampler: tables == oracle restatement (same float64 numpy ops), fused p_sample vs oracle."""
+    from eo_diffusion_amd.diffusion.ddpm import DDPM
+
+    class Fixed(torch.nn.Module):
+        def forward(self, x, t, cond=None, y=None):
+            return self.pred
+
+    for sch in ("linear", "cosine"):
+        m = DDPM(Fixed(), timesteps=1000, beta_schedule=sch, image_size=8, channels=3).to(DEV)
+        lt = SCH.ldm_register_schedule(SCH.ldm_beta_schedule(sch, 1000))
+        for k, v in lt.items():
+            assert bits_equal(getattr(m, k).cpu(), v), (sch, k)
+        x = synth_input("lx", (3, 3, 6, 5), 41)
+        e = synth_input("le", (3, 3, 6, 5), 41)
+        z = synth_input("lz", (3, 3, 6, 5), 41)
+        for tv in ([999, 500, 1], [0, 0, 7], [3, 0, 250]):
+            t = torch.tensor(tv)
+            m.model.pred = e.to(DEV)
+            for clip in (True, False):
+                got = m.p_sample(x.to(DEV), t.to(DEV), clip_denoised=clip, noise=z.to(DEV)).cpu()
+                ref = SR.ldm_p_sample(lt, x, t, e, z, clip_denoised=clip)
+                assert float((got - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max())), (sch, tv, clip)
+        q = m.q_sample(x.to(DEV), torch.tensor([0, 10, 999]).to(DEV), z.to(DEV)).cpu()
+        assert bits_equal(q, SR.q_sample(lt, x, torch.tensor([0, 10, 999]), z))
+
+
+def test_cfg_combine_bit_exact():
+    from eo_diffusion_amd import _lib
+    eu = synth_input("cu", (2, 3, 9, 7), 42).to(DEV)
+    ec = synth_input("cc", (2, 3, 9, 7), 42).to(DEV)
+    out = torch.empty_like(eu)
+    _lib.check(_lib.lib().eod_cfg_combine(eu.data_ptr(), ec.data_ptr(), 3.5, out.data_ptr(), out.numel(),
+                                          torch.cuda.current_stream().cuda_stream))
+    ref = eu.cpu() + 3.5 * (ec.cpu() - eu.cpu())
+    assert bits_equal(out.cpu(), ref)

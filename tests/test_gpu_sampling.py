@@ -67,3 +67,66 @@ def test_philox_sampling_is_invariant_to_batch_sharding():
     lo = m.sampling(2, device=DEV, rng="philox", seed=7, sample_offset=0, progress=False)
     hi = m.sampling(2, device=DEV, rng="philox", seed=7, sample_offset=2, progress=False)
     assert torch.equal(torch.cat([lo, hi]), full)
+
+
+def test_ddim_classifier_free_guidance_branch():
+    """ddim.py:177-181: doubled batch through the UNet (concat conditioning), then e_u + s*(e_c - e_u)."""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from eo_diffusion_amd.diffusion.ddim import DDIMSampler
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    from oracle import sampler_ref as SR
+    from oracle import schedule as SCH
+    from oracle import unet_ref as UR
+    from tests.synth import synth_input
+    cfg = dict(image_size=16, in_channels=7, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[2],
+               channel_mult=[1, 2], num_heads=2)
+    sd = synth_state_dict(unet_param_shapes(**cfg), 7)
+    u = UNetModel(**cfg).set_precision("fp32")
+    u.load_state_dict(sd)
+    m = EODiffusion(u, timesteps=20, image_size=16, in_channels=3, device=DEV).to(DEV).eval()
+    s = DDIMSampler(m)
+    s.make_schedule(ddim_num_steps=10, ddim_eta=0.0, verbose=False)
+    x = synth_input("gx", (2, 3, 16, 16), 51)
+    c = synth_input("gc", (2, 4, 16, 16), 51, uniform=True)
+    uc = torch.zeros_like(c)
+    nz = synth_input("gn", (2, 3, 16, 16), 51)
+    index = 5
+    t = torch.full((2,), int(s.ddim_timesteps[index]), dtype=torch.long)
+    xp, p0 = s.p_sample_ddim(x.to(DEV), c.to(DEV), t.to(DEV), index=index, unconditional_guidance_scale=2.5,
+                             unconditional_conditioning=uc.to(DEV), _noise=nz)
+    e_u = UR.unet_forward(sd, cfg, x, t, cond=uc)
+    e_c = UR.unet_forward(sd, cfg, x, t, cond=c)
+    e = e_u + 2.5 * (e_c - e_u)
+    tb = SCH.eo_cosine_tables(20)
+    dd = SCH.ddim_tables(tb["alphas_cumprod"], SCH.ddim_timesteps("uniform", 10, 20), 0.0)
+    rxp, rp0 = SR.ddim_step(x, e, dd["a"][index], dd["a_prev"][index], dd["sigma"][index], dd["sqrt_1m_a"][index], nz)
+    assert rel_l2(xp.cpu(), rxp) < 2e-5 and rel_l2(p0.cpu(), rp0) < 2e-5
+
+
+def test_ldm_ddpm_loop_with_mask_vs_oracle():
+    """DDPM.p_sample_loop (ddpm.py:1296-1345): mask mix AFTER the step with fresh noise."""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from eo_diffusion_amd.diffusion.ddpm import DDPM
+    from oracle import sampler_ref as SR
+    from oracle import schedule as SCH
+    from oracle import unet_ref as UR
+    from tests.synth import rect_mask, synth_input
+    cfg = unet_cfgs()["u_a0_tiny"]
+    sd = synth_state_dict(unet_param_shapes(**cfg), 7)
+    u = UNetModel(**cfg).set_precision("fp32")
+    u.load_state_dict(sd)
+    T = 8
+    m = DDPM(u, timesteps=T, beta_schedule="linear", image_size=16, channels=3).to(DEV).eval()
+    lt = SCH.ldm_register_schedule(SCH.ldm_beta_schedule("linear", T))
+    xT = synth_input("dxT", (2, 3, 16, 16), 61)
+    x0 = synth_input("dx0", (2, 3, 16, 16), 61, uniform=True)
+    mask = rect_mask(2, 16, 16, 61)
+    noises = [synth_input(f"dn{k}", (2, 3, 16, 16), 61) for k in range(T)]
+    mixes = [synth_input(f"dm{k}", (2, 3, 16, 16), 61) for k in range(T)]
+    out = m.p_sample_loop((2, 3, 16, 16), x_T=xT, mask=mask, x0=x0, noises=noises, mix_noises=mixes).cpu()
+    img = xT
+    for k, i in enumerate(reversed(range(T))):
+        ts = torch.full((2,), i, dtype=torch.long)
+        img = SR.ldm_p_sample(lt, img, ts, UR.unet_forward(sd, cfg, img, ts), noises[k])
+        img = SR.q_sample(lt, x0, ts, mixes[k]) * mask + (1.0 - mask) * img
+    assert rel_l2(out, img) < 2e-5
