@@ -299,7 +299,9 @@ class Program:
                 fl = 2.0 * m * d.Cout * cin_alg * d.ksize * d.ksize
                 by = es * (d.N * d.H * d.W * cin + d.ksize * d.ksize * d.Cout * cin + (0 if d.out_nchw_f32 else m * d.Cout)) \
                     + (4 * m * d.Cout if d.out_nchw_f32 else 0) + (es * m * d.Cout if d.res else 0)
-                out.append(dict(kind="conv", flops=fl, bytes=by,
+                halo = (d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and d.Wo % 16 == 0 and d.Ho % 8 == 0
+                        and d.Cout > 64 and not d.out_nchw_f32)  # mirrors conv_uses_halo() in csrc/igemm.hip
+                out.append(dict(kind="conv", flops=fl, bytes=by, kernel="conv3x3_halo_kernel" if halo else "igemm_kernel",
                                 label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"))
             elif k == OP_GEMM:
                 d = op.u.gemm
