@@ -77,6 +77,7 @@ SYMBOLS = {
     "eod_timer_create": (vp, [i32, i32]),
     "eod_timer_destroy": (None, [vp]),
     "eod_timer_read": (i32, [vp, C.POINTER(f32)]),
+    "eod_timer_set_mask": (i32, [vp, vp, i32]),
     "eod_program_run_timed": (i32, [C.POINTER(Op), i32, vp, vp]),
     "eod_resample2x": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
 }

@@ -634,21 +634,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // UPS = true: the conv input is the nearest-2x upsampling of x (Upsample.conv, unet_openai.py:236-241).  The 8x16
 // output tile then reads only a (8/2+2) x (16/2+2) = 6 x 10 patch of the STORED half-resolution tensor: output pixel
 // (u, v) + tap reads patch row ((u+1)>>1, (v+1)>>1) -- the 2x image is never materialised and A traffic drops ~28x.
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
-    constexpr int BM = 128, TH = 8, TW = 16;
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel(const IgemmP p) {
+    constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
+    constexpr int BM = 32 * NW, TH = BM / 16, TW = 16;
     constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2, PR = PH * PW;  // 180 (60) patch rows
     constexpr int PG = (PR + 7) / 8;                                             // 23 (8) DMA groups of 8 rows
-    constexpr int LAH = (PG + 3) / 4;                                            // 6 (2) patch pieces per wave
+    constexpr int LAH = (PG + NW - 1) / NW;                                      // patch pieces per wave
     constexpr int ES = sizeof(T), EPC = 16 / ES, BKB = 128, BK = BKB / ES;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
-    constexpr int GB = BN / 8, LB = GB / 4;
+    constexpr int GB = BN / 8, LB = GB / NW;
     constexpr int ABUF = PG * 1024, BSTAGE = BN * BKB;
-    static_assert(WAVES_M * WAVES_N == 4 && GB % 4 == 0 && LAH <= 6, "layout");
+    static_assert(GB % NW == 0 && LAH <= 6 && (BSTAGES == 2 || BSTAGES == 3), "layout");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;              // [2][ABUF]
-    char* const sB = smem + 2 * ABUF;   // [2][BSTAGE]
+    char* const sB = smem + 2 * ABUF;   // [BSTAGES][BSTAGE]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -664,10 +665,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
     int pchunk[LAH];
 #pragma unroll
     for (int i = 0; i < LAH; ++i) {
-        const int prow = (wave + 4 * i) * 8 + srow;
+        const int prow = (wave + NW * i) * 8 + srow;
         const int py = prow / PW, px = prow - py * PW;
         const int hi = (UPS ? g.ty0 / 2 : g.ty0) - 1 + py, wi = (UPS ? g.tx0 / 2 : g.tx0) - 1 + px;
-        const bool ok = (wave + 4 * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         pchunk[i] = sslot ^ ((prow >> 1) & 7);
         const unsigned pix = (unsigned)(hi * p.W + wi);
         pv0[i] = ok ? pix * (unsigned)(p.C0 * ES) + pchunk[i] * 16 : EOD_OOB;
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
     int b_chunk[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int row = (wave + 4 * i) * 8 + srow;
+        const int row = (wave + NW * i) * 8 + srow;
         b_chunk[i] = sslot ^ ((row >> 1) & 7);
         b_v[i] = (n0 + row < p.Ncols) ? (unsigned)(row * p.Cin * ES) + b_chunk[i] * 16 : EOD_OOB;
     }
@@ -706,9 +707,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
         unsigned v = c.src ? pv1[i] : pv0[i];
         if (c.ktail) v = (c.kin + pchunk[i] * EPC < c.cw) ? v : EOD_OOB;
         if (c.src)
-            blds16(rsA1, v, (unsigned)(c.kin * ES), abuf + (wave + 4 * i) * 1024);
+            blds16(rsA1, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
         else
-            blds16(rsA0, v, (unsigned)(c.kin * ES), abuf + (wave + 4 * i) * 1024);
+            blds16(rsA0, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
     };
     auto issue_weights = [&](int tap, const Chunk& c, char* bst) {
         const unsigned soff = (unsigned)(tap * tapstride) + c.bk;
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
         for (int i = 0; i < LB; ++i) {
             unsigned v = b_v[i];
             if (c.ktail) v = (c.kin + b_chunk[i] * EPC < c.cw) ? v : EOD_OOB;
-            blds16(rsB, v, soff, bst + (wave + 4 * i) * 1024);
+            blds16(rsB, v, soff, bst + (wave + NW * i) * 1024);
         }
     };
 
@@ -745,15 +746,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
     const int b_rd = (wn * WN + lr) * BKB;
 
     const int KC = p.kc0 + p.kc1;
-    // ---- prologue: whole patch of chunk 0 + weights of step 0 ----
+    const int NSTEP = KC * 9;
+    // next-chunk lookup for the weight prefetch: step -> (chunk, tap)
+    auto issue_weights_for_step = [&](int st) {
+        const int c = st / 9, t = st - c * 9;
+        issue_weights(t, chunk_of(c), sB + (st % BSTAGES) * BSTAGE);
+    };
+    // ---- prologue: whole patch of chunk 0 + weights of the first BSTAGES-1 steps ----
     {
         const Chunk c0 = chunk_of(0);
 #pragma unroll
         for (int i = 0; i < LAH; ++i)
-            if ((wave + 4 * i) < PG) issue_patch_piece(i, c0, sA);
-        issue_weights(0, c0, sB);
+            if ((wave + NW * i) < PG) issue_patch_piece(i, c0, sA);
+#pragma unroll
+        for (int st = 0; st < BSTAGES - 1; ++st)
+            if (st < NSTEP) issue_weights_for_step(st);
     }
-    bool prev_piece = false;  // did the previous K-step issue a patch piece AFTER its weight pieces?
+    // DMA issued AFTER the weights of the step we are about to wait for may stay in flight (vmcnt retires in order):
+    //   pp1 / pp2 : a patch piece was issued one / two steps ago;  ww1 : weights were issued one step ago (3-stage ring)
+    bool pp1 = false, pp2 = false, ww1 = BSTAGES == 3 && NSTEP > 1;
     int step = 0;
     for (int cc = 0; cc < KC; ++cc) {
         const Chunk cur = chunk_of(cc);
@@ -763,26 +774,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p) {
         char* abuf_next = sA + ((cc + 1) & 1) * ABUF;
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++step) {
-            if (step == 0 || !prev_piece) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            {
+                const int allow = (BSTAGES == 3 ? ((pp2 ? 1 : 0) + (ww1 ? LB : 0)) : 0) + (pp1 ? 1 : 0);
+                switch (allow) {
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                }
             }
             __builtin_amdgcn_s_barrier();
-            // DMA for the next K-step: weights first, then (taps 0..5) one piece of the next chunk's patch
-            if (t < 8) {
-                issue_weights(t + 1, cur, sB + ((step + 1) & 1) * BSTAGE);
-            } else if (has_next) {
-                issue_weights(0, nxt, sB + ((step + 1) & 1) * BSTAGE);
+            // DMA for step + BSTAGES - 1: weights first, then (taps 0..LAH-1) one piece of the next chunk's patch
+            pp2 = pp1;
+            ww1 = false;
+            if (step + BSTAGES - 1 < NSTEP) {
+                issue_weights_for_step(step + BSTAGES - 1);
+                ww1 = true;
             }
-            prev_piece = false;
-            if (t < LAH && has_next && (wave + 4 * t) < PG) {
+            pp1 = false;
+            if (t < LAH && has_next && (wave + NW * t) < PG) {
                 issue_patch_piece(t, nxt, abuf_next);
-                prev_piece = true;
+                pp1 = true;
             }
             // ---- MFMAs of tap t: A fragments = patch rows shifted by (dy, dx) ----
             const int dy = t / 3, dx = t - dy * 3;
-            const char* bst = sB + (step & 1) * BSTAGE;
+            const char* bst = sB + (step % BSTAGES) * BSTAGE;
             int arow[TM], asw[TM];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -886,14 +905,16 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
-    constexpr int WM = 128 / WAVES_M, WN = BN / WAVES_N;
-    const size_t ring = 2 * (size_t)((UPS ? 8 : 23) * 1024) + 2 * (size_t)BN * 128;
-    const size_t epi = 4 * (size_t)WM * (WN + 4) * sizeof(float);
+    constexpr int NW = WAVES_M * WAVES_N, BM = 32 * NW, TH = BM / 16;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int PR = UPS ? (TH / 2 + 2) * 10 : (TH + 2) * 18, PG = (PR + 7) / 8;
+    const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128;
+    const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -903,17 +924,17 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     p.kc1 = (p.C1 + BK - 1) / BK;
     p.KT = (p.kc0 + p.kc1) * 9;
     p.tiles_n = (p.Ncols + BN - 1) / BN;
-    p.tw_log2 = 4;  // 8 x 16 pixel patches
-    p.th = 8;
+    p.tw_log2 = 4;  // TH x 16 pixel patches
+    p.th = TH;
     p.tiles_pw = p.Wo / 16;
-    p.tiles_pi = p.tiles_pw * (p.Ho / 8);
+    p.tiles_pi = p.tiles_pw * (p.Ho / TH);
     p.tiles_m = p.tiles_pi * p.N;
     const long long nblk = (long long)p.tiles_m * p.tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         eod_set_error("conv_halo: bad grid %lld", nblk);
         return EOD_EINVAL;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds, st, p);
     EOD_CHECK_LAUNCH("conv3x3_halo");
     return EOD_OK;
 }
@@ -932,6 +953,7 @@ static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo, int force) {
     return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 &&
            d->Cout > 64 && !d->out_nchw_f32 && force != 3 && force != 2 && force != 1;
 }
+static bool halo_big(const eod_conv_desc* d, int Ho, int force) { return force == 4 && Ho % 16 == 0; }
 static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
     if (halo) return 2;
     if (d->Cout <= 64) return 4;
@@ -1009,9 +1031,11 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
     }
     if (halo_ok) {
+        if (halo_big(d, Ho, p.force_cfg) && !d->upsample && !d->stats)  // tuning variant: 16x16 tile, 8 waves, 3-stage weight ring
+            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 4, 2, false, 3>(p, st) : launch_halo<float, 128, 4, 2, false, 3>(p, st);
         if (d->upsample)
-            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, true>(p, st) : launch_halo<float, 128, 2, 2, true>(p, st);
-        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false>(p, st) : launch_halo<float, 128, 2, 2, false>(p, st);
+            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, true, 2>(p, st) : launch_halo<float, 128, 2, 2, true, 2>(p, st);
+        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false, 2>(p, st) : launch_halo<float, 128, 2, 2, false, 2>(p, st);
     }
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }

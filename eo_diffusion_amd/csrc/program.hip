@@ -44,14 +44,17 @@ extern "C" int eod_struct_size(int kind) {
 // ---- per-op HIP-event timer (measurement only; used by bench.py for the roofline numbers) ----
 struct eod_timer {
     int n_ops, max_runs, runs;
-    hipEvent_t* ev;  // [max_runs][n_ops][2]
+    hipEvent_t* ev;        // [max_runs][n_ops][2]
+    unsigned char* mask;   // [n_ops] 1 = bracket this op with events (default: all)
 };
 
 extern "C" void* eod_timer_create(int n_ops, int max_runs) {
     if (n_ops <= 0 || max_runs <= 0) return nullptr;
-    eod_timer* t = new eod_timer{n_ops, max_runs, 0, nullptr};
+    eod_timer* t = new eod_timer{n_ops, max_runs, 0, nullptr, nullptr};
     const size_t n = (size_t)n_ops * max_runs * 2;
     t->ev = new hipEvent_t[n];
+    t->mask = new unsigned char[n_ops];
+    memset(t->mask, 1, n_ops);
     for (size_t i = 0; i < n; ++i)
         if (hipEventCreate(&t->ev[i]) != hipSuccess) return nullptr;
     return t;
@@ -63,7 +66,16 @@ extern "C" void eod_timer_destroy(void* h) {
     const size_t n = (size_t)t->n_ops * t->max_runs * 2;
     for (size_t i = 0; i < n; ++i) (void)hipEventDestroy(t->ev[i]);
     delete[] t->ev;
+    delete[] t->mask;
     delete t;
+}
+
+// every event pair costs a few microseconds of stream idle time; restrict the bracketing to the ops of interest
+extern "C" int eod_timer_set_mask(void* h, const unsigned char* mask, int n_ops) {
+    eod_timer* t = (eod_timer*)h;
+    EOD_REQUIRE(t && mask && n_ops == t->n_ops, "timer_set_mask: bad args");
+    memcpy(t->mask, mask, n_ops);
+    return EOD_OK;
 }
 
 // after the stream has been synchronised: ms[k] = SUM over recorded runs of op k's duration; returns #runs
@@ -73,6 +85,7 @@ extern "C" int eod_timer_read(void* h, float* ms) {
     for (int k = 0; k < t->n_ops; ++k) ms[k] = 0.0f;
     for (int r = 0; r < t->runs; ++r)
         for (int k = 0; k < t->n_ops; ++k) {
+            if (!t->mask[k]) continue;
             float e = 0.0f;
             hipEvent_t* p = t->ev + ((size_t)r * t->n_ops + k) * 2;
             if (hipEventElapsedTime(&e, p[0], p[1]) != hipSuccess) {
@@ -97,7 +110,8 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
     }
     for (int k = 0; k < n_ops; ++k) {
         const eod_op& o = ops[k];
-        if (ev) (void)hipEventRecord(ev[2 * k], (hipStream_t)stream);
+        const bool timed = ev && tm->mask[k];
+        if (timed) (void)hipEventRecord(ev[2 * k], (hipStream_t)stream);
         const eod_small_desc& s = o.u.small;
         int rc;
         switch (o.kind) {
@@ -131,7 +145,7 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
                 eod_set_error("program_run: op %d has unknown kind %d", k, o.kind);
                 return EOD_EINVAL;
         }
-        if (ev) (void)hipEventRecord(ev[2 * k + 1], (hipStream_t)stream);
+        if (timed) (void)hipEventRecord(ev[2 * k + 1], (hipStream_t)stream);
         if (rc != EOD_OK) {
             char tmp[400];
             strncpy(tmp, g_err, sizeof(tmp) - 1);

@@ -265,12 +265,18 @@ class Program:
             check(self.L.eod_program_run(self._arr, len(self.ops), st), "eod_program_run")
 
     # ------------------------------------------------------------------ measurement (bench.py)
-    def enable_timing(self, max_runs):
-        """bracket every op with HIP events on the launch stream for the next `max_runs` runs"""
+    def enable_timing(self, max_runs, only=None):
+        """bracket ops with HIP events on the launch stream for the next `max_runs` runs; `only` = iterable of op
+        indices to time (default all; every event pair costs a few microseconds of stream idle time)"""
         self.disable_timing()
         self._timer = self.L.eod_timer_create(len(self.ops), max_runs)
         if not self._timer:
             raise _lib.EodError("eod_timer_create failed")
+        if only is not None:
+            mask = (C.c_ubyte * len(self.ops))()
+            for k in only:
+                mask[k] = 1
+            check(self.L.eod_timer_set_mask(self._timer, mask, len(self.ops)), "eod_timer_set_mask")
 
     def read_timing(self):
         """(runs, [ms summed over runs] per op); call after synchronising the stream"""

@@ -220,6 +220,8 @@ int eod_program_run(const eod_op* ops, int n_ops, void* stream);
 void* eod_timer_create(int n_ops, int max_runs);
 void eod_timer_destroy(void* timer);
 int eod_timer_read(void* timer, float* ms);
+/* bracket only the ops whose mask byte is non-zero (each event pair idles the stream for a few microseconds) */
+int eod_timer_set_mask(void* timer, const unsigned char* mask, int n_ops);
 int eod_program_run_timed(const eod_op* ops, int n_ops, void* stream, void* timer);
 /* resblock_updown helpers (unet_openai.py:320-325): mode 0 = 2x2 average pool, 1 = nearest 2x */
 int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y,
