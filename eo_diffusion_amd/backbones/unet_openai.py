@@ -289,24 +289,26 @@ class ResBlock(TimestepBlock):
             raise NotImplementedError("dropout > 0 in train mode is not built yet; call .eval()")
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, conv2 = self.out_layers[0], self.out_layers[3]
-        hn = prog.group_norm(srcs, prog.f32(gn1.weight), prog.f32(gn1.bias), silu=True, eps=gn1.eps)
+        # GroupNorm+SiLU of the block input: statistics here, the normalisation itself is applied inside the conv
+        # (fused into the halo-patch staging) whenever the conv kernel can; resblock_updown needs it materialised.
+        ss1 = prog.gn_stats(srcs, prog.f32(gn1.weight), prog.f32(gn1.bias), eps=gn1.eps)
+        off = ctx.offsets[id(self)]
+        emb_ptr_off = ctx.out[:, off:]  # view: pointer to column `off`, row stride J
+        temb = {} if self.use_scale_shift_norm else dict(cbias=emb_ptr_off, cbias_stride=ctx.J)
         if self.updown:
             if len(srcs) != 1:
                 raise _lib.EodError("resblock_updown over a virtual concat is not supported")
-            hn = self.h_upd._emit(prog, hn)
+            hn = self.h_upd._emit(prog, prog.gn_apply(srcs, ss1, silu=True))
             srcs = [self.x_upd._emit(prog, srcs[0])]
-        off = ctx.offsets[id(self)]
-        emb_ptr_off = ctx.out[:, off:]  # view: pointer to column `off`, row stride J
-        if self.use_scale_shift_norm:
-            h1, _ = prog.conv(hn, prog.pack_conv(conv1.weight), prog.f32(conv1.bias), cout, stats=True)
-            h2 = prog.group_norm([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), silu=True, eps=gn2.eps,
-                                 film=emb_ptr_off, film_stride=ctx.J)
-            # FiLM layout: emb_out[:, :cout] = scale, [:, cout:] = shift (th.chunk, :379); the finalize kernel
-            # reads shift at +Ctot (= cout)
+            h1, _ = prog.conv(hn, prog.pack_conv(conv1.weight), prog.f32(conv1.bias), cout, stats=True, **temb)
         else:
-            h1, _ = prog.conv(hn, prog.pack_conv(conv1.weight), prog.f32(conv1.bias), cout, cbias=emb_ptr_off,
-                              cbias_stride=ctx.J, stats=True)
-            h2 = prog.group_norm([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), silu=True, eps=gn2.eps)
+            h1, _ = prog.conv(srcs[0], prog.pack_conv(conv1.weight), prog.f32(conv1.bias), cout,
+                              x2=srcs[1] if len(srcs) > 1 else None, gn=(ss1, True), stats=True, **temb)
+        if self.use_scale_shift_norm:
+            # FiLM (unet_openai.py:377-381): emb_out[:, :cout] = scale, [:, cout:] = shift, folded into the GN table
+            ss2 = prog.gn_stats([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), eps=gn2.eps, film=emb_ptr_off, film_stride=ctx.J)
+        else:
+            ss2 = prog.gn_stats([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), eps=gn2.eps)
         if isinstance(self.skip_connection, nn.Identity):
             if len(srcs) != 1:
                 raise _lib.EodError("identity skip over a virtual concat is not supported")
@@ -317,7 +319,7 @@ class ResBlock(TimestepBlock):
             skip, _ = prog.conv(srcs[0], prog.pack_conv(sc.weight), prog.f32(sc.bias), cout,
                                 x2=srcs[1] if len(srcs) > 1 else None, ksize=k, stride=1, pad=k // 2)
         # every block output feeds a GroupNorm next (in_layers / attention norm / out head): emit its partial sums here
-        out, _ = prog.conv(h2, prog.pack_conv(conv2.weight), prog.f32(conv2.bias), cout, res=skip, stats=True)
+        out, _ = prog.conv(h1, prog.pack_conv(conv2.weight), prog.f32(conv2.bias), cout, res=skip, stats=True, gn=(ss2, True))
         return out
 
     def forward(self, x, emb):

@@ -60,6 +60,8 @@ struct IgemmP {
     long long M;
     int Ncols, K, taps, KT, tiles_m, tiles_n, out_nchw;
     int kc0, kc1;  // conv: channel chunks of source 0 / source 1 (K-steps = taps * (kc0 + kc1))
+    const float* gn_ss;  // halo kernel: fused GroupNorm of the INPUT: {scale, shift} per (image, input channel), or NULL
+    int gn_silu;
     float* stats;  // optional GroupNorm partial sums of the output: [N][stats_P][Cout][2]
     int stats_P, tiles_per_image;
     int force_cfg; // 0 auto, 1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage (EOD_IGEMM_CFG, tuning only)
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // UPS = true: the conv input is the nearest-2x upsampling of x (Upsample.conv, unet_openai.py:236-241).  The 8x16
 // output tile then reads only a (8/2+2) x (16/2+2) = 6 x 10 patch of the STORED half-resolution tensor: output pixel
 // (u, v) + tap reads patch row ((u+1)>>1, (v+1)>>1) -- the 2x image is never materialised and A traffic drops ~28x.
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel(const IgemmP p) {
     constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
     constexpr int BM = 32 * NW, TH = BM / 16, TW = 16;
@@ -650,6 +652,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;              // [2][ABUF]
     char* const sB = smem + 2 * ABUF;   // [BSTAGES][BSTAGE]
+    char* const sS = sB + BSTAGES * BSTAGE;  // GN only: [2][1024] scale/shift of the 64 channels of a chunk
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -663,6 +666,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     const int srow = lane >> 3, sslot = lane & 7;
     unsigned pv0[LAH], pv1[LAH];
     int pchunk[LAH];
+    unsigned pvalid = 0;  // bit i: this lane's row of piece i lies inside the image (zero padding must stay zero)
 #pragma unroll
     for (int i = 0; i < LAH; ++i) {
         const int prow = (wave + NW * i) * 8 + srow;
@@ -670,6 +674,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         const int hi = (UPS ? g.ty0 / 2 : g.ty0) - 1 + py, wi = (UPS ? g.tx0 / 2 : g.tx0) - 1 + px;
         const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         pchunk[i] = sslot ^ ((prow >> 1) & 7);
+        if (ok) pvalid |= 1u << i;
         const unsigned pix = (unsigned)(hi * p.W + wi);
         pv0[i] = ok ? pix * (unsigned)(p.C0 * ES) + pchunk[i] * 16 : EOD_OOB;
         pv1[i] = ok ? pix * (unsigned)(p.C1 * ES) + pchunk[i] * 16 : EOD_OOB;
@@ -686,6 +691,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(p.a1 ? p.a1 + (long long)g.n_first * p.H * p.W * p.C1 * ES : p.a0);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.b + (long long)n0 * p.Cin * ES);
     const int tapstride = p.Cout * p.Cin * ES;
+    // GN: per-(image, channel) {scale, shift} of the fused GroupNorm(+FiLM), fp32 pairs; exact num_records so that the
+    // 64-channel chunk read of a channel tail returns zeros instead of touching memory behind the table
+    __amdgpu_buffer_rsrc_t rsS = rsB;
+    if constexpr (GN)
+        rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gn_ss) + (long long)g.n_first * p.Cin * 2, 0, p.Cin * 8, 0x00020000);
 
     // chunk state (wave-uniform): source, channel offset inside the source, tail flag, weight K offset (bytes)
     struct Chunk {
@@ -710,6 +720,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
             blds16(rsA1, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
         else
             blds16(rsA0, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
+    };
+    // GN: wave 0 stages the chunk's 64 x {scale, shift} (512 B) next to the patch; every wave then normalises the patch
+    // pieces IT has DMA'd (its own vmcnt tells it when they have landed): x -> silu(x*scale + shift), in place in LDS,
+    // once per element (the 9 taps read the normalised patch).  Rows outside the image (conv zero padding) and masked
+    // channel tails are left untouched (zero).
+    auto issue_ss = [&](const Chunk& c, char* ssbuf) {
+        // the whole offset goes through the range-checked per-lane part (exact num_records: a channel tail reads zeros)
+        const unsigned v = lane < 32 ? (unsigned)(lane * 16 + ((c.src ? p.C0 : 0) + c.kin) * 8) : EOD_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void*)ssbuf, 16, v, 0, 0, 0);
+    };
+    auto transform_piece = [&](int i, const Chunk& c, char* abuf, const char* ssbuf) {
+        const bool ok = ((pvalid >> i) & 1u) && (!c.ktail || (c.kin + pchunk[i] * EPC < c.cw));
+        char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
+        const float* sp = reinterpret_cast<const float*>(ssbuf) + pchunk[i] * EPC * 2;
+        const i32x4 raw = *reinterpret_cast<const i32x4*>(ptr);
+        i32x4 outv;
+        if constexpr (ES == 2) {
+            const half8 h = __builtin_bit_cast(half8, raw);
+            half8 o;
+            f32x4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (float)h[e] * q[e >> 1][(e & 1) * 2] + q[e >> 1][(e & 1) * 2 + 1];
+                if (p.gn_silu) v = silu_f<true>(v);
+                o[e] = (half_t)v;
+            }
+            outv = __builtin_bit_cast(i32x4, o);
+        } else {
+            const f32x4 f = __builtin_bit_cast(f32x4, raw);
+            f32x4 o;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            const float sc[4] = {q0[0], q0[2], q1[0], q1[2]}, sh[4] = {q0[1], q0[3], q1[1], q1[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = f[e] * sc[e] + sh[e];
+                if (p.gn_silu) v = silu_f<false>(v);
+                o[e] = v;
+            }
+            outv = __builtin_bit_cast(i32x4, o);
+        }
+        if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
     };
     auto issue_weights = [&](int tap, const Chunk& c, char* bst) {
         const unsigned soff = (unsigned)(tap * tapstride) + c.bk;
@@ -758,13 +811,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
         for (int i = 0; i < LAH; ++i)
             if ((wave + NW * i) < PG) issue_patch_piece(i, c0, sA);
+        if constexpr (GN) {
+            if (wave == 0) issue_ss(c0, sS);
+        }
 #pragma unroll
         for (int st = 0; st < BSTAGES - 1; ++st)
             if (st < NSTEP) issue_weights_for_step(st);
+        if constexpr (GN) {
+            // chunk 0: everything has to land before the first tap anyway; normalise the own pieces now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // wave 0's scale/shift table is visible
+#pragma unroll
+            for (int i = 0; i < LAH; ++i)
+                if ((wave + NW * i) < PG) transform_piece(i, c0, sA, sS);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my LDS writes are done before the loop's first barrier
+        }
     }
     // DMA issued AFTER the weights of the step we are about to wait for may stay in flight (vmcnt retires in order):
     //   pp1 / pp2 : a patch piece was issued one / two steps ago;  ww1 : weights were issued one step ago (3-stage ring)
-    bool pp1 = false, pp2 = false, ww1 = BSTAGES == 3 && NSTEP > 1;
+    int pp1 = 0, pp2 = 0;
+    bool ww1 = BSTAGES == 3 && NSTEP > 1 && !GN;  // (GN: the prologue already drained everything)
     int step = 0;
     for (int cc = 0; cc < KC; ++cc) {
         const Chunk cur = chunk_of(cc);
@@ -775,7 +841,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++step) {
             {
-                const int allow = (BSTAGES == 3 ? ((pp2 ? 1 : 0) + (ww1 ? LB : 0)) : 0) + (pp1 ? 1 : 0);
+                const int allow = (BSTAGES == 3 ? (pp2 + (ww1 ? LB : 0)) : 0) + pp1;
                 switch (allow) {
                     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -786,6 +852,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                     default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
                 }
             }
+            if constexpr (GN) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): in-place normalisation writes are done
             __builtin_amdgcn_s_barrier();
             // DMA for step + BSTAGES - 1: weights first, then (taps 0..LAH-1) one piece of the next chunk's patch
             pp2 = pp1;
@@ -794,10 +861,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                 issue_weights_for_step(step + BSTAGES - 1);
                 ww1 = true;
             }
-            pp1 = false;
+            pp1 = 0;
             if (t < LAH && has_next && (wave + NW * t) < PG) {
                 issue_patch_piece(t, nxt, abuf_next);
-                pp1 = true;
+                pp1 = 1;
+            }
+            if constexpr (GN) {
+                if (t == 0 && has_next && wave == 0) {
+                    issue_ss(nxt, sS + ((cc + 1) & 1) * 1024);
+                    ++pp1;
+                }
             }
             // ---- MFMAs of tap t: A fragments = patch rows shifted by (dy, dx) ----
             const int dy = t / 3, dx = t - dy * 3;
@@ -836,6 +909,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
                     for (int j = 0; j < TN; ++j) Mma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
+            }
+            if constexpr (GN) {
+                // piece (t-2) of the NEXT chunk was issued two steps ago and is covered by this step's vmcnt wait;
+                // the scale/shift table (wave 0, tap 0) became visible with this step's barrier (t >= 2).
+                // (spreading these ~110 VALU ops into the MFMA gaps with sched_group_barrier was measured: 3 % SLOWER)
+                if (t >= 2 && t - 2 < LAH && has_next && (wave + NW * (t - 2)) < PG)
+                    transform_piece(t - 2, nxt, abuf_next, sS + ((cc + 1) & 1) * 1024);
             }
         }
     }
@@ -905,16 +985,16 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int NW = WAVES_M * WAVES_N, BM = 32 * NW, TH = BM / 16;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int PR = UPS ? (TH / 2 + 2) * 10 : (TH + 2) * 18, PG = (PR + 7) / 8;
-    const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128;
+    const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128 + (GN ? 2048 : 0);
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -960,6 +1040,22 @@ static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
     return force == 2 ? 4 : 2;
 }
 static int conv_bm(const eod_conv_desc* d, bool halo, int force) { return (!halo && d->Cout > 64 && force == 2) ? 256 : 128; }
+
+// 1 if eod_conv2d_igemm can apply GroupNorm(+SiLU) to the conv INPUT on the fly (gn_scale_shift) for this geometry.
+// The fused form re-normalises the halo patch once per N-tile (Cout / 128 times), so it only pays while the conv has
+// few N-tiles; measured on MI355X: worth it for Cout <= 256, the separate apply pass wins beyond.
+extern "C" int eod_conv_gn_fusable(const eod_conv_desc* d) {
+    if (!d || d->upsample) return 0;
+    const int Ho = (d->H + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    const int Wo = (d->W + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    static int max_cout = -1;
+    if (max_cout < 0) {
+        const char* e = getenv("EOD_GN_FUSE_MAX_COUT");
+        max_cout = e ? atoi(e) : 256;
+    }
+    if (d->Cout > max_cout) return 0;
+    return conv_uses_halo(d, Ho, Wo, igemm_forced_cfg()) ? 1 : 0;
+}
 
 extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     if (!d || d->out_nchw_f32) return 0;
@@ -1031,12 +1127,19 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
     }
     if (halo_ok) {
+        if (d->gn_scale_shift) {  // GroupNorm(+SiLU) of the input fused into the patch staging
+            EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
+            p.gn_ss = d->gn_scale_shift;
+            p.gn_silu = d->gn_silu;
+            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false, 2, true>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true>(p, st);
+        }
         if (halo_big(d, Ho, p.force_cfg) && !d->upsample && !d->stats)  // tuning variant: 16x16 tile, 8 waves, 3-stage weight ring
-            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 4, 2, false, 3>(p, st) : launch_halo<float, 128, 4, 2, false, 3>(p, st);
+            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 4, 2, false, 3, false>(p, st) : launch_halo<float, 128, 4, 2, false, 3, false>(p, st);
         if (d->upsample)
-            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, true, 2>(p, st) : launch_halo<float, 128, 2, 2, true, 2>(p, st);
-        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false, 2>(p, st) : launch_halo<float, 128, 2, 2, false, 2>(p, st);
+            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, true, 2, false>(p, st) : launch_halo<float, 128, 2, 2, true, 2, false>(p, st);
+        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false, 2, false>(p, st) : launch_halo<float, 128, 2, 2, false, 2, false>(p, st);
     }
+    EOD_REQUIRE(!d->gn_scale_shift, "conv: fused input GroupNorm needs the halo-patch kernel (ask eod_conv_gn_fusable first)");
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }
 

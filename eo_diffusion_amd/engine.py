@@ -121,7 +121,18 @@ class Program:
         self.bindings.setdefault(name, []).append((op_index, setter))
 
     def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
-             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False):
+             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None):
+        """gn = (scale_shift tensor from gn_stats(), silu): GroupNorm(+SiLU) of the conv INPUT.  Fused into the conv's
+        patch staging when the library can (eod_conv_gn_fusable), otherwise applied by a separate pass first."""
+        if gn is not None:
+            probe = ConvDesc()
+            probe.dtype, probe.N, probe.H, probe.W = self.dt, x.N, x.H, x.W
+            probe.C0, probe.C1, probe.Cout = x.C, (x2.C if x2 is not None else 0), cout
+            probe.ksize, probe.stride, probe.pad, probe.upsample, probe.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
+            probe.out_nchw_f32 = int(out_nchw_f32)
+            if not self.L.eod_conv_gn_fusable(C.byref(probe)):
+                x = self.gn_apply([x] + ([x2] if x2 is not None else []), gn[0], silu=gn[1])
+                x2, gn = None, None
         ups = 2 if upsample else 1
         heff, weff = x.H * ups + int(pad_tl), x.W * ups + int(pad_tl)
         ho = (heff + 2 * pad - ksize) // stride + 1
@@ -135,6 +146,8 @@ class Program:
         d.C0, d.C1, d.Cout = x.C, (x2.C if x2 is not None else 0), cout
         d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
         d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
+        if gn is not None:
+            d.gn_scale_shift, d.gn_silu = ptr(gn[0]), int(gn[1])
         if out_nchw_f32:
             y = None  # bound by the caller (external NCHW fp32 tensor)
         else:
@@ -182,9 +195,9 @@ class Program:
             s.f[k] = v
         return idx
 
-    def group_norm(self, srcs, gamma, beta, *, silu, eps=1e-5, groups=32, film=None, film_stride=0):
-        """GroupNorm32 [+FiLM] [+SiLU] over the virtual channel-concat of `srcs` (1 or 2 Acts).
-        Returns one Act with sum(C) channels (this materialises the concat, already normalised)."""
+    def gn_stats(self, srcs, gamma, beta, *, eps=1e-5, groups=32, film=None, film_stride=0):
+        """GroupNorm32 [+FiLM] statistics over the virtual channel-concat of `srcs` (1 or 2 Acts) folded with the
+        affine parameters: returns the fp32 {scale, shift} table [N][sum(C)][2] (y = x*scale + shift)."""
         x0 = srcs[0]
         N, H, W = x0.N, x0.H, x0.W
         HW = H * W
@@ -207,12 +220,24 @@ class Program:
         self._small(OP_GN_FINALIZE,
                     p=(ptr(parts[0][0]), ptr(gamma), ptr(beta), ptr(film) if film is not None else 0, ptr(ss), ptr(p1[0])),
                     l=(HW, film_stride), i=(N, parts[0][1], parts[0][2], groups, p1[1], p1[2]), f=(eps,))
+        return ss
+
+    def gn_apply(self, srcs, ss, *, silu):
+        """y = act(x*scale + shift) as a separate pass; materialises the (normalised) concat of `srcs`."""
+        x0 = srcs[0]
+        N, H, W = x0.N, x0.H, x0.W
+        ctot = sum(s.C for s in srcs)
         y = self.act(N, H, W, ctot)
         coff = 0
         for s in srcs:
-            self._small(OP_GN_APPLY, p=(ptr(s.t), ptr(ss), ptr(y.t)), i=(self.dt, N, HW, s.C, ctot, coff, int(silu)))
+            self._small(OP_GN_APPLY, p=(ptr(s.t), ptr(ss), ptr(y.t)), i=(self.dt, N, H * W, s.C, ctot, coff, int(silu)))
             coff += s.C
         return y
+
+    def group_norm(self, srcs, gamma, beta, *, silu, eps=1e-5, groups=32, film=None, film_stride=0):
+        """GroupNorm32 [+FiLM] [+SiLU] as stats + separate apply pass (returns the normalised Act)."""
+        ss = self.gn_stats(srcs, gamma, beta, eps=eps, groups=groups, film=film, film_stride=film_stride)
+        return self.gn_apply(srcs, ss, silu=silu)
 
     def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):
         return self._small(OP_SOFTMAX, p=(ptr(s_f32), ptr(p_out)), l=(lds, ldp, rows), i=(self.dt, n))

@@ -68,12 +68,17 @@ typedef struct {
     float* stats;        /* optional OUT: per-channel GroupNorm partial sums of y, [N][stats_slots][Cout][2] (sum, sumsq),
                             produced by the epilogue (saves the statistics read pass of the next GroupNorm); NULL = off */
     int32_t stats_slots; /* must equal eod_conv_stats_slots(d) when stats != NULL */
-    int32_t _pad;
+    int32_t gn_silu;     /* with gn_scale_shift: 1 = SiLU after the affine normalisation */
+    const float* gn_scale_shift; /* optional: fuse GroupNorm32 (+FiLM) (+SiLU) of the conv INPUT (in_layers[0:2] / out_layers[0:2],
+                            unet_openai.py:312-316,336-343): {scale, shift} per (image, input channel of the virtual concat),
+                            [N][C0+C1][2] fp32 as written by eod_gn_finalize.  x / x2 are then the UN-normalised tensors; the
+                            normalised activation is never written to HBM.  Only where eod_conv_gn_fusable(d) == 1. */
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
  * images, NCHW output): the caller sizes `stats` with it. */
 int eod_conv_stats_slots(const eod_conv_desc* d);
+int eod_conv_gn_fusable(const eod_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * k3/k7/k8: batched GEMM on MFMA,  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] (+bias)(+res)

@@ -169,3 +169,33 @@ def test_bad_arguments_fail_loudly():
     prog.conv(a, w, None, 8)
     with pytest.raises(_lib.EodError, match="multiples of 8"):
         prog.run()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("dims", [(2, 64, 32, 16, 16, 128), (1, 128, 0, 32, 16, 256), (2, 96, 0, 8, 16, 192), (2, 32, 0, 8, 8, 32)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_conv_with_fused_input_groupnorm(prec, dims, silu):
+    """GroupNorm(+SiLU) of the conv input applied inside the halo-patch kernel (last shape: not fusable -> the engine
+    falls back to the separate apply pass); concat seam, K tail, zero padding must stay zero AFTER normalisation"""
+    from eo_diffusion_amd.engine import Act
+    N, C0, C1, H, W, Cout = dims
+    x0 = synth_input("nx0", (N, C0, H, W), 37, scale=2.0) + 0.7
+    xs = [x0] + ([synth_input("nx1", (N, C1, H, W), 37) - 0.3] if C1 else [])
+    C = C0 + C1
+    gam = 1.0 + 0.2 * synth_input("ng", (C,), 37)
+    bet = 0.1 * synth_input("nb", (C,), 37)
+    w = synth_input("nw", (Cout, C, 3, 3), 37, scale=0.05)
+    b = synth_input("nbias", (Cout,), 37, scale=0.1)
+
+    def emit(prog, a):
+        srcs = [Act(prog.own(t.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), N, H, W, t.shape[1]) for t in xs]
+        ss = prog.gn_stats(srcs, prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV)))
+        y, _ = prog.conv(srcs[0], prog.pack_conv(w.to(DEV)), prog.f32(b.to(DEV)), Cout, x2=srcs[1] if C1 else None, gn=(ss, silu))
+        return y
+
+    got = run_program(prec, torch.cat(xs, 1), emit)
+    hn = F.group_norm(torch.cat(xs, 1), 32, gam, bet, eps=1e-5)
+    if silu:
+        hn = F.silu(hn)
+    ref = F.conv2d(hn, w, b, padding=1)
+    assert rel_l2(got, ref) < TOL[prec]
