@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeodiff.so")
 
 EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
- OP_POOL) = range(1, 11)
+ OP_POOL, OP_ATTN) = range(1, 12)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -37,12 +37,17 @@ class TembDesc(C.Structure):
                 ("J", i32)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [("qk", vp), ("vT", vp), ("out", vp), ("ld_qk", i64), ("ldt", i64), ("dtype", i32), ("N", i32), ("T", i32),
+                ("C", i32), ("heads", i32), ("d", i32), ("dpad", i32), ("k_off", i32)]
+
+
 class SmallDesc(C.Structure):
     _fields_ = [("p", vp * 6), ("l", i64 * 4), ("i", i32 * 10), ("f", f32 * 2)]
 
 
 class _OpU(C.Union):
-    _fields_ = [("conv", ConvDesc), ("gemm", GemmDesc), ("temb", TembDesc), ("small", SmallDesc)]
+    _fields_ = [("conv", ConvDesc), ("gemm", GemmDesc), ("temb", TembDesc), ("attn", AttnDesc), ("small", SmallDesc)]
 
 
 class Op(C.Structure):
@@ -65,6 +70,7 @@ SYMBOLS = {
     "eod_conv_stats_slots": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_gn_fusable": (i32, [C.POINTER(ConvDesc)]),
     "eod_gn_apply": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
+    "eod_attention_fwd": (i32, [C.POINTER(AttnDesc), vp]),
     "eod_softmax_rows": (i32, [vp, i64, vp, i64, i32, i64, i32, vp]),
     "eod_time_embed": (i32, [C.POINTER(TembDesc), vp]),
     "eod_q_sample": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
@@ -103,7 +109,7 @@ def lib():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
-    for kind, st in ((1, ConvDesc), (2, GemmDesc), (3, TembDesc), (4, SmallDesc), (5, Op)):
+    for kind, st in ((1, ConvDesc), (2, GemmDesc), (3, TembDesc), (4, SmallDesc), (5, Op), (6, AttnDesc)):
         if L.eod_struct_size(kind) != C.sizeof(st):
             raise EodError(f"ABI mismatch: struct kind {kind}: C {L.eod_struct_size(kind)} vs ctypes {C.sizeof(st)}")
     _lib = L

@@ -428,16 +428,22 @@ class AttentionBlock(_Emitter):
         vT = prog.empty((N, Cc, ldt), zero=True)
         prog.gemm(wv, xn.t, vT, Cc, T, Cc, Cc, Cc, ldt, bias=bv, bias_mode=2, nb0=N, sa=(0, 0), sb=(T * Cc, 0),
                   sc=(Cc * ldt, 0))
-        # S = (q*s)(k*s)^T, s = d^-1/4 (unet_openai.py:475-478)  ->  alpha = 1/sqrt(d); fp32 scores [N*nh][T][ldt]
-        S = prog.empty((N * nh, T, ldt), th.float32)
-        prog.gemm(qk, qk, S, T, T, dpad, 2 * Cq, 2 * Cq, ldt, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
-                  sa=(T * 2 * Cq, dpad), sb=(T * 2 * Cq, dpad), sc=(nh * T * ldt, T * ldt), b_off=Cq)
-        P = prog.empty((N * nh, T, ldt))
-        prog.softmax_rows(S, ldt, P, ldt, N * nh * T, T)
-        # a[n][t][h*d + j] = sum_s P[n,h][t][s] * vT[n][h*d + j][s]
         a = prog.empty((N * T, Cc))
-        prog.gemm(P, vT, a, T, d, ldt, ldt, ldt, Cc, nb0=N, nb1=nh, sa=(nh * T * ldt, T * ldt),
-                  sb=(Cc * ldt, d * ldt), sc=(T * Cc, d))
+        fused = prog.precision == "fp16" and dpad <= 64 and d % 4 == 0 and os.environ.get("EOD_ATTN", "flash") != "gemm"
+        if fused:
+            # flash-style fused kernel: online softmax, the T x T matrix never exists
+            prog.attention(qk, vT, a, N, T, Cc, nh, d, dpad, 2 * Cq, ldt, Cq)
+        else:
+            # materialised path (fp32 parity mode, head dims > 64): S = (q*s)(k*s)^T with s = d^-1/4 (unet_openai.py:475-478)
+            # -> alpha = 1/sqrt(d); fp32 scores [N*nh][T][ldt], row softmax, then a = P.V
+            S = prog.empty((N * nh, T, ldt), th.float32)
+            prog.gemm(qk, qk, S, T, T, dpad, 2 * Cq, 2 * Cq, ldt, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
+                      sa=(T * 2 * Cq, dpad), sb=(T * 2 * Cq, dpad), sc=(nh * T * ldt, T * ldt), b_off=Cq)
+            P = prog.empty((N * nh, T, ldt))
+            prog.softmax_rows(S, ldt, P, ldt, N * nh * T, T)
+            # a[n][t][h*d + j] = sum_s P[n,h][t][s] * vT[n][h*d + j][s]
+            prog.gemm(P, vT, a, T, d, ldt, ldt, ldt, Cc, nb0=N, nb1=nh, sa=(nh * T * ldt, T * ldt),
+                      sb=(Cc * ldt, d * ldt), sc=(T * Cc, d))
         out = prog.act(N, x.H, x.W, Cc)
         prog.gemm(a, wproj, out.t, N * T, Cc, Cc, Cc, Cc, Cc, bias=bproj, bias_mode=1, res=x.t)
         return out

@@ -37,6 +37,7 @@ extern "C" int eod_struct_size(int kind) {
         case 3: return (int)sizeof(eod_temb_desc);
         case 4: return (int)sizeof(eod_small_desc);
         case 5: return (int)sizeof(eod_op);
+        case 6: return (int)sizeof(eod_attn_desc);
         default: return -1;
     }
 }
@@ -118,6 +119,7 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
             case EOD_OP_CONV: rc = eod_conv2d_igemm(&o.u.conv, stream); break;
             case EOD_OP_GEMM: rc = eod_gemm_nt(&o.u.gemm, stream); break;
             case EOD_OP_TEMB: rc = eod_time_embed(&o.u.temb, stream); break;
+            case EOD_OP_ATTN: rc = eod_attention_fwd(&o.u.attn, stream); break;
             case EOD_OP_GN_PARTIAL:
                 rc = eod_gn_partial(s.p[0], s.i[0], s.i[1], s.i[2], s.i[3], (float*)s.p[1], s.i[4], s.i[5], s.i[6], stream);
                 break;

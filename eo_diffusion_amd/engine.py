@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (OP_CONV, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
+from ._lib import (OP_ATTN, OP_CONV, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
                    OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
 
 PRECISIONS = {"fp32": torch.float32, "fp16": torch.float16}
@@ -239,6 +239,15 @@ class Program:
         ss = self.gn_stats(srcs, gamma, beta, eps=eps, groups=groups, film=film, film_stride=film_stride)
         return self.gn_apply(srcs, ss, silu=silu)
 
+    def attention(self, qk, vT, out, N, T, Cc, heads, d, dpad, ld_qk, ldt, k_off):
+        """fused flash-style attention (fp16, head dim <= 64): eod_attention_fwd"""
+        op, idx = self._push(OP_ATTN)
+        a = op.u.attn
+        a.qk, a.vT, a.out = ptr(qk), ptr(vT), ptr(out)
+        a.ld_qk, a.ldt = ld_qk, ldt
+        a.dtype, a.N, a.T, a.C, a.heads, a.d, a.dpad, a.k_off = self.dt, N, T, Cc, heads, d, dpad, k_off
+        return idx
+
     def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):
         return self._small(OP_SOFTMAX, p=(ptr(s_f32), ptr(p_out)), l=(lds, ldp, rows), i=(self.dt, n))
 
@@ -346,6 +355,10 @@ class Program:
                 by = es * n * hw * c * (1 if k == OP_GN_PARTIAL else 2)
                 out.append(dict(kind="gn_partial" if k == OP_GN_PARTIAL else "gn_apply", flops=0.0, bytes=by,
                                 label=f"gn {hw}px {c}ch"))
+            elif k == OP_ATTN:
+                a = op.u.attn
+                out.append(dict(kind="attention", flops=4.0 * a.N * a.T * a.T * a.C,
+                                bytes=es * a.N * a.T * a.C * 4, label=f"attn T={a.T} h={a.heads} d={a.d}"))
             elif k == OP_SOFTMAX:
                 s = op.u.small
                 out.append(dict(kind="softmax", flops=0.0, bytes=s.l[2] * (4 * s.i[1] + es * s.l[1]), label="softmax"))

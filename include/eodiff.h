@@ -135,6 +135,23 @@ int eod_gn_finalize(const float* part0, int P0, int C0, const float* part1, int 
 int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot,
                  int coff, int silu, void* y, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * k8: fused ("flash"-style) QKVAttention / QKVAttentionLegacy forward (unet_openai.py:465-481, 497-515):
+ *   out[n, t, h*d + j] = sum_s softmax_s((q_t . k_s) / sqrt(d)) v[s, j]     (scale = d^-1/4 on q and on k, :475-478)
+ * online softmax in fp32, the T x T matrix is never materialised.  fp16 storage, head dim <= 64.
+ *   qk  [N*T][ld_qk] : q heads at column h*dpad, k heads at k_off + h*dpad (each head zero-padded to dpad channels)
+ *   vT  [N][C][ldt]  : V transposed (keys contiguous, zero beyond T)
+ *   out [N*T][C]
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* qk;
+    const void* vT;
+    void* out;
+    int64_t ld_qk, ldt;
+    int32_t dtype, N, T, C, heads, d, dpad, k_off;
+} eod_attn_desc;
+int eod_attention_fwd(const eod_attn_desc* d, void* stream);
+
 /* k8 (softmax of QKVAttention, unet_openai.py:479/513): p[r][0..ldp) = softmax(s[r][0..n)), zero pad */
 int eod_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int dtype, int64_t rows, int n,
                      void* stream);
@@ -200,7 +217,7 @@ int eod_randn_philox(float* out, int N, int64_t chw, uint64_t seed, int64_t samp
 enum {
     EOD_OP_CONV = 1, EOD_OP_GEMM = 2, EOD_OP_GN_PARTIAL = 3, EOD_OP_GN_FINALIZE = 4,
     EOD_OP_GN_APPLY = 5, EOD_OP_SOFTMAX = 6, EOD_OP_TEMB = 7, EOD_OP_TO_NHWC = 8, EOD_OP_TO_NCHW = 9,
-    EOD_OP_POOL = 10
+    EOD_OP_POOL = 10, EOD_OP_ATTN = 11
 };
 typedef struct {
     const void* p[6];
@@ -215,6 +232,7 @@ typedef struct {
         eod_conv_desc conv;
         eod_gemm_desc gemm;
         eod_temb_desc temb;
+        eod_attn_desc attn;
         eod_small_desc small;
     } u;
 } eod_op;
