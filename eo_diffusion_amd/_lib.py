@@ -105,6 +105,10 @@ def lib():
         raise EodError(
             f"libeodiff.so not found at {LIB_PATH}. Build it first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C eo_diffusion_amd/csrc). There is no fallback path.")
+    # libeodiff.so must share ONE HIP runtime with PyTorch (device pointers and streams cross the boundary): torch
+    # bundles its own libamdhip64 under the same SONAME, so import torch first and let the loader reuse that copy.
+    # (Loading /opt/rocm's runtime first ends in "no ROCm-capable device is detected" at the first launch.)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
