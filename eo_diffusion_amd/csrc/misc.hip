@@ -155,7 +155,7 @@ __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
 
 extern "C" int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y, void* stream) {
     EOD_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "resample2x: bad args");
-    EOD_REQUIRE(mode == 1 || (H % 2 == 0 && W % 2 == 0), "resample2x: avg-pool needs even dims (%dx%d)", H, W);
+    EOD_REQUIRE(mode == 1 || (H >= 2 && W >= 2), "resample2x: avg-pool needs at least 2x2 (%dx%d)", H, W);  // odd dims: floor, like ATen
     const long long total = (long long)N * (mode ? 2 * H + pad_tl : H / 2) * (mode ? 2 * W + pad_tl : W / 2) * C;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     if (dtype == EOD_F16)

@@ -123,3 +123,32 @@ def test_flash_attention_longer_sequences(C, heads, hw, monkeypatch):
     if hw[0] * hw[1] <= 1024:  # the oracle materialises [heads, T, T] on the CPU
         ref = UR.attention_block({"a." + k: v for k, v in sd.items()}, "a", x, heads, False)
         assert rel_l2(y, ref) < TOL["fp16"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("factory,size", [("UNetSmall", 32), ("UNet", 28)])
+def test_factory_presets_vs_oracle(prec, factory, size):
+    """UNetBig/UNet/UNetSmall presets (unet_openai.py:783-922): FiLM, resblock_updown, new attention order,
+    num_head_channels, class conditioning, 3 attention resolutions; 28x28 exercises ragged maps (14x14, 7x7, T=49)."""
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from oracle import unet_ref as UR
+    from tests.synth import synth_input
+    m = getattr(U, factory)(size, in_channels=3, out_channels=3, num_classes=4)
+    m.dropout = 0.0
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth_state_dict(shapes, 7)
+    m.load_state_dict(sd)
+    m = m.set_precision(prec).to(DEV).eval()
+    mults = {32: (1, 2, 2, 2), 28: (1, 2, 2, 2)}[size]
+    res = "28,14,7" if size == 28 else "32,16,8"
+    cfg = dict(model_channels=m.model_channels, num_res_blocks=m.num_res_blocks, channel_mult=mults,
+               attention_resolutions=tuple(size // int(r) for r in res.split(",")), num_classes=4, num_heads=4,
+               num_head_channels=m.num_head_channels, use_scale_shift_norm=True, resblock_updown=True,
+               use_new_attention_order=True)
+    x = synth_input("fx" + factory, (2, 3, size, size), 2)
+    t = torch.tensor([5, 900])
+    y = torch.tensor([0, 3])
+    with torch.no_grad():
+        out = m(x.to(DEV), t.to(DEV), y=y.to(DEV)).cpu()
+    ref = UR.unet_forward(sd, cfg, x, t, y=y)
+    assert rel_l2(out, ref) < (2e-5 if prec == "fp32" else 1e-2)
