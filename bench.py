@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--arch", default="A0", choices=list(ARCHS))
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--graph", action="store_true", help="replay the UNet program as one hipGraph launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (JSON) here")
@@ -136,6 +137,9 @@ def main():
     torch.cuda.set_device(dev)
 
     m = build_model(args.arch, args.size, args.precision, dev)
+    if args.graph:
+        m.model.enable_graph(True)
+        args.no_op_timing = True  # the event-bracketing executor cannot be captured
     N, S = args.batch, args.size
     shape = (N, 3, S, S)
     seed, sample0 = 3, rank * N

@@ -21,7 +21,7 @@ class ConvDesc(C.Structure):
                 ("cbias_stride", i64), ("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("C0", i32), ("C1", i32),
                 ("Cout", i32), ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32), ("pad_tl", i32),
                 ("Ho", i32), ("Wo", i32), ("out_nchw_f32", i32), ("alpha", f32), ("stats", vp), ("stats_slots", i32),
-                ("gn_silu", i32), ("gn_scale_shift", vp)]
+                ("gn_silu", i32), ("gn_scale_shift", vp), ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class GemmDesc(C.Structure):
@@ -69,6 +69,7 @@ SYMBOLS = {
     "eod_gn_finalize": (i32, [vp, i32, i32, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, i64, vp, vp]),
     "eod_conv_stats_slots": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_gn_fusable": (i32, [C.POINTER(ConvDesc)]),
+    "eod_conv_workspace_size": (i64, [C.POINTER(ConvDesc)]),
     "eod_gn_apply": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
     "eod_attention_fwd": (i32, [C.POINTER(AttnDesc), vp]),
     "eod_softmax_rows": (i32, [vp, i64, vp, i64, i32, i64, i32, vp]),

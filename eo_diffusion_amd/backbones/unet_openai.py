@@ -482,6 +482,7 @@ class UNetModel(_Emitter):
         self.num_head_channels = num_head_channels
         self.num_heads_upsample = num_heads_upsample
         self._precision = "fp16" if use_fp16 else None
+        self._use_graph = None  # None: follow EOD_GRAPH (default off)
 
         ted = model_channels * time_emb_factor
         self.time_embed = nn.Sequential(linear(model_channels, ted), _SiLUMark(), linear(ted, ted))
@@ -548,6 +549,14 @@ class UNetModel(_Emitter):
         st = dict(self.__dict__)
         st.pop("_eod_cache", None)
         return st
+
+    def enable_graph(self, on=True):
+        """Replay the UNet launch program as ONE hipGraph launch (HIP stream capture of eod_program_run).  Inputs are
+        copied into static buffers and the returned tensor is the program's static output buffer: it is overwritten by
+        the next forward (the samplers consume it immediately).  Pays off when the step is launch-bound (small maps)."""
+        self._use_graph = bool(on)
+        self.__dict__.pop("_eod_cache", None)
+        return self
 
     def set_precision(self, precision):
         if precision not in ("fp32", "fp16"):
@@ -646,6 +655,8 @@ class UNetModel(_Emitter):
         if y is not None:
             assert y.shape == (N,), (y.shape, x.shape)
         prog = self.program_for(N, cx, ccond, H, W, x.device, y is not None)
+        if getattr(self, "_use_graph", None) if getattr(self, "_use_graph", None) is not None else os.environ.get("EOD_GRAPH", "0") == "1":
+            return self._forward_graph(prog, x, timesteps, cond, y)
         xin = x if (x.dtype == th.float32 and x.is_contiguous()) else x.float().contiguous()
         t64 = timesteps.to(device=x.device, dtype=th.int64).contiguous()
         assert t64.shape == (N,)
@@ -663,6 +674,49 @@ class UNetModel(_Emitter):
         # xin/t64/cin/y64 may be temporaries: the caching allocator is stream-ordered on this stream,
         # so reuse after this frame is ordered behind the kernels that read them.
         return out.type(x.dtype) if x.dtype != th.float32 else out
+
+
+def _forward_graph(self, prog, x, timesteps, cond, y):
+    """hipGraph replay path of UNetModel.forward (see enable_graph)."""
+    st = getattr(prog, "_graph_state", None)
+    if st is None:
+        dev = x.device
+        st = {"x": th.empty(tuple(x.shape), dtype=th.float32, device=dev),
+              "t": th.zeros((x.shape[0],), dtype=th.int64, device=dev),
+              "out": th.empty(prog.out_shape, dtype=th.float32, device=dev)}
+        prog.set_binding("x", st["x"].data_ptr())
+        prog.set_binding("t", st["t"].data_ptr())
+        prog.set_binding("out", st["out"].data_ptr())
+        if cond is not None:
+            st["cond"] = th.empty(tuple(cond.shape), dtype=th.float32, device=dev)
+            prog.set_binding("cond", st["cond"].data_ptr())
+        if y is not None:
+            st["y"] = th.zeros((x.shape[0],), dtype=th.int64, device=dev)
+            prog.set_binding("y", st["y"].data_ptr())
+        st["x"].copy_(x)
+        st["t"].copy_(timesteps)
+        if cond is not None:
+            st["cond"].copy_(cond)
+        if y is not None:
+            st["y"].copy_(y)
+        prog.run()                      # warm-up outside capture (one-off kernel attribute calls)
+        th.cuda.current_stream(dev).synchronize()
+        g = th.cuda.CUDAGraph()
+        with th.cuda.graph(g):
+            prog.run()                  # eod_program_run enqueues on the capture stream; nothing in it syncs or allocates
+        st["graph"] = g
+        prog._graph_state = st
+    st["x"].copy_(x)
+    st["t"].copy_(timesteps)
+    if cond is not None:
+        st["cond"].copy_(cond)
+    if y is not None:
+        st["y"].copy_(y)
+    st["graph"].replay()
+    return st["out"]
+
+
+UNetModel._forward_graph = _forward_graph
 
 
 def unet_param_shapes(**cfg):

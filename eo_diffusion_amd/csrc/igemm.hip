@@ -64,6 +64,7 @@ struct IgemmP {
     int gn_silu;
     float* stats;  // optional GroupNorm partial sums of the output: [N][stats_P][Cout][2]
     int stats_P, tiles_per_image;
+    int splitk;    // conv: K-steps are split over gridDim.y workgroups; raw fp32 partial tiles go to `y` (= workspace)
     int force_cfg; // 0 auto, 1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage (EOD_IGEMM_CFG, tuning only)
     float alpha;
 };
@@ -398,6 +399,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     const int n0 = tile_n * BN;
     const TileGeom g = make_geom<CONV, BM>(p, tile_m);
     const int n_first = g.n_first;
+    IgemmP pe = p;  // epilogue view of the parameters
+    if constexpr (CONV) {
+        if (p.splitk > 1) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;
+    }
     const long long offA = g.offA, offB = g.offB;
 
     // ---- per-thread staging slots: group g = wave + NW*i, row = g*8 + (lane>>3), slot = lane&7 ----
@@ -464,6 +469,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 
     // ---- scalar K-step state: (src, cc, tap) counters, no division in the loop ----
     int st_tap = 0, st_cc = 0, st_src = 0;
+    // split-K (conv, small M): this workgroup handles K-steps [kt_begin, kt_end) and writes a raw fp32 partial tile
+    int kt_begin = 0, kt_end = p.KT;
+    if constexpr (CONV) {
+        if (p.splitk > 1) {
+            const int per = (p.KT + p.splitk - 1) / p.splitk;
+            kt_begin = (int)blockIdx.y * per;
+            kt_end = min(p.KT, kt_begin + per);
+            const int cl = kt_begin / p.taps;  // linear channel chunk
+            st_tap = kt_begin - cl * p.taps;
+            st_src = cl >= p.kc0 ? 1 : 0;
+            st_cc = st_src ? cl - p.kc0 : cl;
+        }
+    }
     const int tapstride = p.Cout * p.Cin * ES;  // bytes between two taps of the packed weights
 
     // K-step DMA = LA + LB instructions per wave.  They are issued one or two at a time BETWEEN the MFMA sub-steps
@@ -563,7 +581,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     //                 wave finished reading step t-1)  ->  issue the DMA of step t+STAGES-1 into the stage that
     //                 step t-1 just vacated  ->  ds_read + MFMA on stage t.
     // __syncthreads() is avoided on purpose: with LDS-DMA in flight it would drain vmcnt to 0 (guide 5.4).
-    const int KT = p.KT;
+    const int KT = kt_end - kt_begin;  // (may be <= 0 for a trailing split: the tile then stays zero)
 #pragma unroll
     for (int ps = 0; ps < STAGES - 1; ++ps)
         if (ps < KT) issue_loads(ps);
@@ -607,12 +625,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     __builtin_amdgcn_s_barrier();        // ... and so are everybody else's: the ring can be reused by the epilogue
 
     if constexpr (sizeof(T) == 4) {
-        igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(p, g, acc, smem, wave, lane, n0);
+        igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(pe, g, acc, smem, wave, lane, n0);
     } else {
-        if (!CONV && p.c_f32)
-            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(p, g, acc, smem, wave, lane, n0);
+        if (CONV ? p.splitk > 1 : p.c_f32 != 0)
+            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(pe, g, acc, smem, wave, lane, n0);
         else
-            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, false>(p, g, acc, smem, wave, lane, n0);
+            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, false>(pe, g, acc, smem, wave, lane, n0);
     }
 }
 
@@ -924,6 +942,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4>(p, g, acc, smem, wave, lane, n0);
 }
 
+// split-K second pass: y[m][c] = alpha * sum_z ws[z][m][c] + bias[c] + cbias[n(m)][c] + res[m][c]   (fixed z order)
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long M, int Cout, int HoWo, float alpha,
+                                     const float* __restrict__ bias, const float* __restrict__ cbias, long long cbias_stride,
+                                     const T* __restrict__ res, T* __restrict__ y) {
+    const long long total4 = M * Cout / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i * 4, m = e / Cout;
+        const int c = (int)(e - m * Cout);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < S; ++z) a += *reinterpret_cast<const f32x4*>(ws + (long long)z * M * Cout + e);
+        const long long n = m / HoWo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = a[k] * alpha;
+            if (bias) v += bias[c + k];
+            if (cbias) v += cbias[n * cbias_stride + c + k];
+            if (res) v += (float)res[e + k];
+            y[e + k] = (T)v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 #include <stdlib.h>
 static int igemm_forced_cfg() {
@@ -1057,6 +1098,34 @@ extern "C" int eod_conv_gn_fusable(const eod_conv_desc* d) {
     return conv_uses_halo(d, Ho, Wo, igemm_forced_cfg()) ? 1 : 0;
 }
 
+// split-K factor of a conv that the generic kernel would run with too few workgroups to fill the chip (small maps)
+static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo, int force) {
+    if (halo || d->out_nchw_f32 || d->Cout % 4 || force == 6) return 1;
+    // the factor must NOT depend on the batch size: the K summation order of a sample has to be the same whether it is
+    // computed alone or inside a larger batch (bit-exact batch-sharding invariance), so a nominal batch of 16 is used
+    const long long M = 16LL * Ho * Wo;
+    const int bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
+    const long long tiles = ((M + 127) / 128) * ((d->Cout + bn - 1) / bn);
+    const int bk = 128 / eod_esize(d->dtype);
+    const int kt = ((d->C0 + bk - 1) / bk + (d->C1 + bk - 1) / bk) * d->ksize * d->ksize;
+    if (tiles >= 128 || kt < 8) return 1;
+    int s = (int)(256 / tiles);
+    if (s > kt / 4) s = kt / 4;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
+// bytes of caller-provided fp32 workspace eod_conv2d_igemm needs for this descriptor (0 = none)
+extern "C" int64_t eod_conv_workspace_size(const eod_conv_desc* d) {
+    if (!d) return 0;
+    const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
+    const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    const int force = igemm_forced_cfg();
+    const int s = conv_splitk(d, Ho, Wo, conv_uses_halo(d, Ho, Wo, force), force);
+    return s > 1 ? (int64_t)s * d->N * Ho * Wo * d->Cout * 4 : 0;
+}
+
 extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     if (!d || d->out_nchw_f32) return 0;
     if (d->Cout % (16 / eod_esize(d->dtype))) return 0;  // statistics are accumulated on full 16-byte output chunks only
@@ -1065,6 +1134,7 @@ extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int force = igemm_forced_cfg();
     const bool halo = conv_uses_halo(d, Ho, Wo, force);
+    if (conv_splitk(d, Ho, Wo, halo, force) > 1) return 0;  // split-K tiles are reduced by a second pass
     const int bm = conv_bm(d, halo, force);
     if ((Ho * Wo) % bm != 0) return 0;  // tiles must not straddle images
     return (Ho * Wo / bm) * conv_waves_m(d, halo, force);
@@ -1140,6 +1210,27 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false, 2, false>(p, st) : launch_halo<float, 128, 2, 2, false, 2, false>(p, st);
     }
     EOD_REQUIRE(!d->gn_scale_shift, "conv: fused input GroupNorm needs the halo-patch kernel (ask eod_conv_gn_fusable first)");
+    const int splitk = conv_splitk(d, Ho, Wo, false, p.force_cfg);
+    if (splitk > 1) {
+        // small maps: too few output tiles to fill 256 CUs -> split the K loop over gridDim.y workgroups (fp32 partial
+        // tiles in the caller's workspace), then one deterministic reduce + bias/residual pass
+        EOD_REQUIRE(d->workspace && d->workspace_bytes >= eod_conv_workspace_size(d), "conv: workspace of %lld bytes required (eod_conv_workspace_size)", (long long)eod_conv_workspace_size(d));
+        EOD_REQUIRE(!d->stats, "conv: epilogue statistics are not available for split-K shapes");
+        IgemmP q = p;
+        q.splitk = splitk;
+        q.y = (char*)d->workspace;
+        q.bias = nullptr; q.bias_mode = 0; q.cbias = nullptr; q.res = nullptr; q.alpha = 1.0f;
+        const int rc = d->dtype == EOD_F16 ? launch_T<half_t, true>(q, splitk, st) : launch_T<float, true>(q, splitk, st);
+        if (rc != EOD_OK) return rc;
+        const long long total4 = p.M * p.Cout / 4;
+        const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+        if (d->dtype == EOD_F16)
+            hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y);
+        EOD_CHECK_LAUNCH("splitk_reduce");
+        return EOD_OK;
+    }
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }
 

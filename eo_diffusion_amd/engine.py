@@ -148,6 +148,10 @@ class Program:
         d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
         if gn is not None:
             d.gn_scale_shift, d.gn_silu = ptr(gn[0]), int(gn[1])
+        wsz = self.L.eod_conv_workspace_size(C.byref(d))
+        if wsz > 0:  # split-K partial tiles (small maps)
+            ws = self.empty((wsz // 4,), torch.float32)
+            d.workspace, d.workspace_bytes = ptr(ws), wsz
         if out_nchw_f32:
             y = None  # bound by the caller (external NCHW fp32 tensor)
         else:

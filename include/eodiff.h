@@ -73,12 +73,15 @@ typedef struct {
                             unet_openai.py:312-316,336-343): {scale, shift} per (image, input channel of the virtual concat),
                             [N][C0+C1][2] fp32 as written by eod_gn_finalize.  x / x2 are then the UN-normalised tensors; the
                             normalised activation is never written to HBM.  Only where eod_conv_gn_fusable(d) == 1. */
+    void* workspace;     /* caller-owned scratch of eod_conv_workspace_size(d) bytes (split-K partial tiles of small maps) */
+    int64_t workspace_bytes;
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
  * images, NCHW output): the caller sizes `stats` with it. */
 int eod_conv_stats_slots(const eod_conv_desc* d);
 int eod_conv_gn_fusable(const eod_conv_desc* d);
+int64_t eod_conv_workspace_size(const eod_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * k3/k7/k8: batched GEMM on MFMA,  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] (+bias)(+res)
