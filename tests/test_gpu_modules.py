@@ -152,3 +152,21 @@ def test_factory_presets_vs_oracle(prec, factory, size):
         out = m(x.to(DEV), t.to(DEV), y=y.to(DEV)).cpu()
     ref = UR.unet_forward(sd, cfg, x, t, y=y)
     assert rel_l2(out, ref) < (2e-5 if prec == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("shape", [(1, 3, 16, 48), (3, 3, 40, 24)])
+def test_unet_non_square_and_odd_batch(prec, shape):
+    """the UNet itself is shape-agnostic (only EODiffusion assumes square images): non-square maps, batch 1 / 3"""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from oracle import unet_ref as UR
+    from tests.synth import synth_input
+    cfg = unet_cfgs()["u_a1_tiny"]
+    sd = synth_state_dict(unet_param_shapes(**cfg), 7)
+    u = UNetModel(**cfg).set_precision(prec)
+    load_into(u, sd)
+    x = synth_input(f"ns{shape}", shape, 2)
+    t = torch.arange(shape[0]) * 7 + 1
+    with torch.no_grad():
+        out = u(x.to(DEV), t.to(DEV)).cpu()
+    assert rel_l2(out, UR.unet_forward(sd, cfg, x, t)) < TOL[prec]

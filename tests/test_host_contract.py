@@ -121,3 +121,29 @@ def test_dropin_module_paths():
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "eo_diffusion_amd", "dropin") + os.pathsep + ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    """train.py:137-138,155 / inference.py:81-86: torch.save({"model": sd, "model_ema": ema_sd}) and back."""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    mk = lambda: EODiffusion(UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
+                                       attention_resolutions=[2], channel_mult=[1, 2], num_heads=2),
+                             timesteps=50, image_size=16, in_channels=3)
+    m = mk()
+    ema = torch.optim.swa_utils.AveragedModel(m, use_buffers=True)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01)
+    ema.update_parameters(m)
+    path = tmp_path / "ckpt.pt"
+    torch.save({"model": m.state_dict(), "model_ema": ema.state_dict()}, path)
+    ck = torch.load(path)
+    assert set(ck) == {"model", "model_ema"} and "n_averaged" in ck["model_ema"]
+    assert any(k.startswith("module.model.input_blocks.") for k in ck["model_ema"])
+    m2 = mk()
+    ema2 = torch.optim.swa_utils.AveragedModel(m2, use_buffers=True)
+    m2.load_state_dict(ck["model"])
+    ema2.load_state_dict(ck["model_ema"])
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
