@@ -59,28 +59,52 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const AttnP p) {
         }
     }
 
-    // ---- staging assignment: K tile = 64 rows x (DS*2) 16-byte chunks, V^T tile = (DT*32) rows x 8 chunks ----
+    // ---- staging: K tile = 64 rows x (DS*2) 16-byte chunks, V^T tile = (DT*32) rows x 8 chunks.  Split into
+    // stage_load (global -> registers, issued BEFORE the MFMAs of the current tile) and stage_store (registers -> LDS,
+    // AFTER them): the global-load latency hides under the tile's compute (guide T14) ----
     constexpr int KCH = DS * 2;
-    auto stage = [&](int kt, int buf) {
-        char* sK = smem + buf * STAGE;
-        char* sV = sK + AT_KT * AT_KROW;
+    constexpr int NKC = (AT_KT * KCH + 255) / 256, NVC = (DT * 32 * 8 + 255) / 256;
+    i32x4 rk[NKC], rv[NVC];
+    auto stage_load = [&](int kt) {
         const int key0 = kt * AT_KT;
-        for (int c = tid; c < AT_KT * KCH; c += 256) {
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = tid + i * 256;
             const int row = c / KCH, ch = c - row * KCH;
             const int key = key0 + row;
-            i32x4 v = {0, 0, 0, 0};
-            if (key < p.T && ch * 8 < p.dpad) v = *reinterpret_cast<const i32x4*>(kbase + (long long)key * p.ld_qk + ch * 8);
-            *reinterpret_cast<i32x4*>(sK + row * AT_KROW + ((ch ^ ((row >> 1) & 7)) << 4)) = v;
+            const bool ok = c < AT_KT * KCH && key < p.T && ch * 8 < p.dpad;
+            const i32x4 v = *reinterpret_cast<const i32x4*>(ok ? kbase + (long long)key * p.ld_qk + ch * 8 : kbase);
+            rk[i] = ok ? v : i32x4{0, 0, 0, 0};
         }
-        for (int c = tid; c < DT * 32 * 8; c += 256) {
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = tid + i * 256;
             const int row = c >> 3, ch = c & 7;  // row = output channel j of this head, ch = 8-key chunk
-            i32x4 v = {0, 0, 0, 0};
-            // vT rows are zero-padded beyond T (torch.zeros at plan build), chunks beyond ldt are skipped
-            if (row < p.d && key0 + ch * 8 < p.ldt) v = *reinterpret_cast<const i32x4*>(vbase + (long long)row * p.ldt + key0 + ch * 8);
-            long long* dst = reinterpret_cast<long long*>(sV + row * AT_VROW + ch * 16);
-            const long long* sv = reinterpret_cast<const long long*>(&v);
-            dst[0] = sv[0];
-            dst[1] = sv[1];
+            // vT rows are zero beyond T (torch.zeros at plan build); chunks beyond ldt are skipped
+            const bool ok = c < DT * 32 * 8 && row < p.d && key0 + ch * 8 < p.ldt;
+            const i32x4 v = *reinterpret_cast<const i32x4*>(ok ? vbase + (long long)row * p.ldt + key0 + ch * 8 : vbase);
+            rv[i] = ok ? v : i32x4{0, 0, 0, 0};
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* sK = smem + buf * STAGE;
+        char* sV = sK + AT_KT * AT_KROW;
+#pragma unroll
+        for (int i = 0; i < NKC; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / KCH, ch = c - row * KCH;
+            if (c < AT_KT * KCH) *reinterpret_cast<i32x4*>(sK + row * AT_KROW + ((ch ^ ((row >> 1) & 7)) << 4)) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVC; ++i) {
+            const int c = tid + i * 256;
+            const int row = c >> 3, ch = c & 7;
+            if (c < DT * 32 * 8) {
+                long long* dst = reinterpret_cast<long long*>(sV + row * AT_VROW + ch * 16);
+                const long long* sv = reinterpret_cast<const long long*>(&rv[i]);
+                dst[0] = sv[0];
+                dst[1] = sv[1];
+            }
         }
     };
 
@@ -92,11 +116,12 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const AttnP p) {
     float m_run = -INFINITY, l_run = 0.0f;  // running max (log2 domain) / this lane's share of the running sum
 
     const int nkt = (p.T + AT_KT - 1) / AT_KT;
-    stage(0, 0);
+    stage_load(0);
+    stage_store(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+        if (kt + 1 < nkt) stage_load(kt + 1);
         const char* sK = smem + buf * STAGE;
         const char* sV = sK + AT_KT * AT_KROW;
 
@@ -167,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const AttnP p) {
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
             }
         }
+        if (kt + 1 < nkt) stage_store(buf ^ 1);  // the other buffer was last read in iteration kt-1 (barrier below)
         __syncthreads();  // next stage written / this stage free
     }
     // ---- normalise and store: O^T[j][q] -> out[n, q, h*d + j] ----
