@@ -239,7 +239,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
         const int rw = it * (64 / CPR) + lane / CPR;
         ok[it] = c_ok;
         if constexpr (CONV) {
-            int nrel, ho, wo;
+            int nrel = 0, ho = 0, wo = 0;
             ok[it] = ok[it] && decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo);
             off[it] = ((((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo)) * p.Cout + c;
         } else {
