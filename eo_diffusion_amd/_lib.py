@@ -21,7 +21,8 @@ class ConvDesc(C.Structure):
                 ("cbias_stride", i64), ("dtype", i32), ("N", i32), ("H", i32), ("W", i32), ("C0", i32), ("C1", i32),
                 ("Cout", i32), ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32), ("pad_tl", i32),
                 ("Ho", i32), ("Wo", i32), ("out_nchw_f32", i32), ("alpha", f32), ("stats", vp), ("stats_slots", i32),
-                ("gn_silu", i32), ("gn_scale_shift", vp), ("workspace", vp), ("workspace_bytes", i64)]
+                ("gn_silu", i32), ("gn_scale_shift", vp), ("workspace", vp), ("workspace_bytes", i64),
+                ("w_tapmajor", i32), ("reserved0", i32)]
 
 
 class GemmDesc(C.Structure):
@@ -62,6 +63,8 @@ SYMBOLS = {
     "eod_conv2d_igemm": (i32, [C.POINTER(ConvDesc), vp]),
     "eod_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
     "eod_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "eod_pack_conv_weight_tapmajor": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "eod_conv_tapmajor_ldk": (i32, [i32, i32]),
     "eod_pack_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "eod_nchw_to_nhwc": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "eod_nhwc_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -609,8 +609,14 @@ class UNetModel(_Emitter):
         # ---- encoder ----
         hs = []
         conv0 = self.input_blocks[0][0]
-        h, i0 = prog.conv(a0, prog.pack_conv(conv0.weight, cin_pad=c_pad), prog.f32(conv0.bias), conv0.out_channels,
-                          stats=True)
+        epc = 16 // prog.tdtype.itemsize
+        if c_pad // epc in (1, 2, 4) and c_pad % epc == 0:
+            # thin input: K runs over the flattened [tap][channel] axis (2-5 K-steps instead of 9 mostly-zero ones)
+            h, i0 = prog.conv(a0, prog.pack_conv_tapmajor(conv0.weight, c_pad), prog.f32(conv0.bias), conv0.out_channels,
+                              stats=True, w_tapmajor=True)
+        else:
+            h, i0 = prog.conv(a0, prog.pack_conv(conv0.weight, cin_pad=c_pad), prog.f32(conv0.bias), conv0.out_channels,
+                              stats=True)
         prog.ops[i0]._cin_alg = cx + ccond  # algorithmic K excludes the zero padding (bench accounting only)
         hs.append(h)
         for blk in list(self.input_blocks)[1:]:
@@ -621,8 +627,9 @@ class UNetModel(_Emitter):
             h = blk._emit(prog, (h, hs.pop()), ctx)
         # ---- head ----
         gn, conv = self.out[0], self.out[2]
-        hn = prog.group_norm([h], prog.f32(gn.weight), prog.f32(gn.bias), silu=True, eps=gn.eps)
-        _, i_out = prog.conv(hn, prog.pack_conv(conv.weight), prog.f32(conv.bias), self.out_channels, out_nchw_f32=True)
+        ss = prog.gn_stats([h], prog.f32(gn.weight), prog.f32(gn.bias), eps=gn.eps)
+        _, i_out = prog.conv(h, prog.pack_conv(conv.weight), prog.f32(conv.bias), self.out_channels, out_nchw_f32=True,
+                             gn=(ss, True))
         prog.bind("out", i_out, lambda op, v: setattr(op.u.conv, "y", v))
         prog.finalize()
         prog.out_shape = (N, self.out_channels, H, W)

@@ -60,6 +60,8 @@ struct IgemmP {
     long long M;
     int Ncols, K, taps, KT, tiles_m, tiles_n, out_nchw;
     int kc0, kc1;  // conv: channel chunks of source 0 / source 1 (K-steps = taps * (kc0 + kc1))
+    int tapmajor_log2;  // >= 0: thin-input mode, K index = tap * C0 + c (C0 = EPC << tapmajor_log2), weights [Cout][ldk]
+    int ldk;
     const float* gn_ss;  // halo kernel: fused GroupNorm of the INPUT: {scale, shift} per (image, input channel), or NULL
     int gn_silu;
     float* stats;  // optional GroupNorm partial sums of the output: [N][stats_P][Cout][2]
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             }
             a_mask[i] = mask;
             const unsigned pix = (unsigned)((nrel * p.H + bh) * p.W + bw);  // wraps for border rows (see above)
-            a_v0[i] = pix * (unsigned)(p.C0 * ES) + a_chunk[i] * 16;
+            a_v0[i] = pix * (unsigned)(p.C0 * ES) + (p.tapmajor_log2 >= 0 ? 0 : a_chunk[i] * 16);
             a_v1[i] = pix * (unsigned)(p.C1 * ES) + a_chunk[i] * 16;
         } else {
             const long long m = (long long)tile_m * BM + row;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         const int row = (wave + NW * i) * 8 + srow;
         b_chunk[i] = sslot ^ ((row >> 1) & 7);
         const bool ok = n0 + row < p.Ncols;
-        const int ldb = CONV ? p.Cin : (int)p.ldb;
+        const int ldb = CONV ? (p.tapmajor_log2 >= 0 ? p.ldk : p.Cin) : (int)p.ldb;
         b_v[i] = ok ? (unsigned)(row * ldb * ES) + b_chunk[i] * 16 : EOD_OOB;
     }
 
@@ -494,6 +496,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     } ss;
     auto prep_step = [&]() {
         if constexpr (CONV) {
+            if (p.tapmajor_log2 >= 0) {  // K-step = 8 chunks of the [tap][C0] axis; the tap is a per-lane quantity (issue_a)
+                ss.src = 0;
+                ss.cw = p.C0;
+                ss.kin = st_cc * 8;  // first logical chunk of this K-step
+                ss.soffA = 0;
+                ss.soffB = (unsigned)(st_cc * BKB);
+                ss.ktail = false;
+                ss.tapbytes = 0;
+                ss.tapbit = 0;
+                ss.dy = ss.dx = 0;
+                ++st_cc;
+                return;
+            }
             ss.src = st_src;
             ss.cw = st_src ? p.C1 : p.C0;                         // channels of the current source
             ss.kin = st_cc * BK;                                  // first channel of this chunk inside the source
@@ -526,6 +541,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         unsigned v;
         bool ok;
         if constexpr (CONV) {
+            if (p.tapmajor_log2 >= 0) {
+                // logical chunk c of the row = (tap, 16-byte sub-chunk of the tap's C0 channels): one gather per lane
+                const int c = ss.kin + a_chunk[i];
+                const int tap = c >> p.tapmajor_log2, sub = c - (tap << p.tapmajor_log2);
+                const int dy = (tap * 11) >> 5, dx = tap - dy * 3;
+                v = a_v0[i] + (unsigned)((dy * p.W + dx) * p.C0 * ES + sub * 16);
+                ok = tap < 9 && ((a_mask[i] >> tap) & 1u);
+                v = ok ? v : EOD_OOB;
+                blds16(rsA0, v, 0u, sbase + (wave + NW * i) * 1024);
+                return;
+            }
             if (p.ups) {
                 const unsigned pix = (unsigned)((a_nh[i] + ((a_bh[i] + ss.dy) >> 1)) * p.W + ((a_bw[i] + ss.dx) >> 1));
                 v = pix * (unsigned)(ss.cw * ES) + a_chunk[i] * 16;
@@ -993,6 +1019,7 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
         p.kc0 = (p.C0 + BK - 1) / BK;
         p.kc1 = (p.C1 + BK - 1) / BK;
         p.KT = (p.kc0 + p.kc1) * p.taps;
+        if (p.tapmajor_log2 >= 0) p.KT = (9 * p.C0 + BK - 1) / BK;
     } else {
         p.KT = (p.K + BK - 1) / BK;
     }
@@ -1069,10 +1096,18 @@ template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipSt
     return launch_cfg<T, CONV, 128, 128, 2, 2, 2>(p, batch, st);
 }
 
+// row length (elements) of tap-major packed weights: 9*C0 rounded up to whole 128-byte K-steps
+extern "C" int eod_conv_tapmajor_ldk(int C0, int dtype) {
+    const int bk = 128 / (dtype == EOD_F16 ? 2 : 4);
+    return (9 * C0 + bk - 1) / bk * bk;
+}
+
 // which kernel configuration a conv descriptor gets (shared by the launcher and eod_conv_stats_slots)
 static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo, int force) {
+    // wide convs (128-column tiles) and the narrow NCHW-fp32 head conv (32-column tiles, 4x1 waves)
+    const bool shape_ok = (d->Cout > 64 && !d->out_nchw_f32) || (d->Cout <= 32 && d->out_nchw_f32 && !d->upsample && force != 5);
     return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 &&
-           d->Cout > 64 && !d->out_nchw_f32 && force != 3 && force != 2 && force != 1;
+           shape_ok && !d->w_tapmajor && force != 3 && force != 2 && force != 1;
 }
 static bool halo_big(const eod_conv_desc* d, int Ho, int force) { return force == 4 && Ho % 16 == 0; }
 static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
@@ -1100,7 +1135,7 @@ extern "C" int eod_conv_gn_fusable(const eod_conv_desc* d) {
 
 // split-K factor of a conv that the generic kernel would run with too few workgroups to fill the chip (small maps)
 static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo, int force) {
-    if (halo || d->out_nchw_f32 || d->Cout % 4 || force == 6) return 1;
+    if (halo || d->out_nchw_f32 || d->Cout % 4 || d->w_tapmajor || force == 6) return 1;
     // the factor must NOT depend on the batch size: the K summation order of a sample has to be the same whether it is
     // computed alone or inside a larger batch (bit-exact batch-sharding invariance), so a nominal batch of 16 is used
     const long long M = 16LL * Ho * Wo;
@@ -1185,6 +1220,16 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     p.out_nchw = d->out_nchw_f32;
     p.alpha = d->alpha;
     p.nb1 = 1;
+    p.tapmajor_log2 = -1;
+    if (d->w_tapmajor) {
+        // thin-input mode (first conv: 3 / 7 / 13 image channels padded to one or two 16-byte chunks): the K axis is
+        // [tap][C0] flattened, so the conv takes ceil(9*C0/BK) K-steps instead of 9 mostly-zero ones
+        const int cpt = d->C0 / epc;
+        EOD_REQUIRE(d->ksize == 3 && d->C1 == 0 && !d->upsample && !d->pad_tl && !d->gn_scale_shift && (cpt == 1 || cpt == 2 || cpt == 4),
+                    "conv: w_tapmajor needs a 3x3 conv of a single source with C0 in {1,2,4} x %d channels", epc);
+        p.tapmajor_log2 = cpt == 1 ? 0 : cpt == 2 ? 1 : 2;
+        p.ldk = eod_conv_tapmajor_ldk(d->C0, d->dtype);
+    }
     p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
     // 3x3 / stride 1 / pad 1 on maps that tile into 8x16 patches: halo-patch kernel (EOD_IGEMM_CFG=3 disables it)
@@ -1197,6 +1242,14 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
     }
     if (halo_ok) {
+        if (d->Cout <= 32) {  // head conv (out_nchw_f32): HBM-bound, the patch removes the 9x re-gather of the input
+            if (d->gn_scale_shift) {
+                p.gn_ss = d->gn_scale_shift;
+                p.gn_silu = d->gn_silu;
+                return d->dtype == EOD_F16 ? launch_halo<half_t, 32, 4, 1, false, 2, true>(p, st) : launch_halo<float, 32, 4, 1, false, 2, true>(p, st);
+            }
+            return d->dtype == EOD_F16 ? launch_halo<half_t, 32, 4, 1, false, 2, false>(p, st) : launch_halo<float, 32, 4, 1, false, 2, false>(p, st);
+        }
         if (d->gn_scale_shift) {  // GroupNorm(+SiLU) of the input fused into the patch staging
             EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
             p.gn_ss = d->gn_scale_shift;
@@ -1248,6 +1301,7 @@ extern "C" int eod_gemm_nt(const eod_gemm_desc* d, void* stream) {
     EOD_REQUIRE(128 * d->lda * es + (long long)d->K * es < 0x7fffffffLL && 128 * d->ldb * es + (long long)d->K * es < 0x7fffffffLL,
                 "gemm: leading dimension too large for the 2 GiB tile window");
     IgemmP p = {};
+    p.tapmajor_log2 = -1;
     p.a0 = (const char*)d->a;
     p.b = (const char*)d->b;
     p.bias = d->bias;

@@ -34,6 +34,33 @@ extern "C" int eod_pack_conv_weight(const float* w, void* dst, int dtype, int Co
     return EOD_OK;
 }
 
+// OIHW fp32 -> [Cout][ldk], k = tap*cin_pad + c (thin-input first conv, eod_conv_desc.w_tapmajor)
+template <typename T>
+__global__ void pack_conv_w_tapmajor_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int cin_pad, int ldk) {
+    const long long total = (long long)Cout * ldk;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % ldk), co = (int)(i / ldk);
+        const int tap = k / cin_pad, ci = k - tap * cin_pad;
+        const float v = (tap < 9 && ci < Cin) ? w[((long long)co * Cin + ci) * 9 + tap] : 0.0f;
+        dst[i] = cvt<T>(v);
+    }
+}
+
+extern "C" int eod_conv_tapmajor_ldk(int C0, int dtype);
+extern "C" int eod_pack_conv_weight_tapmajor(const float* w, void* dst, int dtype, int Cout, int Cin, int cin_pad, void* stream) {
+    EOD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && cin_pad >= Cin, "pack_conv_weight_tapmajor: bad args");
+    EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "pack_conv_weight_tapmajor: bad dtype %d", dtype);
+    const int ldk = eod_conv_tapmajor_ldk(cin_pad, dtype);
+    const long long total = (long long)Cout * ldk;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(pack_conv_w_tapmajor_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, Cout, Cin, cin_pad, ldk);
+    else
+        hipLaunchKernelGGL(pack_conv_w_tapmajor_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, Cout, Cin, cin_pad, ldk);
+    EOD_CHECK_LAUNCH("pack_conv_weight_tapmajor");
+    return EOD_OK;
+}
+
 template <typename T>
 __global__ void pack_rows_kernel(const float* __restrict__ src, long long ld_src, const int* __restrict__ row_map,
                                  T* __restrict__ dst, long long ld_dst, int rows, int cols) {

@@ -96,6 +96,17 @@ class Program:
                                           current_stream_ptr(self.device)), "pack_conv_weight")
         return dst
 
+    def pack_conv_tapmajor(self, weight, cin_pad):
+        """3x3 Conv2d weight of a thin input (OIHW fp32) -> [Cout][ldk], k = tap*cin_pad + c (conv(..., w_tapmajor=True))."""
+        w = self.f32(weight)
+        cout, cin = w.shape[0], w.shape[1]
+        assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3
+        ldk = self.L.eod_conv_tapmajor_ldk(cin_pad, self.dt)
+        dst = self.empty((cout, ldk))
+        check(self.L.eod_pack_conv_weight_tapmajor(ptr(w), ptr(dst), self.dt, cout, cin, cin_pad,
+                                                   current_stream_ptr(self.device)), "pack_conv_weight_tapmajor")
+        return dst
+
     def pack_rows(self, weight2d, row_index=None):
         """rows of an fp32 [R][K] matrix (optionally gathered by row_index) -> storage dtype [r][K]."""
         w = self.f32(weight2d)
@@ -121,7 +132,7 @@ class Program:
         self.bindings.setdefault(name, []).append((op_index, setter))
 
     def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
-             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None):
+             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None, w_tapmajor=False):
         """gn = (scale_shift tensor from gn_stats(), silu): GroupNorm(+SiLU) of the conv INPUT.  Fused into the conv's
         patch staging when the library can (eod_conv_gn_fusable), otherwise applied by a separate pass first."""
         if gn is not None:
@@ -146,6 +157,7 @@ class Program:
         d.C0, d.C1, d.Cout = x.C, (x2.C if x2 is not None else 0), cout
         d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
         d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
+        d.w_tapmajor = int(w_tapmajor)
         if gn is not None:
             d.gn_scale_shift, d.gn_silu = ptr(gn[0]), int(gn[1])
         wsz = self.L.eod_conv_workspace_size(C.byref(d))
@@ -343,9 +355,11 @@ class Program:
                 fl = 2.0 * m * d.Cout * cin_alg * d.ksize * d.ksize
                 by = es * (d.N * d.H * d.W * cin + d.ksize * d.ksize * d.Cout * cin + (0 if d.out_nchw_f32 else m * d.Cout)) \
                     + (4 * m * d.Cout if d.out_nchw_f32 else 0) + (es * m * d.Cout if d.res else 0)
-                halo = (d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and d.Wo % 16 == 0 and d.Ho % 8 == 0
-                        and d.Cout > 64 and not d.out_nchw_f32)  # mirrors conv_uses_halo() in csrc/igemm.hip
-                out.append(dict(kind="conv", flops=fl, bytes=by, kernel="conv3x3_halo_kernel" if halo else "igemm_kernel",
+                geo = d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and d.Wo % 16 == 0 and d.Ho % 8 == 0
+                halo = geo and d.Cout > 64 and not d.out_nchw_f32 and not d.w_tapmajor  # mirrors conv_uses_halo() in csrc/igemm.hip
+                head = geo and d.Cout <= 32 and d.out_nchw_f32 and not d.upsample  # 32-column instance (HBM-bound head conv)
+                out.append(dict(kind="conv", flops=fl, bytes=by,
+                                kernel="conv3x3_halo_kernel" if halo else "conv3x3_halo_kernel<BN=32>" if head else "igemm_kernel",
                                 label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"))
             elif k == OP_GEMM:
                 d = op.u.gemm

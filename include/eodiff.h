@@ -75,6 +75,11 @@ typedef struct {
                             normalised activation is never written to HBM.  Only where eod_conv_gn_fusable(d) == 1. */
     void* workspace;     /* caller-owned scratch of eod_conv_workspace_size(d) bytes (split-K partial tiles of small maps) */
     int64_t workspace_bytes;
+    int32_t w_tapmajor;  /* 1: thin-input 3x3 conv (the UNet's first conv, unet_openai.py:609: 3 / 7 / 13 image channels):
+                            w is [Cout][ldk] with k = tap*C0 + c (eod_pack_conv_weight_tapmajor, ldk =
+                            eod_conv_tapmajor_ldk) and the K loop runs over the flattened [tap][C0] axis -- ceil(9*C0/BK)
+                            K-steps instead of 9 mostly-zero ones.  Needs C1 == 0, no upsample, C0 in {1,2,4} 16-byte chunks */
+    int32_t reserved0;
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
@@ -109,6 +114,9 @@ int eod_gemm_nt(const eod_gemm_desc* d, void* stream);
 /* weights: OIHW fp32 (Conv2d.weight, unet_openai.py:21-25) -> [tap][Cout][cin_pad] storage dtype */
 int eod_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int ksize,
                          int cin_pad, void* stream);
+/* thin-input variant: OIHW fp32 -> [Cout][ldk], k = tap*cin_pad + c, zero padded (see eod_conv_desc.w_tapmajor) */
+int eod_pack_conv_weight_tapmajor(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int cin_pad, void* stream);
+int eod_conv_tapmajor_ldk(int C0, int dtype);
 /* generic strided 2-D cast-copy: dst[r][c] = (dtype) src[row_map[r]*ld_src + c]; row_map may be NULL
  * (identity); a negative row_map entry yields a zero row (K padding of attention heads) */
 int eod_pack_rows(const float* src, int64_t ld_src, const int32_t* row_map, void* dst, int64_t ld_dst,

@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from eo_diffusion_amd.engine import Program
 from tests.gpu_util import DEV, TOL, run_program
 from tests.helpers import rel_l2
 from tests.synth import synth_input
@@ -199,3 +200,52 @@ def test_conv_with_fused_input_groupnorm(prec, dims, silu):
         hn = F.silu(hn)
     ref = F.conv2d(hn, w, b, padding=1)
     assert rel_l2(got, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("dims", [(2, 3, 16, 16, 128), (1, 7, 32, 16, 128), (2, 13, 8, 24, 64), (1, 4, 7, 9, 32), (1, 3, 64, 64, 128)])
+def test_first_conv_tapmajor(prec, dims):
+    """thin-input 3x3 conv (UNet input conv, unet_openai.py:609): K over the flattened [tap][channel] axis
+    (eod_conv_desc.w_tapmajor); image channels zero-padded to whole 16-byte chunks; borders, ragged maps, N tails"""
+    N, Cin, H, W, Cout = dims
+    x = synth_input(f"tx{dims}", (N, Cin, H, W), 41)
+    w = synth_input(f"tw{dims}", (Cout, Cin, 3, 3), 41, scale=1.0 / math.sqrt(Cin * 9))
+    b = synth_input(f"tb{dims}", (Cout,), 41, scale=0.1)
+
+    def emit(prog, a):
+        if (a.C // prog.epc) not in (1, 2, 4):
+            pytest.skip("channel padding outside the tap-major range for this precision")
+        y, _ = prog.conv(a, prog.pack_conv_tapmajor(w.to(DEV), a.C), prog.f32(b.to(DEV)), Cout, w_tapmajor=True, stats=True)
+        return y
+
+    got = run_program(prec, x, emit)
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_l2(got, ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("dims", [(2, 128, 16, 16, 3), (1, 64, 8, 32, 13), (2, 96, 16, 16, 3)])
+@pytest.mark.parametrize("fused_gn", [True, False])
+def test_head_conv_nchw_f32(prec, dims, fused_gn):
+    """output head (unet_openai.py:739-742): [GroupNorm + SiLU ->] 3x3 conv to a few channels written as NCHW fp32
+    (32-column instance of the halo-patch kernel, GroupNorm fused into the patch staging)"""
+    from eo_diffusion_amd.engine import Act
+    N, C, H, W, Cout = dims
+    x = synth_input(f"hx{dims}", (N, C, H, W), 43, scale=1.5) + 0.2
+    gam = 1.0 + 0.2 * synth_input("hg", (C,), 43)
+    bet = 0.1 * synth_input("hb", (C,), 43)
+    w = synth_input(f"hw{dims}", (Cout, C, 3, 3), 43, scale=0.05)
+    b = synth_input(f"hbias{dims}", (Cout,), 43, scale=0.1)
+    prog = Program(DEV, prec)
+    a = Act(prog.own(x.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), N, H, W, C)
+    out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=DEV)
+    gn = None
+    if fused_gn:
+        gn = (prog.gn_stats([a], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True)
+    _, idx = prog.conv(a, prog.pack_conv(w.to(DEV)), prog.f32(b.to(DEV)), Cout, out_nchw_f32=True, gn=gn)
+    prog.ops[idx].u.conv.y = out.data_ptr()
+    prog.run()
+    torch.cuda.synchronize()
+    hin = F.silu(F.group_norm(x, 32, gam, bet, eps=1e-5)) if fused_gn else x
+    ref = F.conv2d(hin, w, b, padding=1)
+    assert rel_l2(out.cpu(), ref) < TOL[prec]
