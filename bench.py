@@ -212,7 +212,12 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                roof["traffic"] = json.load(open(tf)).get(f"{args.arch}_{args.size}_{args.batch}_{args.precision}")
+                prof = json.load(open(tf))
+                roof["traffic"] = prof.get(f"{args.arch}_{args.size}_{args.batch}_{args.precision}")
+                if args.precision == "fp16" and "_pmc_mfma" in prof:
+                    # PMC evidence from the committed rocprofv3 pass (not measured in this run): the MFMA pipes are busy
+                    # this fraction of the GPU cycles; the clock the chip sustains under this load is far below 2.4 GHz
+                    roof["pmc_mfma"] = prof["_pmc_mfma"]
             except Exception:
                 pass
         if args.dump_ops and rank == 0:
