@@ -245,6 +245,89 @@ __global__ void temb_linear_kernel(const float* __restrict__ in, const long long
     }
 }
 
+// Stage 1 of the embedding MLP with the sinusoid table built ONCE per block in LDS (the generic kernel above would
+// re-evaluate the N x D precise sin/cos for every output column: ~100 us of pure range reduction at E = 512).
+// Block = 4 waves x OPW output columns; summation order per column identical to temb_linear_kernel<0>.
+constexpr int TEMB_NB = 16;   // images per LDS table pass
+constexpr int TEMB_OPW = 4;   // output columns per wave
+constexpr int TEMB_KI = 8;    // K <= 64 * TEMB_KI for the table kernel
+// STAGE 1: table = sinusoid(t), epilogue SiLU (time_embed[0:2]).  STAGE 2: table = h1, epilogue + label_emb[y]
+// (time_embed[2], :597-605).  STAGE 3: table = SiLU(emb), plain epilogue (every ResBlock's emb_layers = SiLU -> Linear,
+// concatenated along J).  Each lane keeps TEMB_NB independent accumulators (one per image), so the loop is not a
+// chain of dependent load -> reduce -> store round trips per image.
+template <int STAGE>
+__global__ __launch_bounds__(256) void temb_table_linear_kernel(const float* __restrict__ in, const long long* __restrict__ t,
+                                                                const float* __restrict__ freqs, const float* __restrict__ w,
+                                                                const float* __restrict__ b, const float* __restrict__ label_emb,
+                                                                const long long* __restrict__ y, float* __restrict__ out, int N,
+                                                                int K, int J) {
+    extern __shared__ float tab[];  // [TEMB_NB][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = K / 2;
+    for (int n0 = 0; n0 < N; n0 += TEMB_NB) {
+        const int nb = min(TEMB_NB, N - n0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < TEMB_NB * K; i += blockDim.x) {
+            const int n = i / K, k = i - n * K;
+            float e = 0.0f;
+            if (n < nb) {
+                if (STAGE == 1) {
+                    const float tf = (float)t[n0 + n];
+                    if (k < half)
+                        e = cosf(tf * freqs[k]);
+                    else if (k < 2 * half)
+                        e = sinf(tf * freqs[k - half]);
+                } else {
+                    e = in[(long long)(n0 + n) * K + k];
+                    if (STAGE == 3) e = silu_f<false>(e);
+                }
+            }
+            tab[i] = e;
+        }
+        __syncthreads();
+        // all weight values this wave needs (TEMB_OPW rows x K/64 per lane) are fetched up front: one memory round trip
+        // instead of one per k iteration
+        float wv[TEMB_OPW][TEMB_KI];
+#pragma unroll
+        for (int o = 0; o < TEMB_OPW; ++o) {
+            const int j = (blockIdx.x * 4 + wave) * TEMB_OPW + o;
+#pragma unroll
+            for (int i = 0; i < TEMB_KI; ++i) {
+                const int k = lane + 64 * i;
+                wv[o][i] = (j < J && k < K) ? w[(long long)j * K + k] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < TEMB_OPW; ++o) {
+            const int j = (blockIdx.x * 4 + wave) * TEMB_OPW + o;
+            if (j >= J) break;  // wave-uniform
+            float acc[TEMB_NB];
+#pragma unroll
+            for (int n = 0; n < TEMB_NB; ++n) acc[n] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < TEMB_KI; ++i) {
+                const int k = lane + 64 * i;
+                if (k < K) {
+#pragma unroll
+                    for (int n = 0; n < TEMB_NB; ++n) acc[n] += tab[n * K + k] * wv[o][i];
+                }
+            }
+            float mine = 0.0f;  // lane n keeps image n's sum
+#pragma unroll
+            for (int n = 0; n < TEMB_NB; ++n) {
+                const float r = wsum(acc[n]);
+                if (lane == n) mine = r;
+            }
+            if (lane < nb) {
+                float v = mine + b[j];
+                if (STAGE == 1) v = silu_f<false>(v);
+                if (STAGE == 2 && label_emb) v += label_emb[y[n0 + lane] * J + j];
+                out[(long long)(n0 + lane) * J + j] = v;
+            }
+        }
+    }
+}
+
 extern "C" int eod_time_embed(const eod_temb_desc* d, void* stream) {
     EOD_REQUIRE(d && d->emb, "time_embed: null pointer");
     EOD_REQUIRE(d->N > 0 && d->E > 0 && d->J >= 0, "time_embed: bad dims");
@@ -253,13 +336,28 @@ extern "C" int eod_time_embed(const eod_temb_desc* d, void* stream) {
         EOD_REQUIRE(d->t && d->freqs && d->b1 && d->w2 && d->b2 && d->h1 && d->D > 0, "time_embed: null pointer");
         EOD_REQUIRE((d->label_emb == nullptr) == (d->y == nullptr), "time_embed: label_emb / y mismatch");
         const unsigned be = (unsigned)((d->E + 3) / 4);
-        hipLaunchKernelGGL(temb_linear_kernel<0>, dim3(be), dim3(256), 0, st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, nullptr, d->N, d->D, d->E);
-        hipLaunchKernelGGL(temb_linear_kernel<1>, dim3(be), dim3(256), 0, st, d->h1, nullptr, nullptr, d->w2, d->b2, d->label_emb, (const long long*)d->y, d->emb, nullptr, d->N, d->E, d->E);
+        if (d->D <= 64 * TEMB_KI) {
+            const unsigned b1 = (unsigned)((d->E + 4 * TEMB_OPW - 1) / (4 * TEMB_OPW));
+            hipLaunchKernelGGL(temb_table_linear_kernel<1>, dim3(b1), dim3(256), (size_t)TEMB_NB * d->D * sizeof(float), st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, d->N, d->D, d->E);
+        } else {
+            hipLaunchKernelGGL(temb_linear_kernel<0>, dim3(be), dim3(256), 0, st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, nullptr, d->N, d->D, d->E);
+        }
+        if (d->E <= 64 * TEMB_KI) {
+            const unsigned b2 = (unsigned)((d->E + 4 * TEMB_OPW - 1) / (4 * TEMB_OPW));
+            hipLaunchKernelGGL(temb_table_linear_kernel<2>, dim3(b2), dim3(256), (size_t)TEMB_NB * d->E * sizeof(float), st, d->h1, nullptr, nullptr, d->w2, d->b2, d->label_emb, (const long long*)d->y, d->emb, d->N, d->E, d->E);
+        } else {
+            hipLaunchKernelGGL(temb_linear_kernel<1>, dim3(be), dim3(256), 0, st, d->h1, nullptr, nullptr, d->w2, d->b2, d->label_emb, (const long long*)d->y, d->emb, nullptr, d->N, d->E, d->E);
+        }
     }
     if (d->J > 0) {
         EOD_REQUIRE(d->wcat && d->bcat && d->out, "time_embed: null wcat/bcat/out");
         const unsigned bj = (unsigned)((d->J + 3) / 4);
-        hipLaunchKernelGGL(temb_linear_kernel<2>, dim3(bj), dim3(256), 0, st, d->emb, nullptr, nullptr, d->wcat, d->bcat, nullptr, nullptr, d->out, nullptr, d->N, d->E, d->J);
+        if (d->E <= 64 * TEMB_KI) {
+            const unsigned b3 = (unsigned)((d->J + 4 * TEMB_OPW - 1) / (4 * TEMB_OPW));
+            hipLaunchKernelGGL(temb_table_linear_kernel<3>, dim3(b3), dim3(256), (size_t)TEMB_NB * d->E * sizeof(float), st, d->emb, nullptr, nullptr, d->wcat, d->bcat, nullptr, nullptr, d->out, d->N, d->E, d->J);
+        } else {
+            hipLaunchKernelGGL(temb_linear_kernel<2>, dim3(bj), dim3(256), 0, st, d->emb, nullptr, nullptr, d->wcat, d->bcat, nullptr, nullptr, d->out, nullptr, d->N, d->E, d->J);
+        }
     }
     EOD_CHECK_LAUNCH("time_embed");
     return EOD_OK;
