@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeodiff.so")
 
 EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
- OP_POOL, OP_ATTN) = range(1, 12)
+ OP_POOL, OP_ATTN, OP_TRANSPOSE) = range(1, 13)
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -65,6 +65,21 @@ SYMBOLS = {
     "eod_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "eod_pack_conv_weight_tapmajor": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "eod_conv_tapmajor_ldk": (i32, [i32, i32]),
+    # training path (csrc/train.hip)
+    "eod_pack_conv_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eod_transpose_gather": (i32, [vp, i32, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eod_rowsum_segments": (i32, [vp, i32, i32, i64, i32, i64, f32, vp, i64, vp]),
+    "eod_colsum": (i32, [vp, i32, i32, vp, vp]),
+    "eod_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
+    "eod_gn_mean_rstd": (i32, [vp, i32, i32, vp, i32, i32, i32, i64, i32, f32, vp, vp]),
+    "eod_gn_bwd_partial": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "eod_gn_bwd_finalize": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp, vp]),
+    "eod_gn_bwd_params": (i32, [vp, i32, i32, f32, vp, vp, vp]),
+    "eod_gn_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "eod_add": (i32, [vp, vp, vp, i32, i64, vp]),
+    "eod_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i32, i64, i32, vp]),
+    "eod_linear_bwd_small": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "eod_temb_pre1": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "eod_pack_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "eod_nchw_to_nhwc": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "eod_nhwc_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -433,7 +433,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             if (ok) {
                 for (int t = 0; t < p.taps; ++t) {
                     const int dy = (p.KS == 3) ? t / 3 : 0, dx = (p.KS == 3) ? t - dy * 3 : 0;
-                    if ((unsigned)(bh + dy) < (unsigned)p.Heff && (unsigned)(bw + dx) < (unsigned)p.Weff) mask |= 1u << t;
+                    bool in = (unsigned)(bh + dy) < (unsigned)p.Heff && (unsigned)(bw + dx) < (unsigned)p.Weff;
+                    if (p.ups == 2) in = in && (((bh + dy) | (bw + dx)) & 1) == 0;  // zero-insertion: only even positions hold data
+                    if (in) mask |= 1u << t;
                 }
             }
             a_mask[i] = mask;
@@ -1105,7 +1107,7 @@ extern "C" int eod_conv_tapmajor_ldk(int C0, int dtype) {
 // which kernel configuration a conv descriptor gets (shared by the launcher and eod_conv_stats_slots)
 static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo, int force) {
     // wide convs (128-column tiles) and the narrow NCHW-fp32 head conv (32-column tiles, 4x1 waves)
-    const bool shape_ok = (d->Cout > 64 && !d->out_nchw_f32) || (d->Cout <= 32 && d->out_nchw_f32 && !d->upsample && force != 5);
+    const bool shape_ok = ((d->Cout > 64 && !d->out_nchw_f32) || (d->Cout <= 32 && d->out_nchw_f32 && !d->upsample && force != 5)) && d->upsample != 2;
     return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 &&
            shape_ok && !d->w_tapmajor && force != 3 && force != 2 && force != 1;
 }
@@ -1181,6 +1183,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     const int es = eod_esize(d->dtype), epc = 16 / es;
     EOD_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize %d", d->ksize);
     EOD_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
+    EOD_REQUIRE(d->upsample >= 0 && d->upsample <= 2, "conv: upsample %d", d->upsample);
     EOD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad dims");
     EOD_REQUIRE(d->C0 % epc == 0 && d->C1 % epc == 0, "conv: C0=%d C1=%d must be multiples of %d", d->C0, d->C1, epc);
     EOD_REQUIRE(d->x && d->w && d->y, "conv: null pointer");

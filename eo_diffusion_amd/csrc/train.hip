@@ -1,0 +1,611 @@
+// Training-path kernels (train.py:109-124 = forward, MSE, backward, AdamW, EMA).
+//
+// Backward of the UNet blocks is built from the SAME MFMA kernels as the forward:
+//   * conv backward-data  = eod_conv2d_igemm on dY with flipped / transposed weights (eod_pack_conv_weight_dgrad);
+//     stride-2 convs use the zero-insertion input mode (eod_conv_desc.upsample = 2), convs on a nearest-2x input are
+//     followed by a 2x2 sum pool (eod_resample2x mode 2);
+//   * conv backward-weights = eod_gemm_nt over the PIXEL axis: dW[tap][co][ci] = sum_p dY[p][co] * X[p + tap][ci].
+//     Both operands are needed K(=pixel)-contiguous, so dY and X are first transposed to [channel][pixel]
+//     (eod_transpose_gather).  For 3x3 / stride-1 convs only three copies of X exist (dx = -1, 0, +1): every image gets
+//     a zero row above and below, so the dy = -1 / +1 taps are the SAME buffer read at a +-W element offset (16-byte
+//     aligned when W % 8 == 0) and the conv's zero padding needs no masks.  The K axis is split over gridDim batches
+//     (fp32 partial tiles), eod_wgrad_reduce sums them in a fixed order into the OIHW fp32 gradient;
+//   * GroupNorm(+SiLU) backward: per-channel partial sums (eod_gn_bwd_partial) -> per-group coefficients
+//     (eod_gn_bwd_finalize, double accumulation) -> dx = k1*dz + k2*x + k3 (eod_gn_bwd_apply), dgamma / dbeta from the
+//     same partial sums.
+// Everything here is HBM-bound elementwise / reduction work: 16-byte accesses, fixed-order sums, no atomics.
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ T cvt_to(float v) { return (T)v; }
+
+// ---------------------------------------------------------------------------------------------
+// weights for backward-data: OIHW fp32 -> [tap'][ci - ci0][cout_pad], tap' = taps-1-tap (180-degree flip), i.e. the
+// packed weights of the conv that maps dY (Cout channels) to dX (the nci input channels starting at ci0)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int taps, int ci0,
+                                         int nci, int cout_pad) {
+    const long long total = (long long)taps * nci * cout_pad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_pad);
+        const long long r = i / cout_pad;
+        const int ci = (int)(r % nci);
+        const int tp = (int)(r / nci);
+        const int tap = taps - 1 - tp;
+        const float v = co < Cout ? w[((long long)co * Cin + ci0 + ci) * taps + tap] : 0.0f;
+        dst[i] = cvt_to<T>(v);
+    }
+}
+
+extern "C" int eod_pack_conv_weight_dgrad(const float* w, void* dst, int dtype, int Cout, int Cin, int ksize, int ci0, int nci,
+                                          int cout_pad, void* stream) {
+    EOD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3) && ci0 >= 0 && nci > 0 && ci0 + nci <= Cin && cout_pad >= Cout,
+                "pack_conv_weight_dgrad: bad args");
+    EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "pack_conv_weight_dgrad: bad dtype %d", dtype);
+    const int taps = ksize * ksize;
+    const long long total = (long long)taps * nci * cout_pad;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(pack_conv_w_dgrad_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, Cout, Cin, taps, ci0, nci, cout_pad);
+    else
+        hipLaunchKernelGGL(pack_conv_w_dgrad_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, Cout, Cin, taps, ci0, nci, cout_pad);
+    EOD_CHECK_LAUNCH("pack_conv_weight_dgrad");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transpose + gather: NHWC [N][H][W][C] -> [C][K],  K = N * (Ho + 2*rp) * Wo (+ nothing else), element
+//   dst[c][(n*(Ho+2rp) + ho + rp)*Wo + wo] = src[n][hi][wi][c],  (hi, wi) = (ho*stride - pad + dy, wo*stride - pad + dx),
+//   with ups: (hi >> 1, wi >> 1) of the stored half-resolution tensor; zero outside the image and in the rp pad rows.
+// 64 x 64 tiles through LDS: 128-byte (fp16) reads along the channels, 128-byte writes along the pixels.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_gather_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W, int C,
+                                                               int Ho, int Wo, int stride, int pad, int dy, int dx, int ups, int rp,
+                                                               long long K, long long ld_dst) {
+    // (columns K .. ld_dst-1 of every row are written as zeros: the K-split GEMM reads whole K-steps)
+    __shared__ T tile[64][66];
+    const long long k0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const int Hp = Ho + 2 * rp;
+    const int Heff = ups ? 2 * H : H, Weff = ups ? 2 * W : W;
+    // load: pixel k0 + r (r = ty, ty+4, ...), channel c0 + tx
+    for (int r = ty; r < 64; r += 4) {
+        const long long k = k0 + r;
+        T v = (T)0.0f;
+        if (k < K && c0 + tx < C) {
+            const int wo = (int)(k % Wo);
+            const long long q = k / Wo;
+            const int hp = (int)(q % Hp), n = (int)(q / Hp);
+            const int ho = hp - rp;
+            int hi = ho * stride - pad + dy, wi = wo * stride - pad + dx;
+            if (ho >= 0 && ho < Ho && (unsigned)hi < (unsigned)Heff && (unsigned)wi < (unsigned)Weff) {
+                if (ups) {
+                    hi >>= 1;
+                    wi >>= 1;
+                }
+                v = src[(((long long)n * H + hi) * W + wi) * C + c0 + tx];
+            }
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    // store: channel c0 + r, pixel k0 + tx
+    for (int r = ty; r < 64; r += 4) {
+        const long long k = k0 + tx;
+        if (c0 + r < C && k < ld_dst) dst[(long long)(c0 + r) * ld_dst + k] = tile[tx][r];
+    }
+}
+
+extern "C" int eod_transpose_gather(const void* src, int dtype, int N, int H, int W, int C, void* dst, int64_t ld_dst, int Ho, int Wo,
+                                    int stride, int pad, int dy, int dx, int ups, int row_pad, void* stream) {
+    EOD_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && (stride == 1 || stride == 2) && row_pad >= 0,
+                "transpose_gather: bad args");
+    EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "transpose_gather: bad dtype %d", dtype);
+    const long long K = (long long)N * (Ho + 2 * row_pad) * Wo;
+    EOD_REQUIRE(ld_dst >= K, "transpose_gather: ld_dst %lld < K %lld", (long long)ld_dst, K);
+    const long long kb = (ld_dst + 63) / 64;
+    EOD_REQUIRE(kb <= 0x7fffffffLL && (C + 63) / 64 <= 65535, "transpose_gather: grid too large");
+    dim3 grid((unsigned)kb, (unsigned)((C + 63) / 64));
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(transpose_gather_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)src, (half_t*)dst, N, H, W, C, Ho, Wo, stride, pad, dy, dx, ups, row_pad, K, (long long)ld_dst);
+    else
+        hipLaunchKernelGGL(transpose_gather_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, N, H, W, C, Ho, Wo, stride, pad, dy, dx, ups, row_pad, K, (long long)ld_dst);
+    EOD_CHECK_LAUNCH("transpose_gather");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segmented row sums of a [C][ld] matrix: seg[s][c] = sum_{k in segment s} x[c][k], segments of seg_len elements
+// (bias gradient: one segment = everything; timestep-embedding gradient: one segment per image).  grid (C, nseg).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ x, long long ld, long long seg_len, float* __restrict__ seg,
+                                                     long long seg_ld, float scale) {
+    __shared__ float red[256];
+    const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const T* row = x + (long long)c * ld + (long long)s * seg_len;
+    float a = 0.0f;
+    for (long long k = tid; k < seg_len; k += 256) a += (float)row[k];
+    red[tid] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) seg[(long long)s * seg_ld + c] = red[0] * scale;
+}
+
+extern "C" int eod_rowsum_segments(const void* x, int dtype, int C, int64_t ld, int nseg, int64_t seg_len, float scale, float* seg,
+                                   int64_t seg_ld, void* stream) {
+    EOD_REQUIRE(x && seg && C > 0 && nseg > 0 && seg_len > 0 && nseg <= 65535 && ld >= (int64_t)nseg * seg_len && seg_ld >= C, "rowsum_segments: bad args");
+    dim3 grid((unsigned)C, (unsigned)nseg);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(rowsum_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (long long)ld, (long long)seg_len, seg, (long long)seg_ld, scale);
+    else
+        hipLaunchKernelGGL(rowsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long long)ld, (long long)seg_len, seg, (long long)seg_ld, scale);
+    EOD_CHECK_LAUNCH("rowsum_segments");
+    return EOD_OK;
+}
+
+// out[c] = sum_s seg[s][c] (fixed order)
+__global__ void colsum_kernel(const float* __restrict__ seg, int S, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.0f;
+    for (int s = 0; s < S; ++s) a += seg[(long long)s * C + c];
+    out[c] = a;
+}
+
+extern "C" int eod_colsum(const float* seg, int S, int C, float* out, void* stream) {
+    EOD_REQUIRE(seg && out && S > 0 && C > 0, "colsum: bad args");
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, seg, S, C, out);
+    EOD_CHECK_LAUNCH("colsum");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient, second pass: dW_oihw[co][ci0 + ci][tap] = scale * sum_s partial[s][tap][co][ci]  (ci < nci <= ldp)
+// ---------------------------------------------------------------------------------------------
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int taps, int Cout, int nci, int ldp, int ci0, int Cin,
+                                    float scale, float* __restrict__ dw) {
+    const long long total = (long long)Cout * nci * taps;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % nci);
+        const long long r = i / nci;
+        const int co = (int)(r % Cout);
+        const int tap = (int)(r / Cout);
+        float a = 0.0f;
+        for (int s = 0; s < S; ++s) a += part[(((long long)s * taps + tap) * Cout + co) * ldp + ci];
+        dw[((long long)co * Cin + ci0 + ci) * taps + tap] = a * scale;
+    }
+}
+
+extern "C" int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout, int nci, int ldp, int ci0, int Cin, float scale,
+                                float* dw_oihw, void* stream) {
+    EOD_REQUIRE(partial && dw_oihw && S > 0 && (ksize == 1 || ksize == 3) && Cout > 0 && nci > 0 && ldp >= nci && ci0 >= 0 && ci0 + nci <= Cin,
+                "wgrad_reduce: bad args");
+    const int taps = ksize * ksize;
+    const long long total = (long long)Cout * nci * taps;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, S, taps, Cout, nci, ldp, ci0, Cin, scale, dw_oihw);
+    EOD_CHECK_LAUNCH("wgrad_reduce");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics as (mean, rstd) per (image, group), from the forward's per-channel partial sums
+// (same inputs and arithmetic as eod_gn_finalize: double accumulation)
+// ---------------------------------------------------------------------------------------------
+__global__ void gn_mean_rstd_kernel(const float* __restrict__ part0, int P0, int C0, const float* __restrict__ part1, int P1, int C1,
+                                    long long HW, int groups, float eps, float* __restrict__ mr) {
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int Ctot = C0 + C1, cpg = Ctot / groups, c0 = g * cpg;
+    double s = 0.0, q = 0.0;
+    const int a0 = min(c0, C0), a1 = min(c0 + cpg, C0);
+    const int n0c = a1 - a0, n1c = cpg - n0c;
+    for (int i = tid; i < P0 * n0c; i += 256) {
+        const int p = i / n0c, c = a0 + (i - p * n0c);
+        const float* pp = part0 + (((long long)n * P0 + p) * C0 + c) * 2;
+        s += (double)pp[0];
+        q += (double)pp[1];
+    }
+    if (n1c > 0) {
+        const int b0 = max(c0, C0) - C0;
+        for (int i = tid; i < P1 * n1c; i += 256) {
+            const int p = i / n1c, c = b0 + (i - p * n1c);
+            const float* pp = part1 + (((long long)n * P1 + p) * C1 + c) * 2;
+            s += (double)pp[0];
+            q += (double)pp[1];
+        }
+    }
+    rs[tid] = s;
+    rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            rs[tid] += rs[tid + o];
+            rq[tid] += rq[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (double)HW * cpg;
+        const double mean = rs[0] / cnt;
+        double var = rq[0] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[((long long)n * groups + g) * 2 + 0] = (float)mean;
+        mr[((long long)n * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+extern "C" int eod_gn_mean_rstd(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW, int groups,
+                                float eps, float* mean_rstd, void* stream) {
+    EOD_REQUIRE(part0 && mean_rstd && N > 0 && P0 > 0 && C0 > 0 && C1 >= 0 && (C1 == 0 || (part1 && P1 > 0)) && groups > 0 &&
+                    (C0 + C1) % groups == 0,
+                "gn_mean_rstd: bad args");
+    hipLaunchKernelGGL(gn_mean_rstd_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part0, P0, C0, part1, P1, C1, (long long)HW, groups, eps, mean_rstd);
+    EOD_CHECK_LAUNCH("gn_mean_rstd");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(+SiLU) backward.  Forward: z = (x - mean)*rstd*gamma + beta, y = silu(z) (or z).
+//   dz = dy * silu'(z);  A[n][c] = sum_hw dz,  B[n][c] = sum_hw dz * x   (raw x: no statistics needed in this pass)
+// partial: same grid / layout as gn_partial: part[n][p][coff + c][0..1] = (A, B) over the pixels of slab p.
+// x is one concat source (C channels at channel offset coff of the Ctot-wide dy / scale-shift tables).
+// ---------------------------------------------------------------------------------------------
+template <bool FAST> __device__ __forceinline__ float dsilu_f(float z) {
+    float sg;
+    if constexpr (FAST)
+        sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+    else
+        sg = 1.0f / (1.0f + expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+template <typename T>
+__global__ void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ ss, int HW, int C,
+                                      float* __restrict__ part, int P, int Ctot, int coff, int silu) {
+    constexpr int EPC = dt<T>::epc;
+    constexpr bool FAST = (EPC == 8);
+    extern __shared__ float red[];  // [RY][CPP*EPC*2]
+    const int CPP = blockDim.x, RY = blockDim.y;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int p = blockIdx.x, n = blockIdx.y;
+    const int per = (HW + P - 1) / P;
+    const int p0 = p * per, p1 = min(HW, p0 + per);
+    float sa[EPC], sb[EPC], sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sa[e] = sb[e] = 0.0f;
+        sc[e] = ss[((long long)n * Ctot + coff + tx * EPC + e) * 2 + 0];
+        sh[e] = ss[((long long)n * Ctot + coff + tx * EPC + e) * 2 + 1];
+    }
+    const T* xb = x + (long long)n * HW * C + (long long)tx * EPC;
+    const T* db = dy + (long long)n * HW * Ctot + coff + (long long)tx * EPC;
+    for (int pix = p0 + ty; pix < p1; pix += RY) {
+        T xv[EPC], dv[EPC];
+        *reinterpret_cast<i32x4*>(xv) = *reinterpret_cast<const i32x4*>(xb + (long long)pix * C);
+        *reinterpret_cast<i32x4*>(dv) = *reinterpret_cast<const i32x4*>(db + (long long)pix * Ctot);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float xf = (float)xv[e];
+            float dz = (float)dv[e];
+            if (silu) dz *= dsilu_f<FAST>(xf * sc[e] + sh[e]);
+            sa[e] += dz;
+            sb[e] += dz * xf;
+        }
+    }
+    const int W2 = CPP * EPC * 2;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[ty * W2 + (tx * EPC + e) * 2 + 0] = sa[e];
+        red[ty * W2 + (tx * EPC + e) * 2 + 1] = sb[e];
+    }
+    __syncthreads();
+    const int tid = ty * CPP + tx, nthr = CPP * RY;
+    for (int i = tid; i < W2; i += nthr) {
+        float a = 0.0f;
+        for (int r = 0; r < RY; ++r) a += red[r * W2 + i];
+        const int c = i >> 1;
+        part[(((long long)n * P + p) * Ctot + coff + c) * 2 + (i & 1)] = a;
+    }
+}
+
+extern "C" int eod_gn_bwd_partial(const void* x, const void* dy, const float* scale_shift, int dtype, int N, int HW, int C, float* part,
+                                  int P, int Ctot, int coff, int silu, void* stream) {
+    EOD_REQUIRE(x && dy && scale_shift && part && N > 0 && HW > 0 && C > 0 && P > 0 && P <= HW, "gn_bwd_partial: bad args");
+    const int epc = 16 / eod_esize(dtype);
+    EOD_REQUIRE(C % epc == 0 && C / epc <= 256 && Ctot % epc == 0 && coff % epc == 0, "gn_bwd_partial: C=%d Ctot=%d coff=%d unsupported", C, Ctot, coff);
+    EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(dy), "gn_bwd_partial: alignment");
+    const int cpp = C / epc;
+    int ry = 256 / cpp;
+    if (ry < 1) ry = 1;
+    const size_t lds = (size_t)ry * cpp * epc * 2 * sizeof(float);
+    dim3 grid(P, N), block(cpp, ry);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(gn_bwd_partial_kernel<half_t>, grid, block, lds, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy, scale_shift, HW, C, part, P, Ctot, coff, silu);
+    else
+        hipLaunchKernelGGL(gn_bwd_partial_kernel<float>, grid, block, lds, (hipStream_t)stream, (const float*)x, (const float*)dy, scale_shift, HW, C, part, P, Ctot, coff, silu);
+    EOD_CHECK_LAUNCH("gn_bwd_partial");
+    return EOD_OK;
+}
+
+// finalize: grid (groups, N).  With xh = (x - mean)*rstd and m = cpg*HW:
+//   S1 = sum_{c in g} gamma_c A_c,   S2 = sum_{c in g} gamma_c * rstd * (B_c - mean*A_c)
+//   dx = rstd*gamma_c*dz - rstd*S1/m - xh*rstd*S2/m  =  k1_c*dz + k2*x + k3
+//   k1_c = rstd*gamma_c,  k2 = -rstd^2*S2/m,  k3 = -rstd*S1/m + mean*rstd^2*S2/m        -> coef[n][c][0..2]
+// and the per-image parameter-gradient terms  gb[n][c] = (rstd*(B_c - mean*A_c), A_c)  (dgamma, dbeta = sum over n).
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int P, int Ctot, long long HW, int groups,
+                                       const float* __restrict__ mr, const float* __restrict__ gamma, float* __restrict__ coef,
+                                       float* __restrict__ gb) {
+    __shared__ double r1[256], r2[256];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = Ctot / groups, c0 = g * cpg;
+    const double mean = (double)mr[((long long)n * groups + g) * 2 + 0], rstd = (double)mr[((long long)n * groups + g) * 2 + 1];
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = c0 + tid; c < c0 + cpg; c += 256) {
+        double A = 0.0, B = 0.0;
+        for (int p = 0; p < P; ++p) {
+            const float* pp = part + (((long long)n * P + p) * Ctot + c) * 2;
+            A += (double)pp[0];
+            B += (double)pp[1];
+        }
+        const double bh = rstd * (B - mean * A);  // sum dz * xh
+        gb[((long long)n * Ctot + c) * 2 + 0] = (float)bh;
+        gb[((long long)n * Ctot + c) * 2 + 1] = (float)A;
+        s1 += (double)gamma[c] * A;
+        s2 += (double)gamma[c] * bh;
+    }
+    r1[tid] = s1;
+    r2[tid] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            r1[tid] += r1[tid + o];
+            r2[tid] += r2[tid + o];
+        }
+        __syncthreads();
+    }
+    const double m = (double)HW * cpg;
+    const double S1 = r1[0], S2 = r2[0];
+    const double k2 = -rstd * rstd * S2 / m;
+    const double k3 = -rstd * S1 / m + mean * rstd * rstd * S2 / m;
+    for (int c = c0 + tid; c < c0 + cpg; c += 256) {
+        coef[((long long)n * Ctot + c) * 3 + 0] = (float)(rstd * (double)gamma[c]);
+        coef[((long long)n * Ctot + c) * 3 + 1] = (float)k2;
+        coef[((long long)n * Ctot + c) * 3 + 2] = (float)k3;
+    }
+}
+
+extern "C" int eod_gn_bwd_finalize(const float* part, int P, int Ctot, int N, int64_t HW, int groups, const float* mean_rstd,
+                                   const float* gamma, float* coef, float* gb, void* stream) {
+    EOD_REQUIRE(part && mean_rstd && gamma && coef && gb && P > 0 && Ctot > 0 && N > 0 && groups > 0 && Ctot % groups == 0, "gn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part, P, Ctot, (long long)HW, groups, mean_rstd, gamma, coef, gb);
+    EOD_CHECK_LAUNCH("gn_bwd_finalize");
+    return EOD_OK;
+}
+
+// dgamma[c] = sum_n gb[n][c][0], dbeta[c] = sum_n gb[n][c][1]   (fixed order)
+__global__ void gn_bwd_params_kernel(const float* __restrict__ gb, int N, int Ctot, float scale, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Ctot) return;
+    float a = 0.0f, b = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        a += gb[((long long)n * Ctot + c) * 2 + 0];
+        b += gb[((long long)n * Ctot + c) * 2 + 1];
+    }
+    dgamma[c] = a * scale;
+    dbeta[c] = b * scale;
+}
+
+extern "C" int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, float* dgamma, float* dbeta, void* stream) {
+    EOD_REQUIRE(gb && dgamma && dbeta && N > 0 && Ctot > 0, "gn_bwd_params: bad args");
+    hipLaunchKernelGGL(gn_bwd_params_kernel, dim3((Ctot + 255) / 256), dim3(256), 0, (hipStream_t)stream, gb, N, Ctot, scale, dgamma, dbeta);
+    EOD_CHECK_LAUNCH("gn_bwd_params");
+    return EOD_OK;
+}
+
+// apply: dx[n][pix][c] = k1*dz + k2*x + k3 (+ add[n][pix][c]);  one concat source per launch (C channels at coff)
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ ss,
+                                    const float* __restrict__ coef, const T* __restrict__ add, long long nchunks, int HW, int C, int Ctot,
+                                    int coff, int silu, T* __restrict__ dx) {
+    constexpr int EPC = dt<T>::epc;
+    constexpr bool FAST = (EPC == 8);
+    const int cpp = C / EPC;
+    const long long per_n = (long long)HW * cpp;
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < nchunks; f += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(f / per_n);
+        const long long rem = f - (long long)n * per_n;
+        const long long pix = rem / cpp;
+        const int c = (int)(rem - pix * cpp) * EPC;
+        T xv[EPC], dv[EPC], av[EPC], ov[EPC];
+        *reinterpret_cast<i32x4*>(xv) = *reinterpret_cast<const i32x4*>(x + f * EPC);
+        *reinterpret_cast<i32x4*>(dv) = *reinterpret_cast<const i32x4*>(dy + ((long long)n * HW + pix) * Ctot + coff + c);
+        if (add) *reinterpret_cast<i32x4*>(av) = *reinterpret_cast<const i32x4*>(add + f * EPC);
+        const float* sp = ss + ((long long)n * Ctot + coff + c) * 2;
+        const float* kp = coef + ((long long)n * Ctot + coff + c) * 3;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float xf = (float)xv[e];
+            float dz = (float)dv[e];
+            if (silu) dz *= dsilu_f<FAST>(xf * sp[2 * e] + sp[2 * e + 1]);
+            float v = kp[3 * e] * dz + kp[3 * e + 1] * xf + kp[3 * e + 2];
+            if (add) v += (float)av[e];
+            ov[e] = (T)v;
+        }
+        *reinterpret_cast<i32x4*>(dx + f * EPC) = *reinterpret_cast<const i32x4*>(ov);
+    }
+}
+
+extern "C" int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype, int N,
+                                int HW, int C, int Ctot, int coff, int silu, void* dx, void* stream) {
+    EOD_REQUIRE(x && dy && scale_shift && coef && dx && N > 0 && HW > 0 && C > 0, "gn_bwd_apply: bad args");
+    const int epc = 16 / eod_esize(dtype);
+    EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_bwd_apply: channel alignment");
+    EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(dy) && eod_aligned16(dx) && (!add || eod_aligned16(add)), "gn_bwd_apply: alignment");
+    const long long nchunks = (long long)N * HW * (C / epc);
+    long long blocks = (nchunks + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const half_t*)x, (const half_t*)dy, scale_shift, coef, (const half_t*)add, nchunks, HW, C, Ctot, coff, silu, (half_t*)dx);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (const float*)dy, scale_shift, coef, (const float*)add, nchunks, HW, C, Ctot, coff, silu, (float*)dx);
+    EOD_CHECK_LAUNCH("gn_bwd_apply");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = a + b (storage dtype, 16-byte chunks): joins two gradient branches when no conv epilogue is at hand
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long nchunks) {
+    constexpr int EPC = dt<T>::epc;
+    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < nchunks; f += (long long)gridDim.x * blockDim.x) {
+        T av[EPC], bv[EPC], ov[EPC];
+        *reinterpret_cast<i32x4*>(av) = *reinterpret_cast<const i32x4*>(a + f * EPC);
+        *reinterpret_cast<i32x4*>(bv) = *reinterpret_cast<const i32x4*>(b + f * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) ov[e] = (T)((float)av[e] + (float)bv[e]);
+        *reinterpret_cast<i32x4*>(y + f * EPC) = *reinterpret_cast<const i32x4*>(ov);
+    }
+}
+
+extern "C" int eod_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream) {
+    const int epc = 16 / eod_esize(dtype);
+    EOD_REQUIRE(a && b && y && n > 0 && n % epc == 0 && eod_aligned16(a) && eod_aligned16(b) && eod_aligned16(y), "add: bad args");
+    const long long nchunks = n / epc;
+    long long blocks = (nchunks + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(add_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b, (half_t*)y, nchunks);
+    else
+        hipLaunchKernelGGL(add_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)y, nchunks);
+    EOD_CHECK_LAUNCH("add");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small dense layers of the timestep-embedding MLP (unet_openai.py:597-602, 329-335), fp32, N = batch rows:
+//   forward  out[n][j] = sum_k in[n][k] * w[j][k] + b[j]
+//   backward dW[j][k] = scale * sum_n dout[n][j] * in[n][k],  db[j] = scale * sum_n dout[n][j],
+//            din[n][k] = sum_j dout[n][j] * w[j][k]
+// `in` is the ACTIVATED input of the layer (act_in: 0 = as stored, 1 = SiLU(in), 2 = sinusoid of t).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float temb_in(const float* in, const long long* t, const float* freqs, int n, int k, int K, int act_in) {
+    if (act_in == 2) {
+        const int half = K / 2;
+        const float tf = (float)t[n];
+        if (k < half) return cosf(tf * freqs[k]);
+        if (k < 2 * half) return sinf(tf * freqs[k - half]);
+        return 0.0f;
+    }
+    const float v = in[(long long)n * K + k];
+    return act_in == 1 ? silu_f<false>(v) : v;
+}
+
+__global__ void linear_bwd_w_kernel(const float* __restrict__ dout, long long ld_dout, const float* __restrict__ in, const long long* __restrict__ t,
+                                    const float* __restrict__ freqs, int N, int K, int J, int act_in, float scale, float* __restrict__ dW,
+                                    float* __restrict__ db) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)J * K) return;
+    const int j = (int)(i / K), k = (int)(i - (long long)j * K);
+    float a = 0.0f, b = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        const float d = dout[(long long)n * ld_dout + j];
+        a += d * temb_in(in, t, freqs, n, k, K, act_in);
+        b += d;
+    }
+    dW[i] = a * scale;
+    if (k == 0 && db) db[j] = b * scale;
+}
+
+// din[n][k] = sum_j dout[n][j] * w[j][k]; optionally multiplied by silu'(pre[n][k]) (the layer's input was SiLU(pre))
+__global__ void linear_bwd_in_kernel(const float* __restrict__ dout, long long ld_dout, const float* __restrict__ w, const float* __restrict__ pre,
+                                     int N, int K, int J, float* __restrict__ din) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+    float a = 0.0f;
+    for (int j = 0; j < J; ++j) a += dout[(long long)n * ld_dout + j] * w[(long long)j * K + k];
+    if (pre) a *= dsilu_f<false>(pre[i]);
+    din[i] = a;
+}
+
+extern "C" int eod_linear_bwd_small(const float* dout, int64_t ld_dout, const float* in, const int64_t* t, const float* freqs,
+                                    const float* w, const float* pre, int N, int K, int J, int act_in, float scale, float* dW, float* db,
+                                    float* din, void* stream) {
+    EOD_REQUIRE(dout && w && N > 0 && K > 0 && J > 0 && ld_dout >= J && act_in >= 0 && act_in <= 2, "linear_bwd_small: bad args");
+    EOD_REQUIRE(act_in == 2 ? (t && freqs) : (in != nullptr || !dW), "linear_bwd_small: missing input");
+    hipStream_t st = (hipStream_t)stream;
+    if (dW) {
+        const long long tot = (long long)J * K;
+        hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dout, (long long)ld_dout, in, (const long long*)t, freqs, N, K, J, act_in, scale, dW, db);
+    }
+    if (din) {
+        const long long tot = (long long)N * K;
+        hipLaunchKernelGGL(linear_bwd_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dout, (long long)ld_dout, w, pre, N, K, J, din);
+    }
+    EOD_CHECK_LAUNCH("linear_bwd_small");
+    return EOD_OK;
+}
+
+// pre-activation of time_embed[0] (needed for SiLU' in the backward; the forward only keeps SiLU(pre1)):
+//   pre1[n][j] = sum_k sinusoid(t[n])[k] * w1[j][k] + b1[j]
+__global__ void temb_pre1_kernel(const long long* __restrict__ t, const float* __restrict__ freqs, const float* __restrict__ w1,
+                                 const float* __restrict__ b1, int N, int D, int E, float* __restrict__ pre1) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * E) return;
+    const int n = (int)(i / E), j = (int)(i - (long long)n * E);
+    float a = 0.0f;
+    for (int k = 0; k < D; ++k) a += temb_in(nullptr, t, freqs, n, k, D, 2) * w1[(long long)j * D + k];
+    pre1[i] = a + b1[j];
+}
+
+extern "C" int eod_temb_pre1(const int64_t* t, const float* freqs, const float* w1, const float* b1, int N, int D, int E, float* pre1,
+                             void* stream) {
+    EOD_REQUIRE(t && freqs && w1 && b1 && pre1 && N > 0 && D > 0 && E > 0, "temb_pre1: bad args");
+    const long long tot = (long long)N * E;
+    hipLaunchKernelGGL(temb_pre1_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long long*)t, freqs, w1, b1, N, D, E, pre1);
+    EOD_CHECK_LAUNCH("temb_pre1");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax backward, one wave per row: dS = P * (dP - sum(dP * P)); pad columns [n, ldp) are zeroed (they are K
+// positions of the following GEMMs)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const T* __restrict__ P, long long ldp, const float* __restrict__ dP, long long lds,
+                                                               T* __restrict__ dS, long long rows, int n) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const T* p = P + r * ldp;
+    const float* g = dP + r * lds;
+    float acc = 0.0f;
+    for (int j = lane; j < n; j += 64) acc += g[j] * (float)p[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    T* o_ = dS + r * ldp;
+    for (int j = lane; j < (int)ldp; j += 64) o_[j] = j < n ? (T)((float)p[j] * (g[j] - acc)) : (T)0.0f;
+}
+
+extern "C" int eod_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lds, void* dS, int dtype, int64_t rows, int n,
+                                    void* stream) {
+    EOD_REQUIRE(P && dP && dS && rows > 0 && n > 0 && ldp >= n && lds >= n, "softmax_bwd_rows: bad args");
+    const long long blocks = (rows + 3) / 4;
+    EOD_REQUIRE(blocks <= 0x7fffffffLL, "softmax_bwd_rows: too many rows");
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(softmax_bwd_rows_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)P, (long long)ldp, dP, (long long)lds, (half_t*)dS, (long long)rows, n);
+    else
+        hipLaunchKernelGGL(softmax_bwd_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)P, (long long)ldp, dP, (long long)lds, (float*)dS, (long long)rows, n);
+    EOD_CHECK_LAUNCH("softmax_bwd_rows");
+    return EOD_OK;
+}

@@ -231,6 +231,7 @@ class Program:
                 parts.append((part, P, s.C))
         if len(parts) > 2:
             raise ValueError("GroupNorm over more than two concatenated sources is not supported")
+        self.last_gn_parts = parts  # (partial-sum tensor, P, C) per source: the training path derives mean / rstd from them
         ss = self.empty((N, ctot, 2), torch.float32)
         p1 = parts[1] if len(parts) == 2 else (None, 0, 0)
         self._small(OP_GN_FINALIZE,

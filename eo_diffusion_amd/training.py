@@ -1,0 +1,525 @@
+"""Training step of the UNet on the HIP path (reference train.py:109-124:
+`pred = model(image, noise)`, `loss = MSELoss(pred, noise)`, `loss.backward()`).
+
+`UNetTrainer` builds, per input shape, (1) a forward Program that keeps every activation the backward needs and
+(2) a static list of backward launches.  The backward reuses the forward's MFMA kernels (see csrc/train.hip):
+backward-data = implicit-GEMM conv with flipped weights, backward-weights = batched NT GEMM over the pixel axis on
+transposed operands, GroupNorm/SiLU/timestep-MLP backward = small HBM-bound kernels.  Parameter gradients are fp32 and are
+assigned to `param.grad`, so `torch.optim.AdamW(model.parameters())` / `AveragedModel` of the reference script work
+unchanged on them.
+
+Scope of this first version: ResBlock (plain), AttentionBlock (legacy qkv order), Upsample / Downsample with conv,
+first / head conv, the timestep MLP.  Not yet: use_scale_shift_norm, resblock_updown, use_new_attention_order, class
+conditioning, dropout > 0, odd spatial sizes -- these raise EodError (never a silent fallback)."""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import OP_TRANSPOSE, ConvDesc, EodError, check, ptr
+from .engine import Act, Program, current_stream_ptr, round_up
+
+
+class _ConvRec:
+    def __init__(self, srcs, conv, y, *, ksize=3, stride=1, upsample=False, res=None, emb=None, src_needs_grad=True, cout_rows=None):
+        self.srcs, self.conv, self.y = srcs, conv, y
+        self.ksize, self.stride, self.upsample, self.res, self.emb = ksize, stride, upsample, res, emb
+        self.src_needs_grad = src_needs_grad
+        self.cout_rows = cout_rows  # real output channels when y is channel-padded (head conv)
+
+
+class _GNRec:
+    def __init__(self, srcs, gn, ss, parts, y, silu):
+        self.srcs, self.gn, self.ss, self.parts, self.y, self.silu = srcs, gn, ss, parts, y, silu
+
+
+class _AttnRec:
+    """softmax(q k^T / sqrt(d)) v on the natural [N][T][heads x (q|k|v) x d] layout of qkv (QKVAttentionLegacy, :465-481)"""
+
+    def __init__(self, qkv, qkvT, ldT, P, a, nh, d):
+        self.qkv, self.qkvT, self.ldT, self.P, self.a, self.nh, self.d = qkv, qkvT, ldT, P, a, nh, d
+
+
+class UNetTrainer:
+    """Forward + backward of one UNetModel for a fixed input shape.  Usage:
+        tr = UNetTrainer(unet, N, H, W, device, loss_scale=1024.)
+        pred = tr.forward(x, t)                  # NCHW fp32, identical math to the inference program (unfused GroupNorm)
+        tr.backward(dpred)                       # dpred NCHW fp32 = dLoss/dpred; fills p.grad for every parameter
+    """
+
+    def __init__(self, unet, N, H, W, device, *, cond_channels=0, loss_scale=1.0):
+        from .backbones import unet_openai as U
+        self.U = U
+        self.unet = unet
+        self.device = torch.device(device)
+        self.N, self.H, self.W = N, H, W
+        self.loss_scale = float(loss_scale)
+        self.inv_scale = 1.0 / self.loss_scale
+        self.prog = Program(self.device, unet.precision)   # forward ops (native executor)
+        self.bprog = Program(self.device, unet.precision)  # backward ops that reuse executor op kinds
+        self.L = self.prog.L
+        self.dt = self.prog.dt
+        self.es = self.prog.tdtype.itemsize
+        self.bwd = []        # backward launches in execution order: ("op", Op) | ("call", fn, args)
+        self.contrib = {}    # id(Act) -> [Act, ...] gradient contributions
+        self.pgrad = {}      # Parameter -> fp32 gradient tensor
+        self.repack = []     # closures refreshing packed weights from the (updated) parameters
+        self.recs = []
+        self._keep = []
+        self._build(cond_channels)
+
+    # ------------------------------------------------------------------ small helpers
+    def _call(self, fn, *args):
+        self.bwd.append(("call", fn, args))
+
+    def _bop(self, build):
+        n0 = len(self.bprog.ops)
+        r = build()
+        for op in self.bprog.ops[n0:]:
+            self.bwd.append(("op", op))
+        return r
+
+    def _param_grad(self, p):
+        if p not in self.pgrad:
+            self.pgrad[p] = torch.zeros_like(p, dtype=torch.float32, device=self.device)
+        return self.pgrad[p]
+
+    def _add_grad(self, act, g):
+        self.contrib.setdefault(id(act), []).append(g)
+        self._keep.append(act)
+
+    def _pop_single(self, act):
+        lst = self.contrib.get(id(act), [])
+        if len(lst) == 1:
+            return lst.pop()
+        return None
+
+    def _take_grad(self, act):
+        lst = self.contrib.pop(id(act), [])
+        if not lst:
+            return None
+        g = lst[0]
+        for other in lst[1:]:
+            out = self.bprog.act(g.N, g.H, g.W, g.C)
+            self._call(self.L.eod_add, ptr(g.t), ptr(other.t), ptr(out.t), self.dt, g.t.numel())
+            g = out
+        return g
+
+    def _pack(self, fn, param):
+        """packed weight buffer that is re-packed from `param` before every forward"""
+        buf = fn()
+        self.repack.append(fn)
+        return buf
+
+    # ------------------------------------------------------------------ forward emission (training form)
+    def _conv_fwd(self, srcs, conv, *, ksize=3, stride=1, upsample=False, res=None, emb=None, stats=True, src_needs_grad=True):
+        prog = self.prog
+        w = prog.pack_conv(conv.weight)
+        self.repack.append(lambda w=w, conv=conv: self._repack_conv(w, conv))
+        kw = {}
+        if emb is not None:
+            kw = dict(cbias=emb[0], cbias_stride=emb[1])
+        y, _ = prog.conv(srcs[0], w, prog.f32(conv.bias), conv.out_channels, x2=srcs[1] if len(srcs) > 1 else None,
+                         ksize=ksize, stride=stride, pad=ksize // 2, upsample=upsample, res=res, stats=stats, **kw)
+        self.recs.append(_ConvRec(srcs, conv, y, ksize=ksize, stride=stride, upsample=upsample, res=res, emb=emb,
+                                  src_needs_grad=src_needs_grad))
+        return y
+
+    def _repack_conv(self, dst, conv, cin_pad=None):
+        w = conv.weight.detach()
+        cout, cin = w.shape[0], w.shape[1]
+        ks = w.shape[2]
+        check(self.L.eod_pack_conv_weight(ptr(w), ptr(dst), self.dt, cout, cin, ks, cin_pad or cin, current_stream_ptr(self.device)),
+              "pack_conv_weight")
+
+    def _gn_fwd(self, srcs, gn, silu=True):
+        prog = self.prog
+        ss = prog.gn_stats(srcs, prog.f32(gn.weight), prog.f32(gn.bias), eps=gn.eps)
+        parts = prog.last_gn_parts
+        y = prog.gn_apply(srcs, ss, silu=silu)
+        self.recs.append(_GNRec(srcs, gn, ss, parts, y, silu))
+        return y
+
+    def _resblock(self, blk, h):
+        U = self.U
+        srcs = list(h) if isinstance(h, tuple) else [h]
+        if blk.updown or blk.use_scale_shift_norm:
+            raise EodError("training: resblock_updown / use_scale_shift_norm are not built yet")
+        if blk.dropout > 0:
+            raise EodError("training: dropout > 0 is not built yet")
+        gn1, conv1 = blk.in_layers[0], blk.in_layers[2]
+        gn2, conv2 = blk.out_layers[0], blk.out_layers[3]
+        a1 = self._gn_fwd(srcs, gn1)
+        off = self.ctx.offsets[id(blk)]
+        emb_view = self.ctx.out[:, off:]
+        h1 = self._conv_fwd([a1], conv1, emb=(emb_view, self.ctx.J, off))
+        a2 = self._gn_fwd([h1], gn2)
+        if isinstance(blk.skip_connection, nn.Identity):
+            if len(srcs) != 1:
+                raise EodError("identity skip over a virtual concat is not supported")
+            skip = srcs[0]
+        else:
+            k = blk.skip_connection.kernel_size[0]
+            skip = self._conv_fwd(srcs, blk.skip_connection, ksize=k, stats=False)
+        return self._conv_fwd([a2], conv2, res=skip)
+
+    def _layer(self, layer, h):
+        U = self.U
+        if isinstance(layer, U.ResBlock):
+            return self._resblock(layer, h)
+        if isinstance(layer, U.Upsample):
+            if not layer.use_conv or isinstance(h, tuple) or (h.H == 3 and h.W == 3):
+                raise EodError("training: this Upsample variant is not built yet")
+            return self._conv_fwd([h], layer.conv, upsample=True)
+        if isinstance(layer, U.Downsample):
+            if not layer.use_conv or h.H % 2 or h.W % 2:
+                raise EodError("training: this Downsample variant is not built yet (needs conv, even sizes)")
+            return self._conv_fwd([h], layer.op, stride=2)
+        if isinstance(layer, U.AttentionBlock):
+            return self._attention(layer, h)
+        raise EodError(f"training: unsupported layer {type(layer).__name__}")
+
+    def _transpose_op(self, prog, src, N, T, C, dst, ld):
+        """[N][T][C] -> [C][ld] (column n*T + t), as an executor op"""
+        prog._small(OP_TRANSPOSE, p=(ptr(src), ptr(dst)), l=(ld, 0, 0, 0), i=(self.dt, N, 1, T, C, 1, T, 1, 0, 0))
+
+    def _attention(self, blk, x):
+        """x + proj_out(attention(qkv(GN(x)))), unet_openai.py:427-433, in a form whose every piece has a backward here:
+        qkv / proj_out as 1x1 convs, scores and P.V as batched NT GEMMs on qkv and its transpose, P kept for the backward"""
+        prog = self.prog
+        if isinstance(x, tuple) or blk.attention.new_order:
+            raise EodError("training: this AttentionBlock variant is not built yet (legacy qkv order, single source)")
+        Cc, nh = blk.channels, blk.num_heads
+        d = Cc // nh
+        N, T = x.N, x.H * x.W
+        if d % prog.epc or T % prog.epc:
+            raise EodError(f"training: attention needs head dim {d} and sequence {T} to be multiples of {prog.epc}")
+        xn = self._gn_fwd([x], blk.norm, silu=False)
+        qkv = self._conv_fwd([xn], blk.qkv, ksize=1, stats=False)          # [N][T][3C], channel = h*3d + {q,k,v}*d + j
+        BK = 128 // self.es
+        ldT = round_up(N * T, BK)
+        qkvT = prog.empty((3 * Cc * ldT,), zero=True)
+        self._transpose_op(prog, qkv.t, N, T, 3 * Cc, qkvT, ldT)
+        S = prog.empty((N * nh, T, T), torch.float32)
+        prog.gemm(qkv.t, qkv.t, S, T, T, d, 3 * Cc, 3 * Cc, T, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
+                  sa=(T * 3 * Cc, 3 * d), sb=(T * 3 * Cc, 3 * d), sc=(nh * T * T, T * T), b_off=d)
+        P = prog.empty((N * nh, T, T))
+        prog.softmax_rows(S, T, P, T, N * nh * T, T)
+        a = prog.act(N, x.H, x.W, Cc)
+        # a[n][t][h*d + j] = sum_s P[n,h][t][s] * v[n][s][h][j]  with v^T rows taken from qkvT
+        prog.gemm(P, qkvT, a.t, T, d, T, T, ldT, Cc, nb0=N, nb1=nh, sa=(nh * T * T, T * T), sb=(T, 3 * d * ldT),
+                  sc=(T * Cc, d), b_off=2 * d * ldT)
+        self.recs.append(_AttnRec(qkv, qkvT, ldT, P, a, nh, d))
+        return self._conv_fwd([a], blk.proj_out, ksize=1, res=x, stats=True)
+
+    def _attn_bwd(self, rec):
+        L, bp, dt, es = self.L, self.bprog, self.dt, self.es
+        da = self._take_grad(rec.a)
+        if da is None:
+            raise EodError("training: attention output has no gradient (graph bug)")
+        qkv, qkvT, ldT, P, nh, d = rec.qkv, rec.qkvT, rec.ldT, rec.P, rec.nh, rec.d
+        N, T, Cc = qkv.N, qkv.H * qkv.W, rec.a.C
+        B = N * nh
+        alpha = 1.0 / math.sqrt(d)
+        BK = 128 // es
+        # dP[b][t][s] = sum_j da[n][t][h*d+j] * v[n][s][h][j]
+        dP = bp.empty((B, T, T), torch.float32)
+        self._bop(lambda: bp.gemm(da.t, qkv.t, dP, T, T, d, Cc, 3 * Cc, T, c_f32=True, nb0=N, nb1=nh, sa=(T * Cc, d),
+                                  sb=(T * 3 * Cc, 3 * d), sc=(nh * T * T, T * T), b_off=2 * d))
+        dS = bp.empty((B, T, T))
+        self._call(L.eod_softmax_bwd_rows, ptr(P), T, ptr(dP), T, ptr(dS), dt, B * T, T)
+        ldB = round_up(B * T, BK)
+        dST = bp.empty((T * ldB,), zero=True)   # [s][b*T + t]
+        PT = bp.empty((T * ldB,), zero=True)
+        self._call(L.eod_transpose_gather, ptr(dS), dt, B, 1, T, T, ptr(dST), ldB, 1, T, 1, 0, 0, 0, 0, 0)
+        self._call(L.eod_transpose_gather, ptr(P), dt, B, 1, T, T, ptr(PT), ldB, 1, T, 1, 0, 0, 0, 0, 0)
+        daT = bp.empty((Cc * ldT,), zero=True)  # [h*d + j][n*T + t]
+        self._call(L.eod_transpose_gather, ptr(da.t), dt, N, 1, T, Cc, ptr(daT), ldT, 1, T, 1, 0, 0, 0, 0, 0)
+        dqkv = bp.act(qkv.N, qkv.H, qkv.W, 3 * Cc)
+        # dq[n][t][h][j] = alpha * sum_s dS[b][t][s] * k[n][s][h][j]      (k^T rows from qkvT)
+        self._bop(lambda: bp.gemm(dS, qkvT, dqkv.t, T, d, T, T, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T * T, T * T),
+                                  sb=(T, 3 * d * ldT), sc=(T * 3 * Cc, 3 * d), b_off=d * ldT))
+        # dk[n][s][h][j] = alpha * sum_t dS[b][t][s] * q[n][t][h][j]      (dS^T and q^T)
+        self._bop(lambda: bp.gemm(dST, qkvT, dqkv.t, T, d, T, ldB, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T, T),
+                                  sb=(T, 3 * d * ldT), sc=(T * 3 * Cc, 3 * d), c_off=d))
+        # dv[n][s][h][j] = sum_t P[b][t][s] * da[n][t][h*d+j]
+        self._bop(lambda: bp.gemm(PT, daT, dqkv.t, T, d, T, ldB, ldT, 3 * Cc, nb0=N, nb1=nh, sa=(nh * T, T),
+                                  sb=(T, d * ldT), sc=(T * 3 * Cc, 3 * d), c_off=2 * d))
+        self._add_grad(qkv, dqkv)
+
+    def _seq(self, seq, h):
+        for layer in seq:
+            h = self._layer(layer, h)
+        return h
+
+    def _build(self, ccond):
+        U, unet, prog, N, H, W = self.U, self.unet, self.prog, self.N, self.H, self.W
+        if unet.num_classes is not None:
+            raise EodError("training: class conditioning is not built yet")
+        cx = unet.in_channels - ccond
+        c_pad = round_up(unet.in_channels, prog.epc)
+        a0, self.i_in = prog.to_nhwc(N, cx, ccond, H, W, c_pad)
+        # ---- timestep embedding (same single descriptor as the inference program) ----
+        ctx = self.ctx = U._EmbCtx()
+        for m in unet.modules():
+            if isinstance(m, U.ResBlock):
+                ctx.register(m)
+        te1, te2 = unet.time_embed[0], unet.time_embed[2]
+        self.E, self.D = te1.out_features, te1.in_features
+        self.wcat = prog.empty((ctx.J, self.E), torch.float32)
+        self.bcat = prog.empty((ctx.J,), torch.float32)
+        self.repack.append(self._refresh_cat)
+        self.freqs = prog.own(U.timestep_frequencies(self.D).to(self.device))
+        ctx.out = prog.empty((N, ctx.J), torch.float32)
+        self.h1 = prog.empty((N, self.E), torch.float32)
+        self.emb = prog.empty((N, self.E), torch.float32)
+        self.i_t = prog.temb(dict(
+            t=0, freqs=ptr(self.freqs), w1=ptr(prog.f32(te1.weight)), b1=ptr(prog.f32(te1.bias)),
+            w2=ptr(prog.f32(te2.weight)), b2=ptr(prog.f32(te2.bias)), label_emb=0, y=0,
+            wcat=ptr(self.wcat), bcat=ptr(self.bcat), h1=ptr(self.h1), emb=ptr(self.emb), out=ptr(ctx.out),
+            N=N, D=self.D, E=self.E, J=ctx.J))
+        # ---- encoder / middle / decoder ----
+        conv0 = unet.input_blocks[0][0]
+        w0 = prog.pack_conv(conv0.weight, cin_pad=c_pad)
+        self.repack.append(lambda: self._repack_conv(w0, conv0, c_pad))
+        h, _ = prog.conv(a0, w0, prog.f32(conv0.bias), conv0.out_channels, stats=True)
+        self.recs.append(_ConvRec([a0], conv0, h, src_needs_grad=False))
+        hs = [h]
+        for blk in list(unet.input_blocks)[1:]:
+            h = self._seq(blk, h)
+            hs.append(h)
+        h = self._seq(unet.middle_block, h)
+        for blk in unet.output_blocks:
+            h = self._seq(blk, (h, hs.pop()))
+        # ---- head: the NCHW fp32 output is produced from a channel-padded NHWC conv output ----
+        gn, conv = unet.out[0], unet.out[2]
+        a = self._gn_fwd([h], gn)
+        self.cout = unet.out_channels
+        self.cout_pad = round_up(self.cout, prog.epc)
+        wh = prog.pack_conv(conv.weight)
+        self.repack.append(lambda: self._repack_conv(wh, conv))
+        self.pred = torch.empty((N, self.cout, H, W), dtype=torch.float32, device=self.device)
+        _, i_out = prog.conv(a, wh, prog.f32(conv.bias), self.cout, out_nchw_f32=True)
+        prog.ops[i_out].u.conv.y = self.pred.data_ptr()
+        self.head = (a, conv)
+        prog.finalize()
+        self._build_backward()
+
+    def _refresh_cat(self):
+        torch.cat([b.emb_layers[1].weight.detach().float() for b in self.ctx.blocks], 0, out=self.wcat)
+        torch.cat([b.emb_layers[1].bias.detach().float() for b in self.ctx.blocks], 0, out=self.bcat)
+
+    # ------------------------------------------------------------------ backward emission
+    def _build_backward(self):
+        N, H, W = self.N, self.H, self.W
+        bp = self.bprog
+        # dLoss/dpred arrives NCHW fp32 -> NHWC storage dtype, channels padded to one 16-byte chunk, times loss_scale
+        self.dpred = torch.zeros((N, self.cout, H, W), dtype=torch.float32, device=self.device)
+        gpred, _ = self._bop(lambda: bp.to_nhwc(N, self.cout, 0, H, W, self.cout_pad))
+        self.bwd[-1][1].u.small.p[0] = self.dpred.data_ptr()
+        self.dout_cat = bp.empty((N, self.ctx.J), torch.float32)
+        a_head, conv_head = self.head
+        head_y = Act(None, N, H, W, self.cout_pad)
+        self._add_grad(head_y, gpred)
+        self._conv_bwd(_ConvRec([a_head], conv_head, head_y, cout_rows=self.cout))
+        for rec in reversed(self.recs):
+            if isinstance(rec, _ConvRec):
+                self._conv_bwd(rec)
+            elif isinstance(rec, _AttnRec):
+                self._attn_bwd(rec)
+            else:
+                self._gn_bwd(rec)
+        self._temb_bwd()
+        bp.finalize()
+
+    def _wgrad(self, rec, dy, dYt, ld, Kper, S, rp, cout):
+        """dW of one conv from the transposed output gradient dYt [rows][ld] (see csrc/train.hip)"""
+        L, bp, dt, es = self.L, self.bprog, self.dt, self.es
+        N, Ho, Wo = dy.N, dy.H, dy.W
+        ks, stride = rec.ksize, rec.stride
+        taps = ks * ks
+        conv = rec.conv
+        cin_total = conv.weight.shape[1]
+        dW = self._param_grad(conv.weight)
+        ci0 = 0
+        for xs in rec.srcs:
+            cs = xs.C
+            cs_real = min(cs, cin_total - ci0)
+            ldp = round_up(cs, 4)
+            s1 = ks == 3 and stride == 1
+            ncopy = 3 if s1 else taps
+            margin = round_up(Wo, 8) if s1 else 0
+            xt = bp.empty((ncopy * (cs * ld + 2 * margin),))
+            xt.zero_()
+            per = cs * ld + 2 * margin
+            for k in range(ncopy):
+                if s1:
+                    gdy, gdx, pad = 1, k, 1
+                elif ks == 3:
+                    gdy, gdx, pad = k // 3, k % 3, 1
+                else:
+                    gdy, gdx, pad = 0, 0, 0
+                self._call(L.eod_transpose_gather, ptr(xs.t), dt, xs.N, xs.H, xs.W, cs, ptr(xt) + (k * per + margin) * es, ld, Ho, Wo,
+                           stride, pad, gdy, gdx, int(bool(rec.upsample)), rp)
+            partial = bp.empty((S * taps * cout * ldp,), torch.float32)
+            if s1:
+                for kx in range(3):
+                    self._bop(lambda kx=kx: bp.gemm(dYt, xt, partial, cout, cs, Kper, ld, ld, ldp, c_f32=True, nb0=S, nb1=3,
+                                                    sa=(Kper, 0), sb=(Kper, Wo), sc=(taps * cout * ldp, 3 * cout * ldp),
+                                                    b_off=kx * per + margin - Wo, c_off=kx * cout * ldp))
+            else:
+                self._bop(lambda: bp.gemm(dYt, xt, partial, cout, cs, Kper, ld, ld, ldp, c_f32=True, nb0=S, nb1=taps,
+                                          sa=(Kper, 0), sb=(Kper, per), sc=(taps * cout * ldp, cout * ldp), b_off=margin))
+            self._call(L.eod_wgrad_reduce, ptr(partial), S, ks, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(dW))
+            ci0 += cs_real
+
+    def _conv_bwd(self, rec):
+        L, bp, dt, es = self.L, self.bprog, self.dt, self.es
+        dy = self._take_grad(rec.y)
+        if dy is None:
+            raise EodError("training: a conv output has no gradient (graph bug)")
+        N, Ho, Wo = dy.N, dy.H, dy.W
+        conv = rec.conv
+        cout = rec.cout_rows or conv.out_channels
+        ks, stride = rec.ksize, rec.stride
+        if Wo * es % 16:
+            raise EodError(f"training: map width {Wo} is not a multiple of {16 // es} (weight-gradient GEMM alignment)")
+        s1 = ks == 3 and stride == 1
+        rp = 1 if s1 else 0
+        K = N * (Ho + 2 * rp) * Wo
+        BK = 128 // es
+        steps = (K + BK - 1) // BK
+        cin_max = max(s.C for s in rec.srcs)
+        tiles = ((cout + 127) // 128) * ((cin_max + 127) // 128) * ks * ks
+        S = max(1, min(steps, (768 + tiles - 1) // tiles))
+        per_steps = (steps + S - 1) // S
+        S = (steps + per_steps - 1) // per_steps
+        Kper = per_steps * BK
+        ld = S * Kper
+        dYt = bp.empty((dy.C * ld + 16,))
+        self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, rp)
+        if conv.bias is not None:
+            self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, 1, ld, self.inv_scale, ptr(self._param_grad(conv.bias)), cout)
+        if rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
+            off = rec.emb[2]
+            self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wo, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
+        self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout)
+        if rec.res is not None:
+            self._add_grad(rec.res, dy)
+        if not rec.src_needs_grad:
+            return
+        ci0 = 0
+        cin_total = conv.weight.shape[1]
+        for xs in rec.srcs:
+            cs = xs.C
+            wd = bp.empty((ks * ks, cs, dy.C))
+            pack = (lambda wd=wd, ci0=ci0, cs=cs: check(L.eod_pack_conv_weight_dgrad(
+                ptr(conv.weight.detach()), ptr(wd), dt, conv.out_channels, cin_total, ks, ci0, cs, dy.C, current_stream_ptr(self.device)),
+                "pack_conv_weight_dgrad"))
+            pack()
+            self.repack.append(pack)
+            prev = None if rec.upsample else self._pop_single(xs)
+            g, _ = self._bop(lambda: bp.conv(dy, wd, None, cs, ksize=ks, stride=1, pad=ks // 2, upsample=(2 if stride == 2 else False),
+                                             res=prev))
+            if rec.upsample:
+                g = self._bop(lambda: bp.resample2x(g, 2))
+            if (g.H, g.W) != (xs.H, xs.W):
+                raise EodError(f"training: backward-data shape {g.H}x{g.W} != input {xs.H}x{xs.W}")
+            self._add_grad(xs, g)
+            ci0 += cs
+
+    def _gn_bwd(self, rec):
+        L, bp, dt = self.L, self.bprog, self.dt
+        dy = self._take_grad(rec.y)
+        if dy is None:
+            raise EodError("training: a GroupNorm output has no gradient (graph bug)")
+        gn = rec.gn
+        N, HW, ctot = dy.N, dy.H * dy.W, dy.C
+        groups = 32
+        parts = rec.parts
+        p1 = parts[1] if len(parts) == 2 else (None, 0, 0)
+        mr = bp.empty((N, groups, 2), torch.float32)
+        self._call(L.eod_gn_mean_rstd, ptr(parts[0][0]), parts[0][1], parts[0][2], ptr(p1[0]), p1[1], p1[2], N, HW, groups, gn.eps, ptr(mr))
+        P = max(1, min(256, HW // 64))
+        part = bp.empty((N, P, ctot, 2), torch.float32)
+        coef = bp.empty((N, ctot, 3), torch.float32)
+        gb = bp.empty((N, ctot, 2), torch.float32)
+        coff = 0
+        for s in rec.srcs:
+            self._call(L.eod_gn_bwd_partial, ptr(s.t), ptr(dy.t), ptr(rec.ss), dt, N, HW, s.C, ptr(part), P, ctot, coff, int(rec.silu))
+            coff += s.C
+        self._call(L.eod_gn_bwd_finalize, ptr(part), P, ctot, N, HW, groups, ptr(mr), ptr(self.prog.f32(gn.weight)), ptr(coef), ptr(gb))
+        self._call(L.eod_gn_bwd_params, ptr(gb), N, ctot, self.inv_scale, ptr(self._param_grad(gn.weight)), ptr(self._param_grad(gn.bias)))
+        coff = 0
+        for s in rec.srcs:
+            dx = bp.act(s.N, s.H, s.W, s.C)
+            prev = self._pop_single(s)
+            self._call(L.eod_gn_bwd_apply, ptr(s.t), ptr(dy.t), ptr(rec.ss), ptr(coef), ptr(prev.t) if prev is not None else 0, dt,
+                       N, HW, s.C, ctot, coff, int(rec.silu), ptr(dx.t))
+            self._add_grad(s, dx)
+            coff += s.C
+
+    def _temb_bwd(self):
+        L, bp, N, E, D, J = self.L, self.bprog, self.N, self.E, self.D, self.ctx.J
+        te1, te2 = self.unet.time_embed[0], self.unet.time_embed[2]
+        inv = self.inv_scale
+        self.dwcat = bp.empty((J, E), torch.float32)
+        self.dbcat = bp.empty((J,), torch.float32)
+        demb = bp.empty((N, E), torch.float32)
+        dpre1 = bp.empty((N, E), torch.float32)
+        pre1 = bp.empty((N, E), torch.float32)
+        self._t_slot = torch.zeros((N,), dtype=torch.int64, device=self.device)
+        tp = self._t_slot.data_ptr()
+        # emb_layers of every ResBlock (concatenated): out = Linear(SiLU(emb))
+        self._call(L.eod_linear_bwd_small, ptr(self.dout_cat), J, ptr(self.emb), 0, 0, ptr(self.wcat), ptr(self.emb), N, E, J, 1, inv,
+                   ptr(self.dwcat), ptr(self.dbcat), ptr(demb))
+        # time_embed[2]: emb = W2 h1 + b2, h1 = SiLU(pre1)
+        self._call(L.eod_temb_pre1, tp, ptr(self.freqs), ptr(self.prog.f32(te1.weight)), ptr(self.prog.f32(te1.bias)), N, D, E, ptr(pre1))
+        self._call(L.eod_linear_bwd_small, ptr(demb), E, ptr(self.h1), 0, 0, ptr(self.prog.f32(te2.weight)), ptr(pre1), N, E, E, 0, inv,
+                   ptr(self._param_grad(te2.weight)), ptr(self._param_grad(te2.bias)), ptr(dpre1))
+        # time_embed[0]: pre1 = W1 sinusoid(t) + b1
+        self._call(L.eod_linear_bwd_small, ptr(dpre1), E, 0, tp, ptr(self.freqs), ptr(self.prog.f32(te1.weight)), 0, N, D, E, 2, inv,
+                   ptr(self._param_grad(te1.weight)), ptr(self._param_grad(te1.bias)), 0)
+        off = 0
+        for blk in self.ctx.blocks:  # the per-block projection gradients are row slices of the concatenated ones
+            lin = blk.emb_layers[1]
+            n = lin.out_features
+            self.pgrad[lin.weight] = self.dwcat[off:off + n]
+            self.pgrad[lin.bias] = self.dbcat[off:off + n]
+            off += n
+
+    # ------------------------------------------------------------------ execution
+    def forward(self, x, timesteps, cond=None):
+        """x NCHW fp32 on the GPU, timesteps int64 [N] -> prediction NCHW fp32 (a buffer owned by the trainer)"""
+        for fn in self.repack:
+            fn()
+        self._x = x.contiguous().float()
+        self._t = timesteps.to(torch.int64).contiguous()
+        self._t_slot.copy_(self._t)
+        self.prog.ops[self.i_in].u.small.p[0] = self._x.data_ptr()
+        if cond is not None:
+            self._c = cond.contiguous().float()
+            self.prog.ops[self.i_in].u.small.p[1] = self._c.data_ptr()
+        self.prog.ops[self.i_t].u.temb.t = self._t_slot.data_ptr()
+        self.prog._arr = None
+        self.prog.run()
+        return self.pred
+
+    def backward(self, dpred):
+        """dpred = dLoss/dpred (NCHW fp32).  Fills `param.grad` (fp32) of every UNet parameter."""
+        st = current_stream_ptr(self.device)
+        torch.mul(dpred, self.loss_scale, out=self.dpred)
+        L = self.L
+        for item in self.bwd:
+            if item[0] == "op":
+                check(L.eod_program_run(C.byref(item[1]), 1, st), "backward op")
+            else:
+                check(item[1](*item[2], st), item[1].__name__)
+        for p, g in self.pgrad.items():
+            p.grad = g
+        for p in self.unet.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, dtype=torch.float32)
+        return None

@@ -59,7 +59,9 @@ typedef struct {
     int32_t ksize;       /* 1 or 3 */
     int32_t stride;      /* 1 or 2 */
     int32_t pad;         /* 0 or 1 */
-    int32_t upsample;    /* 1: A is the nearest-2x upsampling of x (H,W are the stored dims)     */
+    int32_t upsample;    /* 1: A is the nearest-2x upsampling of x (H,W are the stored dims);
+                            2: A is x with zeros inserted between the pixels (z[2i][2j] = x[i][j]): the input of the
+                            backward-data conv of a stride-2 conv (training path)                */
     int32_t pad_tl;      /* 1: extra zero row/col on top/left after upsampling (3x3 -> 7x7 hack,
                             unet_openai.py:237-239)                                              */
     int32_t Ho, Wo;      /* output spatial dims */
@@ -228,7 +230,8 @@ int eod_randn_philox(float* out, int N, int64_t chw, uint64_t seed, int64_t samp
 enum {
     EOD_OP_CONV = 1, EOD_OP_GEMM = 2, EOD_OP_GN_PARTIAL = 3, EOD_OP_GN_FINALIZE = 4,
     EOD_OP_GN_APPLY = 5, EOD_OP_SOFTMAX = 6, EOD_OP_TEMB = 7, EOD_OP_TO_NHWC = 8, EOD_OP_TO_NCHW = 9,
-    EOD_OP_POOL = 10, EOD_OP_ATTN = 11
+    EOD_OP_POOL = 10, EOD_OP_ATTN = 11,
+    EOD_OP_TRANSPOSE = 12 /* eod_transpose_gather (training forward: transposed q|k|v for the attention GEMMs) */
 };
 typedef struct {
     const void* p[6];
@@ -257,9 +260,53 @@ int eod_timer_read(void* timer, float* ms);
 /* bracket only the ops whose mask byte is non-zero (each event pair idles the stream for a few microseconds) */
 int eod_timer_set_mask(void* timer, const unsigned char* mask, int n_ops);
 int eod_program_run_timed(const eod_op* ops, int n_ops, void* stream, void* timer);
-/* resblock_updown helpers (unet_openai.py:320-325): mode 0 = 2x2 average pool, 1 = nearest 2x */
+/* resblock_updown helpers (unet_openai.py:320-325): mode 0 = 2x2 average pool, 1 = nearest 2x,
+ * 2 = 2x2 sum pool (backward of nearest 2x, training path) */
 int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y,
                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training path (train.py:109-124: forward, nn.MSELoss, loss.backward(), AdamW.step(), EMA update).
+ * The backward of every UNet block runs on the forward's MFMA kernels (see csrc/train.hip):
+ *   backward-data    = eod_conv2d_igemm(dY, eod_pack_conv_weight_dgrad(W))        (stride 2: upsample = 2)
+ *   backward-weights = eod_gemm_nt over the pixel axis on eod_transpose_gather'ed operands + eod_wgrad_reduce
+ * ------------------------------------------------------------------------------------------ */
+/* OIHW fp32 -> [taps-1-tap][ci - ci0][cout_pad]: packed weights of the conv dY -> dX[:, ci0:ci0+nci] */
+int eod_pack_conv_weight_dgrad(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int ksize, int ci0, int nci,
+                               int cout_pad, void* stream);
+/* NHWC [N][H][W][C] -> [C][ld_dst], column k = (n*(Ho+2*row_pad) + ho + row_pad)*Wo + wo holds
+ * src[n][ho*stride - pad + dy][wo*stride - pad + dx][c] (ups: of the nearest-2x image), zero outside / in pad rows */
+int eod_transpose_gather(const void* src, int dtype, int N, int H, int W, int C, void* dst, int64_t ld_dst, int Ho, int Wo,
+                         int stride, int pad, int dy, int dx, int ups, int row_pad, void* stream);
+/* seg[s][c] = scale * sum of x[c][s*seg_len .. (s+1)*seg_len)   (bias / timestep-embedding gradients) */
+int eod_rowsum_segments(const void* x, int dtype, int C, int64_t ld, int nseg, int64_t seg_len, float scale, float* seg,
+                        int64_t seg_ld, void* stream);
+int eod_colsum(const float* seg, int S, int C, float* out, void* stream); /* out[c] = sum_s seg[s][c] */
+/* dW_oihw[co][ci0+ci][tap] = scale * sum_s partial[s][tap][co][ci]  (partial: fp32 [S][taps][Cout][ldp]) */
+int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout, int nci, int ldp, int ci0, int Cin, float scale,
+                     float* dw_oihw, void* stream);
+/* GroupNorm32 (+SiLU) backward (unet_openai.py:11-13,312-316): see csrc/train.hip for the algebra */
+int eod_gn_mean_rstd(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW, int groups,
+                     float eps, float* mean_rstd, void* stream);
+int eod_gn_bwd_partial(const void* x, const void* dy, const float* scale_shift, int dtype, int N, int HW, int C, float* part,
+                       int P, int Ctot, int coff, int silu, void* stream);
+int eod_gn_bwd_finalize(const float* part, int P, int Ctot, int N, int64_t HW, int groups, const float* mean_rstd,
+                        const float* gamma, float* coef, float* gb, void* stream);
+int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, float* dgamma, float* dbeta, void* stream);
+int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype,
+                     int N, int HW, int C, int Ctot, int coff, int silu, void* dx, void* stream);
+int eod_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
+/* softmax backward on rows (QKVAttention, unet_openai.py:479): dS[r][j] = P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]),
+ * P / dS storage dtype with row stride ldp, dP fp32 with row stride lds; columns n..ldp-1 of dS are written as zeros */
+int eod_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lds, void* dS, int dtype, int64_t rows, int n,
+                         void* stream);
+/* dense layers of the timestep-embedding MLP (unet_openai.py:597-602,329-335), fp32: dW, db (scaled) and / or din;
+ * act_in: the layer's input is 0 = in, 1 = SiLU(in), 2 = sinusoid(t); pre != NULL multiplies din by SiLU'(pre) */
+int eod_linear_bwd_small(const float* dout, int64_t ld_dout, const float* in, const int64_t* t, const float* freqs, const float* w,
+                         const float* pre, int N, int K, int J, int act_in, float scale, float* dW, float* db, float* din,
+                         void* stream);
+int eod_temb_pre1(const int64_t* t, const float* freqs, const float* w1, const float* b1, int N, int D, int E, float* pre1,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,98 @@
+"""GPU parity of the training step: UNet forward + backward on the HIP path vs torch
+autograd through the CPU oracle (oracle/unet_ref.py restates unet_openai.py; loss = nn.MSELoss(pred, noise),
+train.py:86,116-118).  fp32 mode: exact-fp32 MFMA, tight tolerance; fp16 mode: fp16 storage with loss scaling."""
+import pytest
+import torch
+
+from tests.gpu_util import DEV
+from tests.helpers import rel_l2
+from tests.synth import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+# gradient tolerances (rel-L2 per parameter tensor, vs fp32 autograd on the CPU)
+GTOL = {"fp32": 2e-4, "fp16": 4e-2}
+
+
+def _setup(prec, size, base, mults, nrb, N, in_ch=3):
+    import eo_diffusion_amd.backbones.unet_openai as U
+    m = U.UNetModel(size, in_channels=in_ch, model_channels=base, out_channels=3, num_res_blocks=nrb, attention_resolutions=[],
+                    channel_mult=mults, num_heads=1)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth_state_dict(shapes, 11)
+    m.load_state_dict(sd)
+    m = m.set_precision(prec).to(DEV).train()
+    cfg = dict(model_channels=base, num_res_blocks=nrb, channel_mult=mults, attention_resolutions=(), num_heads=1)
+    x = synth_input("trx", (N, in_ch, size, size), 3)
+    noise = synth_input("trn", (N, 3, size, size), 4)
+    t = torch.tensor([7, 650, 999, 0][:N])
+    return m, sd, cfg, x, noise, t
+
+
+def _oracle_grads(sd, cfg, x, noise, t):
+    from oracle import unet_ref as UR
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred = UR.unet_forward(sdg, cfg, x, t)
+    loss = torch.nn.functional.mse_loss(pred, noise)
+    loss.backward()
+    return pred.detach(), {k: v.grad for k, v in sdg.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("arch", [(16, 32, (1, 2), 1, 2), (32, 32, (1, 2, 2), 1, 3), (16, 64, (1, 2), 2, 2)])
+def test_unet_training_step_gradients(prec, arch):
+    from eo_diffusion_amd.training import UNetTrainer
+    size, base, mults, nrb, N = arch
+    m, sd, cfg, x, noise, t = _setup(prec, size, base, mults, nrb, N)
+    pred_ref, gref = _oracle_grads(sd, cfg, x, noise, t)
+    tr = UNetTrainer(m, N, size, size, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
+    pred = tr.forward(x.to(DEV), t.to(DEV))
+    assert rel_l2(pred.cpu(), pred_ref) < (2e-5 if prec == "fp32" else 1e-2)
+    dpred = 2.0 * (pred - noise.to(DEV)) / pred.numel()  # d MSELoss(mean) / d pred
+    tr.backward(dpred)
+    torch.cuda.synchronize()
+    worst = ("", 0.0)
+    n_checked = 0
+    gmax = max(float(v.norm()) for v in gref.values())
+    for name, p in m.named_parameters():
+        if name not in gref:
+            continue
+        g = p.grad
+        assert g is not None and g.dtype == torch.float32 and g.shape == p.shape, name
+        if float(gref[name].norm()) < 1e-5 * gmax:  # mathematically-zero gradients (a bias absorbed by the next GroupNorm): round-off only
+            assert float(g.norm()) < 1e-3 * gmax, name
+            continue
+        e = rel_l2(g.cpu(), gref[name])
+        n_checked += 1
+        if e > worst[1]:
+            worst = (name, e)
+    assert n_checked > 20
+    assert worst[1] < GTOL[prec], f"worst gradient: {worst}"
+
+
+def test_training_step_with_torch_adamw_reduces_loss():
+    """the reference loop (train.py:109-124) with torch.optim.AdamW on the HIP-computed gradients: the loss on a fixed
+    batch goes down, and the trainer picks up the updated parameters (weights are re-packed every forward)"""
+    from eo_diffusion_amd.training import UNetTrainer
+    m, sd, cfg, x, noise, t = _setup("fp32", 16, 32, (1, 2), 1, 2)
+    tr = UNetTrainer(m, 2, 16, 16, DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3)
+    xg, ng, tg = x.to(DEV), noise.to(DEV), t.to(DEV)
+    losses = []
+    for _ in range(6):
+        pred = tr.forward(xg, tg)
+        losses.append(float(torch.nn.functional.mse_loss(pred, ng)))
+        tr.backward(2.0 * (pred - ng) / pred.numel())
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_training_rejects_unbuilt_variants():
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from eo_diffusion_amd._lib import EodError
+    from eo_diffusion_amd.training import UNetTrainer
+    m = U.UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[2],
+                    channel_mult=(1, 2), num_heads=2).to(DEV)
+    with pytest.raises(EodError):
+        UNetTrainer(m, 2, 16, 16, DEV)
