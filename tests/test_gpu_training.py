@@ -14,15 +14,15 @@ pytestmark = pytest.mark.gpu
 GTOL = {"fp32": 2e-4, "fp16": 4e-2}
 
 
-def _setup(prec, size, base, mults, nrb, N, in_ch=3):
+def _setup(prec, size, base, mults, nrb, N, in_ch=3, attn=(), heads=1):
     import eo_diffusion_amd.backbones.unet_openai as U
-    m = U.UNetModel(size, in_channels=in_ch, model_channels=base, out_channels=3, num_res_blocks=nrb, attention_resolutions=[],
-                    channel_mult=mults, num_heads=1)
+    m = U.UNetModel(size, in_channels=in_ch, model_channels=base, out_channels=3, num_res_blocks=nrb, attention_resolutions=list(attn),
+                    channel_mult=mults, num_heads=heads)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = synth_state_dict(shapes, 11)
     m.load_state_dict(sd)
     m = m.set_precision(prec).to(DEV).train()
-    cfg = dict(model_channels=base, num_res_blocks=nrb, channel_mult=mults, attention_resolutions=(), num_heads=1)
+    cfg = dict(model_channels=base, num_res_blocks=nrb, channel_mult=mults, attention_resolutions=tuple(attn), num_heads=heads)
     x = synth_input("trx", (N, in_ch, size, size), 3)
     noise = synth_input("trn", (N, 3, size, size), 4)
     t = torch.tensor([7, 650, 999, 0][:N])
@@ -39,11 +39,12 @@ def _oracle_grads(sd, cfg, x, noise, t):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-@pytest.mark.parametrize("arch", [(16, 32, (1, 2), 1, 2), (32, 32, (1, 2, 2), 1, 3), (16, 64, (1, 2), 2, 2)])
+@pytest.mark.parametrize("arch", [(16, 32, (1, 2), 1, 2, (), 1), (32, 32, (1, 2, 2), 1, 3, (), 1), (16, 64, (1, 2), 2, 2, (), 1),
+                                  (16, 32, (1, 2), 1, 2, (1, 2), 2)])  # last: attention at both levels, 2 heads (d = 16 / 32)
 def test_unet_training_step_gradients(prec, arch):
     from eo_diffusion_amd.training import UNetTrainer
-    size, base, mults, nrb, N = arch
-    m, sd, cfg, x, noise, t = _setup(prec, size, base, mults, nrb, N)
+    size, base, mults, nrb, N, attn, heads = arch
+    m, sd, cfg, x, noise, t = _setup(prec, size, base, mults, nrb, N, attn=attn, heads=heads)
     pred_ref, gref = _oracle_grads(sd, cfg, x, noise, t)
     tr = UNetTrainer(m, N, size, size, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
     pred = tr.forward(x.to(DEV), t.to(DEV))
@@ -92,7 +93,11 @@ def test_training_rejects_unbuilt_variants():
     import eo_diffusion_amd.backbones.unet_openai as U
     from eo_diffusion_amd._lib import EodError
     from eo_diffusion_amd.training import UNetTrainer
-    m = U.UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[2],
-                    channel_mult=(1, 2), num_heads=2).to(DEV)
+    m = U.UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
+                    channel_mult=(1, 2), num_heads=2, use_scale_shift_norm=True).to(DEV)
     with pytest.raises(EodError):
         UNetTrainer(m, 2, 16, 16, DEV)
+    m = U.UNetModel(28, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
+                    channel_mult=(2, 4)).to(DEV)  # 28 -> 14 -> 7: odd maps are not built yet
+    with pytest.raises(EodError):
+        UNetTrainer(m, 2, 28, 28, DEV)
