@@ -64,20 +64,28 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const T* __restri
                                                                int Ho, int Wo, int stride, int pad, int dy, int dx, int ups, int rp,
                                                                long long K, long long ld_dst) {
     // (columns K .. ld_dst-1 of every row are written as zeros: the K-split GEMM reads whole K-steps)
-    __shared__ T tile[64][66];
+    constexpr int EPC = dt<T>::epc;          // elements per 16-byte chunk
+    constexpr int TPR = 64 / EPC;            // threads per pixel row of the tile (64 channels)
+    constexpr int PPP = 256 / TPR;           // pixels per load pass
+    constexpr int LDT = 64 + EPC;            // tile row stride (elements): rows stay 16-byte aligned
+    __shared__ __attribute__((aligned(16))) T tile[64 * LDT];
     const long long k0 = (long long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+    const int tid = threadIdx.x;
     const int Hp = Ho + 2 * rp;
     const int Heff = ups ? 2 * H : H, Weff = ups ? 2 * W : W;
-    // load: pixel k0 + r (r = ty, ty+4, ...), channel c0 + tx
-    for (int r = ty; r < 64; r += 4) {
+    // load: 16 bytes (EPC channels) per thread
+    const int q = tid % TPR;
+#pragma unroll
+    for (int ps = 0; ps < 64 / PPP; ++ps) {
+        const int r = ps * PPP + tid / TPR;
         const long long k = k0 + r;
-        T v = (T)0.0f;
-        if (k < K && c0 + tx < C) {
+        i32x4 v = {0, 0, 0, 0};
+        const int c = c0 + q * EPC;
+        if (k < K && c < C) {
             const int wo = (int)(k % Wo);
-            const long long q = k / Wo;
-            const int hp = (int)(q % Hp), n = (int)(q / Hp);
+            const long long qq = k / Wo;
+            const int hp = (int)(qq % Hp), n = (int)(qq / Hp);
             const int ho = hp - rp;
             int hi = ho * stride - pad + dy, wi = wo * stride - pad + dx;
             if (ho >= 0 && ho < Ho && (unsigned)hi < (unsigned)Heff && (unsigned)wi < (unsigned)Weff) {
@@ -85,16 +93,22 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const T* __restri
                     hi >>= 1;
                     wi >>= 1;
                 }
-                v = src[(((long long)n * H + hi) * W + wi) * C + c0 + tx];
+                v = *reinterpret_cast<const i32x4*>(src + (((long long)n * H + hi) * W + wi) * C + c);  // C % EPC == 0
             }
         }
-        tile[r][tx] = v;
+        *reinterpret_cast<i32x4*>(&tile[r * LDT + q * EPC]) = v;
     }
     __syncthreads();
-    // store: channel c0 + r, pixel k0 + tx
-    for (int r = ty; r < 64; r += 4) {
-        const long long k = k0 + tx;
-        if (c0 + r < C && k < ld_dst) dst[(long long)(c0 + r) * ld_dst + k] = tile[tx][r];
+    // store: EPC consecutive pixels (16 bytes) of one channel per thread; lanes of a wave = 64 consecutive channels
+    const int ch = tid & 63;
+#pragma unroll
+    for (int ps = 0; ps < 64 / (4 * EPC); ++ps) {
+        const int px0 = (ps * 4 + (tid >> 6)) * EPC;
+        T o[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = tile[(px0 + e) * LDT + ch];
+        const long long k = k0 + px0;
+        if (c0 + ch < C && k < ld_dst) *reinterpret_cast<i32x4*>(dst + (long long)(c0 + ch) * ld_dst + k) = *reinterpret_cast<const i32x4*>(o);
     }
 }
 
@@ -105,6 +119,8 @@ extern "C" int eod_transpose_gather(const void* src, int dtype, int N, int H, in
     EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "transpose_gather: bad dtype %d", dtype);
     const long long K = (long long)N * (Ho + 2 * row_pad) * Wo;
     EOD_REQUIRE(ld_dst >= K, "transpose_gather: ld_dst %lld < K %lld", (long long)ld_dst, K);
+    EOD_REQUIRE(C % (16 / eod_esize(dtype)) == 0 && ld_dst % (16 / eod_esize(dtype)) == 0 && eod_aligned16(src) && eod_aligned16(dst),
+                "transpose_gather: C and ld_dst must be multiples of one 16-byte chunk, pointers 16-byte aligned");
     const long long kb = (ld_dst + 63) / 64;
     EOD_REQUIRE(kb <= 0x7fffffffLL && (C + 63) / 64 <= 65535, "transpose_gather: grid too large");
     dim3 grid((unsigned)kb, (unsigned)((C + 63) / 64));

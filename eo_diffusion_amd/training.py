@@ -400,8 +400,12 @@ class UNetTrainer:
         ld = S * Kper
         dYt = bp.empty((dy.C * ld + 16,))
         self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, rp)
-        if conv.bias is not None:
-            self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, 1, ld, self.inv_scale, ptr(self._param_grad(conv.bias)), cout)
+        if conv.bias is not None:  # bias gradient = row sums of dYt, in two levels (enough blocks to fill the chip)
+            units = ld // BK
+            nseg = max(dv for dv in range(1, min(units, 128) + 1) if units % dv == 0)
+            tmp = bp.empty((nseg, cout), torch.float32)
+            self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, nseg, ld // nseg, self.inv_scale, ptr(tmp), cout)
+            self._call(L.eod_colsum, ptr(tmp), nseg, cout, ptr(self._param_grad(conv.bias)))
         if rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
             off = rec.emb[2]
             self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wo, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
