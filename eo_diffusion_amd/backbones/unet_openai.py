@@ -548,6 +548,7 @@ class UNetModel(_Emitter):
     def __getstate__(self):
         st = dict(self.__dict__)
         st.pop("_eod_cache", None)
+        st.pop("_eod_trainers", None)
         return st
 
     def enable_graph(self, on=True):
@@ -652,8 +653,9 @@ class UNetModel(_Emitter):
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
         if th.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "UNetModel backward (training) kernels are not built yet; run under torch.no_grad() / sampling.")
+            # training (train.py:116-118): forward that keeps the activations + HIP backward behind torch.autograd
+            from ..training import unet_train_forward
+            return unet_train_forward(self, x, timesteps, cond, y)
         N, cx, H, W = x.shape
         ccond = 0
         if cond is not None:

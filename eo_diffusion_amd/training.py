@@ -495,8 +495,11 @@ class UNetTrainer:
             off += n
 
     # ------------------------------------------------------------------ execution
+    step_id = 0
+
     def forward(self, x, timesteps, cond=None):
         """x NCHW fp32 on the GPU, timesteps int64 [N] -> prediction NCHW fp32 (a buffer owned by the trainer)"""
+        self.step_id += 1
         for fn in self.repack:
             fn()
         self._x = x.contiguous().float()
@@ -511,8 +514,9 @@ class UNetTrainer:
         self.prog.run()
         return self.pred
 
-    def backward(self, dpred):
-        """dpred = dLoss/dpred (NCHW fp32).  Fills `param.grad` (fp32) of every UNet parameter."""
+    def backward(self, dpred, assign=True):
+        """dpred = dLoss/dpred (NCHW fp32).  assign=True: sets `param.grad` (fp32) of every UNet parameter;
+        assign=False: returns the gradients in `unet.parameters()` order (clones, for torch.autograd accumulation)."""
         st = current_stream_ptr(self.device)
         torch.mul(dpred, self.loss_scale, out=self.dpred)
         L = self.L
@@ -521,9 +525,49 @@ class UNetTrainer:
                 check(L.eod_program_run(C.byref(item[1]), 1, st), "backward op")
             else:
                 check(item[1](*item[2], st), item[1].__name__)
+        if not assign:
+            return [self.pgrad[p].to(p.dtype).clone() if p in self.pgrad else torch.zeros_like(p) for p in self.unet.parameters()]
         for p, g in self.pgrad.items():
             p.grad = g
         for p in self.unet.parameters():
             if p.grad is None:
                 p.grad = torch.zeros_like(p, dtype=torch.float32)
         return None
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """autograd bridge: the UNet parameters are inputs of the node, so `loss.backward()` accumulates the HIP-computed
+    gradients into `param.grad` exactly like the reference's autograd graph does (train.py:118)."""
+
+    @staticmethod
+    def forward(ctx, trainer, x, timesteps, cond, *params):
+        ctx.trainer = trainer
+        ctx.n_params = len(params)
+        pred = trainer.forward(x, timesteps, cond)
+        ctx.step_id = trainer.step_id
+        return pred.clone()  # the trainer's own buffer is overwritten by the next forward
+
+    @staticmethod
+    def backward(ctx, dpred):
+        tr = ctx.trainer
+        if ctx.step_id != tr.step_id:
+            raise EodError("training: backward called after another forward of the same shape (saved activations were overwritten)")
+        grads = tr.backward(dpred.contiguous().float(), assign=False)
+        return (None, None, None, None) + tuple(grads)
+
+
+def unet_train_forward(unet, x, timesteps, cond=None, y=None):
+    """UNetModel.forward in training mode (called when autograd is enabled and parameters require grad)."""
+    if y is not None or unet.num_classes is not None:
+        raise EodError("training: class conditioning is not built yet")
+    N, cx, H, W = x.shape
+    ccond = 0 if cond is None else cond.shape[1]
+    cache = unet.__dict__.setdefault("_eod_trainers", {})
+    key = (N, cx, ccond, H, W, str(x.device), unet.precision)
+    tr = cache.get(key)
+    if tr is None:
+        import os
+        scale = float(os.environ.get("EOD_LOSS_SCALE", "1024" if unet.precision == "fp16" else "1"))
+        tr = cache[key] = UNetTrainer(unet, N, H, W, x.device, cond_channels=ccond, loss_scale=scale)
+    params = [p for p in unet.parameters()]
+    return _UNetTrainFn.apply(tr, x.detach(), timesteps, None if cond is None else cond.detach(), *params)
