@@ -13,7 +13,7 @@ EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
  OP_POOL, OP_ATTN, OP_TRANSPOSE) = range(1, 13)
 
-vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
 
 class ConvDesc(C.Structure):
@@ -78,8 +78,11 @@ SYMBOLS = {
     "eod_gn_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "eod_add": (i32, [vp, vp, vp, i32, i64, vp]),
     "eod_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i32, i64, i32, vp]),
-    "eod_linear_bwd_small": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "eod_linear_bwd_small": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "eod_temb_pre1": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "eod_mse_loss": (i32, [vp, vp, i64, vp, vp, vp, i32, vp]),
+    "eod_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),
+    "eod_ema_update": (i32, [vp, vp, i64, f64, vp]),
     "eod_pack_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "eod_nchw_to_nhwc": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "eod_nhwc_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -542,21 +542,33 @@ __global__ void linear_bwd_w_kernel(const float* __restrict__ dout, long long ld
     if (k == 0 && db) db[j] = b * scale;
 }
 
-// din[n][k] = sum_j dout[n][j] * w[j][k]; optionally multiplied by silu'(pre[n][k]) (the layer's input was SiLU(pre))
+// din[n][k] = sum_j dout[n][j] * w[j][k]; optionally multiplied by silu'(pre[n][k]) (the layer's input was SiLU(pre)).
+// J is split over gridDim.y (fixed-order partial sums in `din` itself when gridDim.y == 1, else in a scratch that the
+// caller provides: here the split results are combined by a second launch, linear_bwd_in_sum_kernel)
 __global__ void linear_bwd_in_kernel(const float* __restrict__ dout, long long ld_dout, const float* __restrict__ w, const float* __restrict__ pre,
-                                     int N, int K, int J, float* __restrict__ din) {
+                                     int N, int K, int J, int jper, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * K) return;
     const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+    const int j0 = blockIdx.y * jper, j1 = min(J, j0 + jper);
     float a = 0.0f;
-    for (int j = 0; j < J; ++j) a += dout[(long long)n * ld_dout + j] * w[(long long)j * K + k];
+    for (int j = j0; j < j1; ++j) a += dout[(long long)n * ld_dout + j] * w[(long long)j * K + k];
+    if (gridDim.y == 1 && pre) a *= dsilu_f<false>(pre[i]);
+    out[(long long)blockIdx.y * N * K + i] = a;
+}
+
+__global__ void linear_bwd_in_sum_kernel(const float* __restrict__ part, int S, const float* __restrict__ pre, long long NK, float* __restrict__ din) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NK) return;
+    float a = 0.0f;
+    for (int s = 0; s < S; ++s) a += part[(long long)s * NK + i];
     if (pre) a *= dsilu_f<false>(pre[i]);
     din[i] = a;
 }
 
 extern "C" int eod_linear_bwd_small(const float* dout, int64_t ld_dout, const float* in, const int64_t* t, const float* freqs,
                                     const float* w, const float* pre, int N, int K, int J, int act_in, float scale, float* dW, float* db,
-                                    float* din, void* stream) {
+                                    float* din, float* scratch, void* stream) {
     EOD_REQUIRE(dout && w && N > 0 && K > 0 && J > 0 && ld_dout >= J && act_in >= 0 && act_in <= 2, "linear_bwd_small: bad args");
     EOD_REQUIRE(act_in == 2 ? (t && freqs) : (in != nullptr || !dW), "linear_bwd_small: missing input");
     hipStream_t st = (hipStream_t)stream;
@@ -566,7 +578,12 @@ extern "C" int eod_linear_bwd_small(const float* dout, int64_t ld_dout, const fl
     }
     if (din) {
         const long long tot = (long long)N * K;
-        hipLaunchKernelGGL(linear_bwd_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dout, (long long)ld_dout, w, pre, N, K, J, din);
+        const int S = (scratch && J >= 512) ? 32 : 1;  // split the J loop when a scratch of 32*N*K floats is supplied
+        const int jper = (J + S - 1) / S;
+        hipLaunchKernelGGL(linear_bwd_in_kernel, dim3((unsigned)((tot + 255) / 256), S), dim3(256), 0, st, dout, (long long)ld_dout, w, pre, N, K, J, jper,
+                           S == 1 ? din : scratch);
+        if (S > 1)
+            hipLaunchKernelGGL(linear_bwd_in_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, scratch, S, pre, tot, din);
     }
     EOD_CHECK_LAUNCH("linear_bwd_small");
     return EOD_OK;
@@ -623,5 +640,92 @@ extern "C" int eod_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP,
     else
         hipLaunchKernelGGL(softmax_bwd_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)P, (long long)ldp, dP, (long long)lds, (float*)dS, (long long)rows, n);
     EOD_CHECK_LAUNCH("softmax_bwd_rows");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Optimizer side of the step (train.py:86,117-122): nn.MSELoss(reduction='mean') with its gradient, torch.optim.AdamW
+// (single-tensor algorithm of the pinned PyTorch 1.13: decoupled decay, bias corrections folded into step_size and
+// bc2_sqrt on the host), and the EMA of utils.py:56-67 (decay*avg + (1-decay)*param).  Plain fp32 elementwise kernels
+// over FLAT buffers (one launch for all parameters); this file is built with -ffp-contract=off so that they are
+// bit-exact against oracle/train_ref.py.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target, long long n,
+                                                          float grad_scale, float* __restrict__ dpred, float* __restrict__ part) {
+    __shared__ float red[256];
+    float a = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = pred[i] - target[i];
+        a += d * d;
+        if (dpred) dpred[i] = d * grad_scale;  // grad_scale = 2/n (mean reduction)
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ void mse_final_kernel(const float* __restrict__ part, int P, float inv_n, float* __restrict__ loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float a = 0.0f;
+        for (int i = 0; i < P; ++i) a += part[i];
+        loss[0] = a * inv_n;
+    }
+}
+
+extern "C" int eod_mse_loss(const float* pred, const float* target, int64_t n, float* loss, float* dpred, float* scratch, int scratch_len,
+                            void* stream) {
+    EOD_REQUIRE(pred && target && loss && scratch && n > 0 && scratch_len >= 1, "mse_loss: bad args");
+    int P = scratch_len < 1024 ? scratch_len : 1024;
+    if ((long long)P * 256 > n) P = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, pred, target, (long long)n, 2.0f / (float)n, dpred, scratch);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, P, 1.0f / (float)n, loss);
+    EOD_CHECK_LAUNCH("mse_loss");
+    return EOD_OK;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                             float decay_mul, float beta1, float one_m_beta1, float beta2, float one_m_beta2, float bc2_sqrt, float eps,
+                             float neg_step_size) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * decay_mul;                       // param.mul_(1 - lr * weight_decay)
+        const float mi = m[i] * beta1 + gi * one_m_beta1;  // exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1)
+        const float vi = v[i] * beta2 + (one_m_beta2 * gi) * gi;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;    // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+        pi = pi + neg_step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int eod_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, int step, void* stream) {
+    EOD_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad args");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = lr / bc1;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, (float)(1.0 - lr * weight_decay),
+                       (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-step_size));
+    EOD_CHECK_LAUNCH("adamw_step");
+    return EOD_OK;
+}
+
+__global__ void ema_kernel(float* __restrict__ avg, const float* __restrict__ p, long long n, float decay, float one_m_decay) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        avg[i] = decay * avg[i] + one_m_decay * p[i];
+}
+
+extern "C" int eod_ema_update(float* avg, const float* p, int64_t n, double decay, void* stream) {
+    EOD_REQUIRE(avg && p && n > 0, "ema_update: bad args");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, avg, p, (long long)n, (float)decay, (float)(1.0 - decay));
+    EOD_CHECK_LAUNCH("ema_update");
     return EOD_OK;
 }

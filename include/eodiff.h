@@ -304,9 +304,19 @@ int eod_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t ld
  * act_in: the layer's input is 0 = in, 1 = SiLU(in), 2 = sinusoid(t); pre != NULL multiplies din by SiLU'(pre) */
 int eod_linear_bwd_small(const float* dout, int64_t ld_dout, const float* in, const int64_t* t, const float* freqs, const float* w,
                          const float* pre, int N, int K, int J, int act_in, float scale, float* dW, float* db, float* din,
-                         void* stream);
+                         float* scratch /* optional, 32*N*K floats: splits the J loop of din */, void* stream);
 int eod_temb_pre1(const int64_t* t, const float* freqs, const float* w1, const float* b1, int N, int D, int E, float* pre1,
                   void* stream);
+/* nn.MSELoss(reduction='mean') (train.py:86,117): loss[0] = mean((pred-target)^2), dpred = 2*(pred-target)/n (optional);
+ * scratch: scratch_len (>= 1, up to 1024 used) floats of per-block partial sums (fixed-order two-level sum) */
+int eod_mse_loss(const float* pred, const float* target, int64_t n, float* loss, float* dpred, float* scratch, int scratch_len,
+                 void* stream);
+/* torch.optim.AdamW single-tensor step (train.py:75,119; algorithm of the pinned PyTorch 1.13, eo_diffusion.yml:114) on flat
+ * fp32 buffers; `step` is the 1-based update count */
+int eod_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int step, void* stream);
+/* EMA of script_utils/utils.py:56-67: avg = decay*avg + (1-decay)*p */
+int eod_ema_update(float* avg, const float* p, int64_t n, double decay, void* stream);
 
 #ifdef __cplusplus
 }

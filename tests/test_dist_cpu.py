@@ -54,3 +54,38 @@ def test_gloo_world2_gather_matches_single_rank(n_total):
     ref = philox_randn(n_total, 48, 11, 0, 5, 1).reshape(n_total, 3, 4, 4)  # what ONE rank would have produced
     for r in range(2):
         assert np.array_equal(res[r], ref)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eo_diffusion_amd.training import allreduce_mean_
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)  # rank-dependent "gradients" in one flat bucket
+        allreduce_mean_(flat)
+        q.put((rank, flat.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_bucket_is_averaged():
+    """data-parallel training (config 5): every rank ends with the MEAN of the ranks' flat gradient buckets"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = np.arange(1000, dtype=np.float32) * 1.5
+    for r in range(2):
+        assert np.array_equal(res[r], ref)
+
+
+def test_allreduce_mean_is_a_noop_without_a_process_group():
+    from eo_diffusion_amd.training import allreduce_mean_
+    t = torch.ones(8)
+    assert allreduce_mean_(t) is t and bool((t == 1).all())

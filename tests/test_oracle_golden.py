@@ -226,3 +226,37 @@ def test_philox_known_answer():
     assert [int(x[0]) for x in _philox(z, z, z, z, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
     f = np.full(1, 0xFFFFFFFF, np.uint32)
     assert [int(x[0]) for x in _philox(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# optimizer side of the training step (oracle/train_ref.py): pinned against the torch build of the container
+# ---------------------------------------------------------------------------------------------------------------
+def test_train_ref_adamw_vs_torch():
+    import numpy as np
+    from oracle import train_ref as TR
+    from tests.synth import synth_input
+    p0 = synth_input("adam_p", (257,), 1)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    pn, m, v = p0.numpy().copy(), np.zeros(257, np.float32), np.zeros(257, np.float32)
+    for step in range(1, 7):
+        g = synth_input(f"adam_g{step}", (257,), 2, scale=0.1)
+        p.grad = g.clone()
+        opt.step()
+        pn, m, v = TR.adamw_step(pn, g.numpy(), m, v, lr=3e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, step=step)
+        assert np.allclose(pn, p.detach().numpy(), rtol=2e-6, atol=1e-8), step
+
+
+def test_train_ref_mse_and_ema_vs_torch():
+    import numpy as np
+    from oracle import train_ref as TR
+    from tests.synth import synth_input
+    a, b = synth_input("mse_a", (2, 3, 8, 8), 1), synth_input("mse_b", (2, 3, 8, 8), 2)
+    ar = a.clone().requires_grad_(True)
+    loss = torch.nn.functional.mse_loss(ar, b)
+    loss.backward()
+    l, d = TR.mse_loss(a.numpy(), b.numpy())
+    assert abs(float(l) - float(loss)) < 1e-6 * float(loss)
+    assert np.allclose(d, ar.grad.numpy(), rtol=1e-6, atol=1e-10)
+    avg = TR.ema_update(a.numpy(), b.numpy(), 0.99)
+    assert np.allclose(avg, (0.99 * a + (1 - 0.99) * b).numpy(), rtol=1e-6, atol=1e-8)
