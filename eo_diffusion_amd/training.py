@@ -82,6 +82,7 @@ class UNetTrainer:
         self.repack = []     # closures refreshing packed weights from the (updated) parameters
         self.recs = []
         self._keep = []
+        self._scratch, self._scratch_all = {}, []
         self._alloc_flat_grad()
         self._build(cond_channels)
 
@@ -136,6 +137,18 @@ class UNetTrainer:
             self._call(self.L.eod_add, ptr(g.t), ptr(other.t), ptr(out.t), self.dt, g.t.numel())
             g = out
         return g
+
+    def _shared(self, key, numel, dtype=None, zero=False):
+        """scratch tensor shared by all launches that ask for `key`: everything runs in order on one stream, so
+        temporaries whose lifetime ends inside one block (attention scores, their gradients, ...) can alias.  A request that is
+        larger than what was handed out before gets a new buffer (pointers already captured stay valid)."""
+        dtype = dtype or self.prog.tdtype
+        cur = self._scratch.get((key, dtype))
+        if cur is None or cur.numel() < numel:
+            cur = (torch.zeros if zero else torch.empty)((numel,), dtype=dtype, device=self.device)
+            self._scratch[(key, dtype)] = cur
+            self._scratch_all.append(cur)
+        return cur[:numel]
 
     def _pack(self, fn, param):
         """packed weight buffer that is re-packed from `param` before every forward"""
@@ -232,7 +245,7 @@ class UNetTrainer:
         ldT = round_up(N * T, BK)
         qkvT = prog.empty((3 * Cc * ldT,), zero=True)
         self._transpose_op(prog, qkv.t, N, T, 3 * Cc, qkvT, ldT)
-        S = prog.empty((N * nh, T, T), torch.float32)
+        S = self._shared("attn_S", N * nh * T * T, torch.float32)  # only P is kept for the backward
         prog.gemm(qkv.t, qkv.t, S, T, T, d, 3 * Cc, 3 * Cc, T, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
                   sa=(T * 3 * Cc, 3 * d), sb=(T * 3 * Cc, 3 * d), sc=(nh * T * T, T * T), b_off=d)
         P = prog.empty((N * nh, T, T))
@@ -255,17 +268,17 @@ class UNetTrainer:
         alpha = 1.0 / math.sqrt(d)
         BK = 128 // es
         # dP[b][t][s] = sum_j da[n][t][h*d+j] * v[n][s][h][j]
-        dP = bp.empty((B, T, T), torch.float32)
+        dP = self._shared("attn_dP", B * T * T, torch.float32)
         self._bop(lambda: bp.gemm(da.t, qkv.t, dP, T, T, d, Cc, 3 * Cc, T, c_f32=True, nb0=N, nb1=nh, sa=(T * Cc, d),
                                   sb=(T * 3 * Cc, 3 * d), sc=(nh * T * T, T * T), b_off=2 * d))
-        dS = bp.empty((B, T, T))
+        dS = self._shared("attn_dS", B * T * T)
         self._call(L.eod_softmax_bwd_rows, ptr(P), T, ptr(dP), T, ptr(dS), dt, B * T, T)
         ldB = round_up(B * T, BK)
-        dST = bp.empty((T * ldB,), zero=True)   # [s][b*T + t]
-        PT = bp.empty((T * ldB,), zero=True)
+        dST = self._shared("attn_dST", T * ldB)   # [s][b*T + t]; the transposes write every column up to ldB
+        PT = self._shared("attn_PT", T * ldB)
         self._call(L.eod_transpose_gather, ptr(dS), dt, B, 1, T, T, ptr(dST), ldB, 1, T, 1, 0, 0, 0, 0, 0)
         self._call(L.eod_transpose_gather, ptr(P), dt, B, 1, T, T, ptr(PT), ldB, 1, T, 1, 0, 0, 0, 0, 0)
-        daT = bp.empty((Cc * ldT,), zero=True)  # [h*d + j][n*T + t]
+        daT = self._shared("attn_daT", Cc * ldT)  # [h*d + j][n*T + t]
         self._call(L.eod_transpose_gather, ptr(da.t), dt, N, 1, T, Cc, ptr(daT), ldT, 1, T, 1, 0, 0, 0, 0, 0)
         dqkv = bp.act(qkv.N, qkv.H, qkv.W, 3 * Cc)
         # dq[n][t][h][j] = alpha * sum_s dS[b][t][s] * k[n][s][h][j]      (k^T rows from qkvT)
