@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-timing", action="store_true")
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (JSON) here")
+    ap.add_argument("--train", action="store_true", help="time the TRAINING step (forward + MSE + backward + fused AdamW [+ gradient "
+                    "all-reduce for N > 1]) instead of the sampling step; SURVEY section 8f rank 1 / BASELINE config 5")
+    ap.add_argument("--in-ch", type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +140,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.train:
+        return train_main(args, world, rank, dev, use_dist)
     m = build_model(args.arch, args.size, args.precision, dev)
     if args.graph:
         m.model.enable_graph(True)
@@ -244,6 +249,63 @@ def main():
             res["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.arch, S, N)
+        print(json.dumps(res), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def train_main(args, world, rank, dev, use_dist):
+    """one training step per "step": q_sample -> UNet forward (activations kept) -> MSE -> backward -> [all-reduce] -> AdamW"""
+    import torch.distributed as dist
+    from eo_diffusion_amd.optim import AdamW, mse_loss
+    from eo_diffusion_amd.training import UNetTrainer
+    m = build_model(args.arch, args.size, args.precision, dev, in_ch=args.in_ch)
+    unet = m.model.train()
+    N, S, C = args.batch, args.size, args.in_ch
+    tr = UNetTrainer(unet, N, S, S, dev, loss_scale=(1024.0 if args.precision == "fp16" else 1.0))
+    opt = AdamW(unet.parameters(), lr=1e-4)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    x = torch.rand((N, C, S, S), device=dev, generator=g)
+    noise = torch.randn((N, C, S, S), device=dev, generator=g)
+    t = torch.randint(0, m.timesteps, (N,), device=dev, generator=g)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def one_step():
+        x_t = m._forward_diffusion(x, t, noise)
+        pred = tr.forward(x_t, t)
+        loss, dpred = mse_loss(pred, noise)
+        tr.backward(dpred)
+        tr.allreduce_grads()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        res = {"metric": f"training steps/sec (UNet fwd + MSE + bwd + AdamW) at {S}x{S} bs={N}", "value": world * args.steps / dt,
+               "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+               "config": {"workload": f"training step, {S}x{S}x{C}, batch {N} per GPU, UNet arch {args.arch}, MSE(eps) loss, fused AdamW, "
+                                      f"loss scale {tr.loss_scale:g}", "global_batch": world * N, "image_size": S,
+                          "parallelism": f"data-parallel x{world} (one flat-bucket gradient all-reduce per step)", "accumulate": "fp32"},
+               "images_per_sec": world * N * args.steps / dt, "loss": float(loss), "loss_finite": bool(torch.isfinite(loss).all()),
+               "hbm_gib": {"forward": tr.prog.nbytes / 2**30, "backward": tr.bprog.nbytes / 2**30}}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
