@@ -13,6 +13,7 @@ first / head conv, the timestep MLP.  Not yet: use_scale_shift_norm, resblock_up
 conditioning, dropout > 0, odd spatial sizes -- these raise EodError (never a silent fallback)."""
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -377,8 +378,11 @@ class UNetTrainer:
         self._temb_bwd()
         bp.finalize()
 
-    def _wgrad(self, rec, dy, dYt, ld, Kper, S, rp, cout):
-        """dW of one conv from the transposed output gradient dYt [rows][ld] (see csrc/train.hip)"""
+    def _wgrad(self, rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy=None):
+        """dW of one conv from the transposed output gradient dYt [rows][ld] (see csrc/train.hip).
+        shift_dy = (buffer, per, margin): 3x3 / stride-1 convs whose inputs are wider than their output shift the OUTPUT gradient
+        instead of the input (three dx-shifted copies of dY, ONE copy of every input source; the dy taps are the -+W offsets
+        of the dY copies)."""
         L, bp, dt, es = self.L, self.bprog, self.dt, self.es
         N, Ho, Wo = dy.N, dy.H, dy.W
         ks, stride = rec.ksize, rec.stride
@@ -392,14 +396,14 @@ class UNetTrainer:
             cs_real = min(cs, cin_total - ci0)
             ldp = round_up(cs, 4)
             s1 = ks == 3 and stride == 1
-            ncopy = 3 if s1 else taps
-            margin = round_up(Wo, 8) if s1 else 0
+            ncopy = (1 if shift_dy else 3) if s1 else taps
+            margin = round_up(Wo, 8) if (s1 and not shift_dy) else 0
             xt = bp.empty((ncopy * (cs * ld + 2 * margin),))
             xt.zero_()
             per = cs * ld + 2 * margin
             for k in range(ncopy):
                 if s1:
-                    gdy, gdx, pad = 1, k, 1
+                    gdy, gdx, pad = 1, (1 if shift_dy else k), 1
                 elif ks == 3:
                     gdy, gdx, pad = k // 3, k % 3, 1
                 else:
@@ -407,7 +411,13 @@ class UNetTrainer:
                 self._call(L.eod_transpose_gather, ptr(xs.t), dt, xs.N, xs.H, xs.W, cs, ptr(xt) + (k * per + margin) * es, ld, Ho, Wo,
                            stride, pad, gdy, gdx, int(bool(rec.upsample)), rp)
             partial = bp.empty((S * taps * cout * ldp,), torch.float32)
-            if s1:
+            if s1 and shift_dy:
+                ybuf, yper, ymargin = shift_dy
+                for kx in range(3):  # A = dY shifted by -(kx-1) pixels, read at -(ky-1)*W; B = the single copy of X
+                    self._bop(lambda kx=kx: bp.gemm(ybuf, xt, partial, cout, cs, Kper, ld, ld, ldp, c_f32=True, nb0=S, nb1=3,
+                                                    sa=(Kper, -Wo), sb=(Kper, 0), sc=(taps * cout * ldp, 3 * cout * ldp),
+                                                    a_off=kx * yper + ymargin + Wo, c_off=kx * cout * ldp))
+            elif s1:
                 for kx in range(3):
                     self._bop(lambda kx=kx: bp.gemm(dYt, xt, partial, cout, cs, Kper, ld, ld, ldp, c_f32=True, nb0=S, nb1=3,
                                                     sa=(Kper, 0), sb=(Kper, Wo), sc=(taps * cout * ldp, 3 * cout * ldp),
@@ -441,8 +451,20 @@ class UNetTrainer:
         S = (steps + per_steps - 1) // per_steps
         Kper = per_steps * BK
         ld = S * Kper
-        dYt = bp.empty((dy.C * ld + 16,))
-        self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, rp)
+        shift_dy = None
+        if s1 and dy.C < sum(x.C for x in rec.srcs) and os.environ.get("EOD_WGRAD_SHIFT", "auto") != "x":
+            # inputs wider than the output: three dx-shifted copies of dY (pad rows, +-W margins) instead of three of each input
+            ymargin = round_up(Wo, 8)
+            yper = dy.C * ld + 2 * ymargin
+            ybuf = bp.empty((3 * yper,), zero=True)
+            for kx in range(3):  # dYs_kx[co][(n, hp, w)] = dY[n][hp-1][w - (kx-1)]
+                self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(ybuf) + (kx * yper + ymargin) * es, ld, Ho, Wo,
+                           1, 1, 1, 2 - kx, 0, rp)
+            shift_dy = (ybuf, yper, ymargin)
+            dYt = ybuf[yper + ymargin:]  # the un-shifted copy (kx = 1) doubles as the plain transpose for the row sums
+        else:
+            dYt = bp.empty((dy.C * ld + 16,))
+            self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, rp)
         if conv.bias is not None:  # bias gradient = row sums of dYt, in two levels (enough blocks to fill the chip)
             units = ld // BK
             nseg = max(dv for dv in range(1, min(units, 128) + 1) if units % dv == 0)
@@ -452,7 +474,7 @@ class UNetTrainer:
         if rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
             off = rec.emb[2]
             self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wo, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
-        self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout)
+        self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy)
         if rec.res is not None:
             self._add_grad(rec.res, dy)
         if not rec.src_needs_grad:
