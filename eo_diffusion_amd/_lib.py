@@ -73,13 +73,14 @@ SYMBOLS = {
     "eod_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "eod_gn_mean_rstd": (i32, [vp, i32, i32, vp, i32, i32, i32, i64, i32, f32, vp, vp]),
     "eod_gn_bwd_partial": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
-    "eod_gn_bwd_finalize": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp, vp]),
+    "eod_gn_bwd_finalize": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
     "eod_gn_bwd_params": (i32, [vp, i32, i32, f32, vp, vp, vp]),
     "eod_gn_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "eod_add": (i32, [vp, vp, vp, i32, i64, vp]),
     "eod_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i32, i64, i32, vp]),
     "eod_linear_bwd_small": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "eod_temb_pre1": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "eod_embedding_bwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
     "eod_mse_loss": (i32, [vp, vp, i64, vp, vp, vp, i32, vp]),
     "eod_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),
     "eod_ema_update": (i32, [vp, vp, i64, f64, vp]),

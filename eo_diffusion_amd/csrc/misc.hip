@@ -155,11 +155,11 @@ extern "C" int eod_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, i
 
 // ---------------------------------------------------------------------------------------------
 // 2x resampling on NHWC (resblock_updown, unet_openai.py:320-325): mode 0 avg-pool 2x2, 1 nearest 2x,
-// 2 = 2x2 SUM pool (backward of nearest 2x)
+// 2 = 2x2 SUM pool (backward of nearest 2x), 3 = nearest 2x times 0.25 (backward of the average pool)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int mode, int pad_tl) {
-    const bool up = mode == 1;
+    const bool up = mode == 1 || mode == 3;
     const int Ho = up ? 2 * H + pad_tl : H / 2, Wo = up ? 2 * W + pad_tl : W / 2;
     const long long total = (long long)N * Ho * Wo * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -173,6 +173,7 @@ __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
         if (up) {
             const int hi = ho - pad_tl, wi = wo - pad_tl;
             v = (hi >= 0 && wi >= 0) ? (float)x[((n * H + (hi >> 1)) * W + (wi >> 1)) * C + c] : 0.0f;
+            if (mode == 3) v *= 0.25f;
         } else {
             const T* b = x + ((n * H + 2 * ho) * W + 2 * wo) * C + c;
             // same summation order as ATen's avg_pool2d (row-major window), then * 0.25
@@ -184,9 +185,10 @@ __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
 
 extern "C" int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y, void* stream) {
     EOD_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "resample2x: bad args");
-    EOD_REQUIRE(mode >= 0 && mode <= 2, "resample2x: mode %d", mode);
-    EOD_REQUIRE(mode == 1 || (H >= 2 && W >= 2), "resample2x: avg-pool needs at least 2x2 (%dx%d)", H, W);  // odd dims: floor, like ATen
-    const long long total = (long long)N * (mode == 1 ? 2 * H + pad_tl : H / 2) * (mode == 1 ? 2 * W + pad_tl : W / 2) * C;
+    EOD_REQUIRE(mode >= 0 && mode <= 3, "resample2x: mode %d", mode);
+    const bool up = mode == 1 || mode == 3;
+    EOD_REQUIRE(up || (H >= 2 && W >= 2), "resample2x: avg-pool needs at least 2x2 (%dx%d)", H, W);  // odd dims: floor, like ATen
+    const long long total = (long long)N * (up ? 2 * H + pad_tl : H / 2) * (up ? 2 * W + pad_tl : W / 2) * C;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     if (dtype == EOD_F16)
         hipLaunchKernelGGL(resample2x_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, N, H, W, C, mode, pad_tl);

@@ -356,8 +356,11 @@ extern "C" int eod_gn_bwd_partial(const void* x, const void* dy, const float* sc
 //   k1_c = rstd*gamma_c,  k2 = -rstd^2*S2/m,  k3 = -rstd*S1/m + mean*rstd^2*S2/m        -> coef[n][c][0..2]
 // and the per-image parameter-gradient terms  gb[n][c] = (rstd*(B_c - mean*A_c), A_c)  (dgamma, dbeta = sum over n).
 __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int P, int Ctot, long long HW, int groups,
-                                       const float* __restrict__ mr, const float* __restrict__ gamma, float* __restrict__ coef,
-                                       float* __restrict__ gb) {
+                                       const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ film, long long film_stride, float* __restrict__ dfilm,
+                                       long long dfilm_stride, float* __restrict__ coef, float* __restrict__ gb) {
+    // FiLM (use_scale_shift_norm, unet_openai.py:377-381): y = z*(1+s) + t with z = xh*gamma + beta and film[n] = [s | t]:
+    // the GroupNorm sees the effective gamma_c*(1+s[n][c]); ds = sum dy*z = gamma*Bh + beta*A, dt = A  -> dfilm[n] = [ds | dt]
     __shared__ double r1[256], r2[256];
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cpg = Ctot / groups, c0 = g * cpg;
@@ -370,11 +373,17 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int P, in
             A += (double)pp[0];
             B += (double)pp[1];
         }
-        const double bh = rstd * (B - mean * A);  // sum dz * xh
-        gb[((long long)n * Ctot + c) * 2 + 0] = (float)bh;
-        gb[((long long)n * Ctot + c) * 2 + 1] = (float)A;
-        s1 += (double)gamma[c] * A;
-        s2 += (double)gamma[c] * bh;
+        const double bh = rstd * (B - mean * A);  // sum dy * xh
+        const double fs = film ? 1.0 + (double)film[(long long)n * film_stride + c] : 1.0;
+        const double ge = (double)gamma[c] * fs;
+        gb[((long long)n * Ctot + c) * 2 + 0] = (float)(bh * fs);
+        gb[((long long)n * Ctot + c) * 2 + 1] = (float)(A * fs);
+        if (dfilm) {
+            dfilm[(long long)n * dfilm_stride + c] = (float)((double)gamma[c] * bh + (double)beta[c] * A);
+            dfilm[(long long)n * dfilm_stride + Ctot + c] = (float)A;
+        }
+        s1 += ge * A;
+        s2 += ge * bh;
     }
     r1[tid] = s1;
     r2[tid] = s2;
@@ -391,16 +400,20 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int P, in
     const double k2 = -rstd * rstd * S2 / m;
     const double k3 = -rstd * S1 / m + mean * rstd * rstd * S2 / m;
     for (int c = c0 + tid; c < c0 + cpg; c += 256) {
-        coef[((long long)n * Ctot + c) * 3 + 0] = (float)(rstd * (double)gamma[c]);
+        const double fs = film ? 1.0 + (double)film[(long long)n * film_stride + c] : 1.0;
+        coef[((long long)n * Ctot + c) * 3 + 0] = (float)(rstd * (double)gamma[c] * fs);
         coef[((long long)n * Ctot + c) * 3 + 1] = (float)k2;
         coef[((long long)n * Ctot + c) * 3 + 2] = (float)k3;
     }
 }
 
 extern "C" int eod_gn_bwd_finalize(const float* part, int P, int Ctot, int N, int64_t HW, int groups, const float* mean_rstd,
-                                   const float* gamma, float* coef, float* gb, void* stream) {
+                                   const float* gamma, const float* beta, const float* film, int64_t film_stride, float* dfilm,
+                                   int64_t dfilm_stride, float* coef, float* gb, void* stream) {
     EOD_REQUIRE(part && mean_rstd && gamma && coef && gb && P > 0 && Ctot > 0 && N > 0 && groups > 0 && Ctot % groups == 0, "gn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part, P, Ctot, (long long)HW, groups, mean_rstd, gamma, coef, gb);
+    EOD_REQUIRE(!dfilm || (film && beta), "gn_bwd_finalize: dfilm needs film and beta");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part, P, Ctot, (long long)HW, groups, mean_rstd, gamma, beta,
+                       film, (long long)film_stride, dfilm, (long long)dfilm_stride, coef, gb);
     EOD_CHECK_LAUNCH("gn_bwd_finalize");
     return EOD_OK;
 }
@@ -727,5 +740,28 @@ extern "C" int eod_ema_update(float* avg, const float* p, int64_t n, double deca
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, avg, p, (long long)n, (float)decay, (float)(1.0 - decay));
     EOD_CHECK_LAUNCH("ema_update");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// nn.Embedding backward (label_emb, unet_openai.py:604-605,764-766): dW[c][e] = scale * sum_{n: y[n] == c} dout[n][e]
+// (fixed order over n: deterministic, no atomics)
+// ---------------------------------------------------------------------------------------------
+__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ y, int N, int E, int classes, float scale,
+                                     float* __restrict__ dW) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)classes * E) return;
+    const int c = (int)(i / E), e = (int)(i - (long long)c * E);
+    float a = 0.0f;
+    for (int n = 0; n < N; ++n)
+        if (y[n] == c) a += dout[(long long)n * E + e];
+    dW[i] = a * scale;
+}
+
+extern "C" int eod_embedding_bwd(const float* dout, const int64_t* y, int N, int E, int classes, float scale, float* dW, void* stream) {
+    EOD_REQUIRE(dout && y && dW && N > 0 && E > 0 && classes > 0, "embedding_bwd: bad args");
+    const long long tot = (long long)classes * E;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, (const long long*)y, N, E, classes, scale, dW);
+    EOD_CHECK_LAUNCH("embedding_bwd");
     return EOD_OK;
 }

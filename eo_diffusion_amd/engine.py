@@ -278,7 +278,7 @@ class Program:
         return idx
 
     def resample2x(self, x, mode, pad_tl=False):
-        if mode == 1:
+        if mode in (1, 3):
             ho, wo = 2 * x.H + int(pad_tl), 2 * x.W + int(pad_tl)
         else:
             ho, wo = x.H // 2, x.W // 2

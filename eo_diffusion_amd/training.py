@@ -9,8 +9,9 @@ assigned to `param.grad`, so `torch.optim.AdamW(model.parameters())` / `Averaged
 unchanged on them.
 
 Scope of this first version: ResBlock (plain), AttentionBlock (legacy qkv order), Upsample / Downsample with conv,
-first / head conv, the timestep MLP.  Not yet: use_scale_shift_norm, resblock_updown, use_new_attention_order, class
-conditioning, dropout > 0, odd spatial sizes -- these raise EodError (never a silent fallback)."""
+first / head conv, the timestep MLP, class conditioning, and the factory variants use_scale_shift_norm (FiLM),
+resblock_updown, use_new_attention_order.  Not yet: dropout > 0, odd spatial sizes, Up/Downsample without conv outside
+resblock_updown, the 3x3 -> 7x7 pad hack -- these raise EodError (never a silent fallback)."""
 import ctypes as C
 import math
 import os
@@ -46,15 +47,24 @@ class _ConvRec:
 
 
 class _GNRec:
-    def __init__(self, srcs, gn, ss, parts, y, silu):
+    def __init__(self, srcs, gn, ss, parts, y, silu, film=None):
         self.srcs, self.gn, self.ss, self.parts, self.y, self.silu = srcs, gn, ss, parts, y, silu
+        self.film = film  # (view of the [N][J] emb_layers output at this block's columns, J, column offset) or None
+
+
+class _PoolRec:
+    """2x resampling without conv (resblock_updown, unet_openai.py:320-325): mode 0 = average pool, 1 = nearest"""
+
+    def __init__(self, src, y, mode):
+        self.src, self.y, self.mode = src, y, mode
 
 
 class _AttnRec:
     """softmax(q k^T / sqrt(d)) v on the natural [N][T][heads x (q|k|v) x d] layout of qkv (QKVAttentionLegacy, :465-481)"""
 
-    def __init__(self, qkv, qkvT, ldT, P, a, nh, d):
+    def __init__(self, qkv, qkvT, ldT, P, a, nh, d, lay):
         self.qkv, self.qkvT, self.ldT, self.P, self.a, self.nh, self.d = qkv, qkvT, ldT, P, a, nh, d
+        self.lay = lay  # (q offset, k offset, v offset, head stride) in channels of the 3C-wide qkv tensor
 
 
 class UNetTrainer:
@@ -178,28 +188,44 @@ class UNetTrainer:
         check(self.L.eod_pack_conv_weight(ptr(w), ptr(dst), self.dt, cout, cin, ks, cin_pad or cin, current_stream_ptr(self.device)),
               "pack_conv_weight")
 
-    def _gn_fwd(self, srcs, gn, silu=True):
+    def _gn_fwd(self, srcs, gn, silu=True, film=None):
         prog = self.prog
-        ss = prog.gn_stats(srcs, prog.f32(gn.weight), prog.f32(gn.bias), eps=gn.eps)
+        kw = dict(film=film[0], film_stride=film[1]) if film is not None else {}
+        ss = prog.gn_stats(srcs, prog.f32(gn.weight), prog.f32(gn.bias), eps=gn.eps, **kw)
         parts = prog.last_gn_parts
         y = prog.gn_apply(srcs, ss, silu=silu)
-        self.recs.append(_GNRec(srcs, gn, ss, parts, y, silu))
+        self.recs.append(_GNRec(srcs, gn, ss, parts, y, silu, film))
+        return y
+
+    def _pool_fwd(self, src, mode):
+        y = self.prog.resample2x(src, mode)
+        self.recs.append(_PoolRec(src, y, mode))
         return y
 
     def _resblock(self, blk, h):
         U = self.U
         srcs = list(h) if isinstance(h, tuple) else [h]
-        if blk.updown or blk.use_scale_shift_norm:
-            raise EodError("training: resblock_updown / use_scale_shift_norm are not built yet")
         if blk.dropout > 0:
             raise EodError("training: dropout > 0 is not built yet")
         gn1, conv1 = blk.in_layers[0], blk.in_layers[2]
         gn2, conv2 = blk.out_layers[0], blk.out_layers[3]
         a1 = self._gn_fwd(srcs, gn1)
+        if blk.updown:  # resblock_updown (:366-371): resample the normalised branch and the skip input, no conv
+            if len(srcs) != 1 or blk.h_upd.use_conv:
+                raise EodError("training: this resblock_updown variant is not built yet")
+            mode = 1 if isinstance(blk.h_upd, U.Upsample) else 0
+            if mode == 0 and (a1.H % 2 or a1.W % 2):
+                raise EodError("training: average pool of an odd map is not built yet")
+            a1 = self._pool_fwd(a1, mode)
+            srcs = [self._pool_fwd(srcs[0], mode)]
         off = self.ctx.offsets[id(blk)]
         emb_view = self.ctx.out[:, off:]
-        h1 = self._conv_fwd([a1], conv1, emb=(emb_view, self.ctx.J, off))
-        a2 = self._gn_fwd([h1], gn2)
+        if blk.use_scale_shift_norm:  # FiLM (:377-381): emb_out = [scale | shift] modulates the second GroupNorm
+            h1 = self._conv_fwd([a1], conv1)
+            a2 = self._gn_fwd([h1], gn2, film=(emb_view, self.ctx.J, off))
+        else:
+            h1 = self._conv_fwd([a1], conv1, emb=(emb_view, self.ctx.J, off))
+            a2 = self._gn_fwd([h1], gn2)
         if isinstance(blk.skip_connection, nn.Identity):
             if len(srcs) != 1:
                 raise EodError("identity skip over a virtual concat is not supported")
@@ -233,29 +259,31 @@ class UNetTrainer:
         """x + proj_out(attention(qkv(GN(x)))), unet_openai.py:427-433, in a form whose every piece has a backward here:
         qkv / proj_out as 1x1 convs, scores and P.V as batched NT GEMMs on qkv and its transpose, P kept for the backward"""
         prog = self.prog
-        if isinstance(x, tuple) or blk.attention.new_order:
-            raise EodError("training: this AttentionBlock variant is not built yet (legacy qkv order, single source)")
+        if isinstance(x, tuple):
+            raise EodError("training: AttentionBlock over a virtual concat is not supported")
         Cc, nh = blk.channels, blk.num_heads
         d = Cc // nh
         N, T = x.N, x.H * x.W
         if d % prog.epc or T % prog.epc:
             raise EodError(f"training: attention needs head dim {d} and sequence {T} to be multiples of {prog.epc}")
+        # channel layout of qkv: legacy [h][q|k|v][d] (unet_openai.py:474), new order [q|k|v][h][d] (:506-514)
+        qo, ko, vo, hs = (0, Cc, 2 * Cc, d) if blk.attention.new_order else (0, d, 2 * d, 3 * d)
         xn = self._gn_fwd([x], blk.norm, silu=False)
-        qkv = self._conv_fwd([xn], blk.qkv, ksize=1, stats=False)          # [N][T][3C], channel = h*3d + {q,k,v}*d + j
+        qkv = self._conv_fwd([xn], blk.qkv, ksize=1, stats=False)          # [N][T][3C]
         BK = 128 // self.es
         ldT = round_up(N * T, BK)
         qkvT = prog.empty((3 * Cc * ldT,), zero=True)
         self._transpose_op(prog, qkv.t, N, T, 3 * Cc, qkvT, ldT)
         S = self._shared("attn_S", N * nh * T * T, torch.float32)  # only P is kept for the backward
         prog.gemm(qkv.t, qkv.t, S, T, T, d, 3 * Cc, 3 * Cc, T, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
-                  sa=(T * 3 * Cc, 3 * d), sb=(T * 3 * Cc, 3 * d), sc=(nh * T * T, T * T), b_off=d)
+                  sa=(T * 3 * Cc, hs), sb=(T * 3 * Cc, hs), sc=(nh * T * T, T * T), a_off=qo, b_off=ko)
         P = prog.empty((N * nh, T, T))
         prog.softmax_rows(S, T, P, T, N * nh * T, T)
         a = prog.act(N, x.H, x.W, Cc)
         # a[n][t][h*d + j] = sum_s P[n,h][t][s] * v[n][s][h][j]  with v^T rows taken from qkvT
-        prog.gemm(P, qkvT, a.t, T, d, T, T, ldT, Cc, nb0=N, nb1=nh, sa=(nh * T * T, T * T), sb=(T, 3 * d * ldT),
-                  sc=(T * Cc, d), b_off=2 * d * ldT)
-        self.recs.append(_AttnRec(qkv, qkvT, ldT, P, a, nh, d))
+        prog.gemm(P, qkvT, a.t, T, d, T, T, ldT, Cc, nb0=N, nb1=nh, sa=(nh * T * T, T * T), sb=(T, hs * ldT),
+                  sc=(T * Cc, d), b_off=vo * ldT)
+        self.recs.append(_AttnRec(qkv, qkvT, ldT, P, a, nh, d, (qo, ko, vo, hs)))
         return self._conv_fwd([a], blk.proj_out, ksize=1, res=x, stats=True)
 
     def _attn_bwd(self, rec):
@@ -264,6 +292,7 @@ class UNetTrainer:
         if da is None:
             raise EodError("training: attention output has no gradient (graph bug)")
         qkv, qkvT, ldT, P, nh, d = rec.qkv, rec.qkvT, rec.ldT, rec.P, rec.nh, rec.d
+        qo, ko, vo, hs = rec.lay
         N, T, Cc = qkv.N, qkv.H * qkv.W, rec.a.C
         B = N * nh
         alpha = 1.0 / math.sqrt(d)
@@ -271,7 +300,7 @@ class UNetTrainer:
         # dP[b][t][s] = sum_j da[n][t][h*d+j] * v[n][s][h][j]
         dP = self._shared("attn_dP", B * T * T, torch.float32)
         self._bop(lambda: bp.gemm(da.t, qkv.t, dP, T, T, d, Cc, 3 * Cc, T, c_f32=True, nb0=N, nb1=nh, sa=(T * Cc, d),
-                                  sb=(T * 3 * Cc, 3 * d), sc=(nh * T * T, T * T), b_off=2 * d))
+                                  sb=(T * 3 * Cc, hs), sc=(nh * T * T, T * T), b_off=vo))
         dS = self._shared("attn_dS", B * T * T)
         self._call(L.eod_softmax_bwd_rows, ptr(P), T, ptr(dP), T, ptr(dS), dt, B * T, T)
         ldB = round_up(B * T, BK)
@@ -284,13 +313,13 @@ class UNetTrainer:
         dqkv = bp.act(qkv.N, qkv.H, qkv.W, 3 * Cc)
         # dq[n][t][h][j] = alpha * sum_s dS[b][t][s] * k[n][s][h][j]      (k^T rows from qkvT)
         self._bop(lambda: bp.gemm(dS, qkvT, dqkv.t, T, d, T, T, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T * T, T * T),
-                                  sb=(T, 3 * d * ldT), sc=(T * 3 * Cc, 3 * d), b_off=d * ldT))
+                                  sb=(T, hs * ldT), sc=(T * 3 * Cc, hs), b_off=ko * ldT, c_off=qo))
         # dk[n][s][h][j] = alpha * sum_t dS[b][t][s] * q[n][t][h][j]      (dS^T and q^T)
         self._bop(lambda: bp.gemm(dST, qkvT, dqkv.t, T, d, T, ldB, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T, T),
-                                  sb=(T, 3 * d * ldT), sc=(T * 3 * Cc, 3 * d), c_off=d))
+                                  sb=(T, hs * ldT), sc=(T * 3 * Cc, hs), b_off=qo * ldT, c_off=ko))
         # dv[n][s][h][j] = sum_t P[b][t][s] * da[n][t][h*d+j]
         self._bop(lambda: bp.gemm(PT, daT, dqkv.t, T, d, T, ldB, ldT, 3 * Cc, nb0=N, nb1=nh, sa=(nh * T, T),
-                                  sb=(T, d * ldT), sc=(T * 3 * Cc, 3 * d), c_off=2 * d))
+                                  sb=(T, d * ldT), sc=(T * 3 * Cc, hs), c_off=vo))
         self._add_grad(qkv, dqkv)
 
     def _seq(self, seq, h):
@@ -300,8 +329,7 @@ class UNetTrainer:
 
     def _build(self, ccond):
         U, unet, prog, N, H, W = self.U, self.unet, self.prog, self.N, self.H, self.W
-        if unet.num_classes is not None:
-            raise EodError("training: class conditioning is not built yet")
+        self.with_y = unet.num_classes is not None
         cx = unet.in_channels - ccond
         c_pad = round_up(unet.in_channels, prog.epc)
         a0, self.i_in = prog.to_nhwc(N, cx, ccond, H, W, c_pad)
@@ -321,7 +349,8 @@ class UNetTrainer:
         self.emb = prog.empty((N, self.E), torch.float32)
         self.i_t = prog.temb(dict(
             t=0, freqs=ptr(self.freqs), w1=ptr(prog.f32(te1.weight)), b1=ptr(prog.f32(te1.bias)),
-            w2=ptr(prog.f32(te2.weight)), b2=ptr(prog.f32(te2.bias)), label_emb=0, y=0,
+            w2=ptr(prog.f32(te2.weight)), b2=ptr(prog.f32(te2.bias)),
+            label_emb=ptr(prog.f32(unet.label_emb.weight)) if self.with_y else 0, y=0,
             wcat=ptr(self.wcat), bcat=ptr(self.bcat), h1=ptr(self.h1), emb=ptr(self.emb), out=ptr(ctx.out),
             N=N, D=self.D, E=self.E, J=ctx.J))
         # ---- encoder / middle / decoder ----
@@ -373,6 +402,8 @@ class UNetTrainer:
                 self._conv_bwd(rec)
             elif isinstance(rec, _AttnRec):
                 self._attn_bwd(rec)
+            elif isinstance(rec, _PoolRec):
+                self._pool_bwd(rec)
             else:
                 self._gn_bwd(rec)
         self._temb_bwd()
@@ -519,7 +550,13 @@ class UNetTrainer:
         for s in rec.srcs:
             self._call(L.eod_gn_bwd_partial, ptr(s.t), ptr(dy.t), ptr(rec.ss), dt, N, HW, s.C, ptr(part), P, ctot, coff, int(rec.silu))
             coff += s.C
-        self._call(L.eod_gn_bwd_finalize, ptr(part), P, ctot, N, HW, groups, ptr(mr), ptr(self.prog.f32(gn.weight)), ptr(coef), ptr(gb))
+        if rec.film is not None:  # d[scale | shift] of the FiLM go to this block's columns of the emb_layers gradient (loss-scaled)
+            fv, fj, foff = rec.film
+            self._call(L.eod_gn_bwd_finalize, ptr(part), P, ctot, N, HW, groups, ptr(mr), ptr(self.prog.f32(gn.weight)), ptr(self.prog.f32(gn.bias)),
+                       ptr(fv), fj, ptr(self.dout_cat) + foff * 4, self.ctx.J, ptr(coef), ptr(gb))
+        else:
+            self._call(L.eod_gn_bwd_finalize, ptr(part), P, ctot, N, HW, groups, ptr(mr), ptr(self.prog.f32(gn.weight)), 0, 0, 0, 0, 0,
+                       ptr(coef), ptr(gb))
         self._call(L.eod_gn_bwd_params, ptr(gb), N, ctot, self.inv_scale, ptr(self._param_grad(gn.weight)), ptr(self._param_grad(gn.bias)))
         coff = 0
         for s in rec.srcs:
@@ -529,6 +566,16 @@ class UNetTrainer:
                        N, HW, s.C, ctot, coff, int(rec.silu), ptr(dx.t))
             self._add_grad(s, dx)
             coff += s.C
+
+    def _pool_bwd(self, rec):
+        dy = self._take_grad(rec.y)
+        if dy is None:
+            raise EodError("training: a resampled tensor has no gradient (graph bug)")
+        # nearest 2x -> 2x2 sum pool; 2x2 average pool -> nearest 2x times 1/4
+        g = self._bop(lambda: self.bprog.resample2x(dy, 2 if rec.mode == 1 else 3))
+        if (g.H, g.W) != (rec.src.H, rec.src.W):
+            raise EodError("training: resample backward shape mismatch")
+        self._add_grad(rec.src, g)
 
     def _temb_bwd(self):
         L, bp, N, E, D, J = self.L, self.bprog, self.N, self.E, self.D, self.ctx.J
@@ -551,6 +598,10 @@ class UNetTrainer:
         scratch = bp.empty((32, N, E), torch.float32)
         self._call(L.eod_linear_bwd_small, ptr(self.dout_cat), J, ptr(self.emb), 0, 0, ptr(self.wcat), ptr(self.emb), N, E, J, 1, inv,
                    0, 0, ptr(demb), ptr(scratch))
+        self._y_slot = torch.zeros((N,), dtype=torch.int64, device=self.device)
+        if self.with_y:  # emb = time_embed(...) + label_emb(y): the embedding rows get the same gradient rows
+            lw = self.unet.label_emb.weight
+            self._call(L.eod_embedding_bwd, ptr(demb), self._y_slot.data_ptr(), N, E, lw.shape[0], inv, ptr(self._param_grad(lw)))
         # time_embed[2]: emb = W2 h1 + b2, h1 = SiLU(pre1)
         self._call(L.eod_temb_pre1, tp, ptr(self.freqs), ptr(self.prog.f32(te1.weight)), ptr(self.prog.f32(te1.bias)), N, D, E, ptr(pre1))
         self._call(L.eod_linear_bwd_small, ptr(demb), E, ptr(self.h1), 0, 0, ptr(self.prog.f32(te2.weight)), ptr(pre1), N, E, E, 0, inv,
@@ -562,8 +613,9 @@ class UNetTrainer:
     # ------------------------------------------------------------------ execution
     step_id = 0
 
-    def forward(self, x, timesteps, cond=None):
+    def forward(self, x, timesteps, cond=None, y=None):
         """x NCHW fp32 on the GPU, timesteps int64 [N] -> prediction NCHW fp32 (a buffer owned by the trainer)"""
+        assert (y is not None) == self.with_y, "must specify y if and only if the model is class-conditional"
         self.step_id += 1
         for fn in self.repack:
             fn()
@@ -575,6 +627,9 @@ class UNetTrainer:
             self._c = cond.contiguous().float()
             self.prog.ops[self.i_in].u.small.p[1] = self._c.data_ptr()
         self.prog.ops[self.i_t].u.temb.t = self._t_slot.data_ptr()
+        if y is not None:
+            self._y_slot.copy_(y.to(torch.int64))
+            self.prog.ops[self.i_t].u.temb.y = self._y_slot.data_ptr()
         self.prog._arr = None
         self.prog.run()
         return self.pred
@@ -605,10 +660,10 @@ class _UNetTrainFn(torch.autograd.Function):
     gradients into `param.grad` exactly like the reference's autograd graph does (train.py:118)."""
 
     @staticmethod
-    def forward(ctx, trainer, x, timesteps, cond, *params):
+    def forward(ctx, trainer, x, timesteps, cond, y, *params):
         ctx.trainer = trainer
         ctx.n_params = len(params)
-        pred = trainer.forward(x, timesteps, cond)
+        pred = trainer.forward(x, timesteps, cond, y)
         ctx.step_id = trainer.step_id
         return pred.clone()  # the trainer's own buffer is overwritten by the next forward
 
@@ -618,13 +673,11 @@ class _UNetTrainFn(torch.autograd.Function):
         if ctx.step_id != tr.step_id:
             raise EodError("training: backward called after another forward of the same shape (saved activations were overwritten)")
         grads = tr.backward(dpred.contiguous().float(), assign=False)
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 def unet_train_forward(unet, x, timesteps, cond=None, y=None):
     """UNetModel.forward in training mode (called when autograd is enabled and parameters require grad)."""
-    if y is not None or unet.num_classes is not None:
-        raise EodError("training: class conditioning is not built yet")
     N, cx, H, W = x.shape
     ccond = 0 if cond is None else cond.shape[1]
     cache = unet.__dict__.setdefault("_eod_trainers", {})
@@ -635,4 +688,4 @@ def unet_train_forward(unet, x, timesteps, cond=None, y=None):
         scale = float(os.environ.get("EOD_LOSS_SCALE", "1024" if unet.precision == "fp16" else "1"))
         tr = cache[key] = UNetTrainer(unet, N, H, W, x.device, cond_channels=ccond, loss_scale=scale)
     params = [p for p in unet.parameters()]
-    return _UNetTrainFn.apply(tr, x.detach(), timesteps, None if cond is None else cond.detach(), *params)
+    return _UNetTrainFn.apply(tr, x.detach(), timesteps, None if cond is None else cond.detach(), y, *params)

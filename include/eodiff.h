@@ -261,7 +261,7 @@ int eod_timer_read(void* timer, float* ms);
 int eod_timer_set_mask(void* timer, const unsigned char* mask, int n_ops);
 int eod_program_run_timed(const eod_op* ops, int n_ops, void* stream, void* timer);
 /* resblock_updown helpers (unet_openai.py:320-325): mode 0 = 2x2 average pool, 1 = nearest 2x,
- * 2 = 2x2 sum pool (backward of nearest 2x, training path) */
+ * 2 = 2x2 sum pool (backward of nearest 2x), 3 = nearest 2x times 0.25 (backward of the average pool) -- training path */
 int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y,
                    void* stream);
 
@@ -290,8 +290,11 @@ int eod_gn_mean_rstd(const float* part0, int P0, int C0, const float* part1, int
                      float eps, float* mean_rstd, void* stream);
 int eod_gn_bwd_partial(const void* x, const void* dy, const float* scale_shift, int dtype, int N, int HW, int C, float* part,
                        int P, int Ctot, int coff, int silu, void* stream);
+/* film / dfilm (optional): FiLM of use_scale_shift_norm (:377-381), film[n] = [scale | shift] with row stride film_stride;
+ * dfilm[n] = [d scale | d shift] */
 int eod_gn_bwd_finalize(const float* part, int P, int Ctot, int N, int64_t HW, int groups, const float* mean_rstd,
-                        const float* gamma, float* coef, float* gb, void* stream);
+                        const float* gamma, const float* beta, const float* film, int64_t film_stride, float* dfilm,
+                        int64_t dfilm_stride, float* coef, float* gb, void* stream);
 int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, float* dgamma, float* dbeta, void* stream);
 int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype,
                      int N, int HW, int C, int Ctot, int coff, int silu, void* dx, void* stream);
@@ -307,6 +310,8 @@ int eod_linear_bwd_small(const float* dout, int64_t ld_dout, const float* in, co
                          float* scratch /* optional, 32*N*K floats: splits the J loop of din */, void* stream);
 int eod_temb_pre1(const int64_t* t, const float* freqs, const float* w1, const float* b1, int N, int D, int E, float* pre1,
                   void* stream);
+/* nn.Embedding backward (label_emb :604-605): dW[c][e] = scale * sum over the rows n with y[n] == c of dout[n][e] */
+int eod_embedding_bwd(const float* dout, const int64_t* y, int N, int E, int classes, float scale, float* dW, void* stream);
 /* nn.MSELoss(reduction='mean') (train.py:86,117): loss[0] = mean((pred-target)^2), dpred = 2*(pred-target)/n (optional);
  * scratch: scratch_len (>= 1, up to 1024 used) floats of per-block partial sums (fixed-order two-level sum) */
 int eod_mse_loss(const float* pred, const float* target, int64_t n, float* loss, float* dpred, float* scratch, int scratch_len,

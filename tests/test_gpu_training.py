@@ -14,25 +14,26 @@ pytestmark = pytest.mark.gpu
 GTOL = {"fp32": 2e-4, "fp16": 4e-2}
 
 
-def _setup(prec, size, base, mults, nrb, N, in_ch=3, attn=(), heads=1):
+def _setup(prec, size, base, mults, nrb, N, in_ch=3, attn=(), heads=1, extra=None):
     import eo_diffusion_amd.backbones.unet_openai as U
+    extra = extra or {}
     m = U.UNetModel(size, in_channels=in_ch, model_channels=base, out_channels=3, num_res_blocks=nrb, attention_resolutions=list(attn),
-                    channel_mult=mults, num_heads=heads)
+                    channel_mult=mults, num_heads=heads, **extra)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     sd = synth_state_dict(shapes, 11)
     m.load_state_dict(sd)
     m = m.set_precision(prec).to(DEV).train()
-    cfg = dict(model_channels=base, num_res_blocks=nrb, channel_mult=mults, attention_resolutions=tuple(attn), num_heads=heads)
+    cfg = dict(model_channels=base, num_res_blocks=nrb, channel_mult=mults, attention_resolutions=tuple(attn), num_heads=heads, **extra)
     x = synth_input("trx", (N, in_ch, size, size), 3)
     noise = synth_input("trn", (N, 3, size, size), 4)
     t = torch.tensor([7, 650, 999, 0][:N])
     return m, sd, cfg, x, noise, t
 
 
-def _oracle_grads(sd, cfg, x, noise, t):
+def _oracle_grads(sd, cfg, x, noise, t, y=None):
     from oracle import unet_ref as UR
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    pred = UR.unet_forward(sdg, cfg, x, t)
+    pred = UR.unet_forward(sdg, cfg, x, t, y=y)
     loss = torch.nn.functional.mse_loss(pred, noise)
     loss.backward()
     return pred.detach(), {k: v.grad for k, v in sdg.items() if v.grad is not None}
@@ -94,7 +95,7 @@ def test_training_rejects_unbuilt_variants():
     from eo_diffusion_amd._lib import EodError
     from eo_diffusion_amd.training import UNetTrainer
     m = U.UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
-                    channel_mult=(1, 2), num_heads=2, use_scale_shift_norm=True).to(DEV)
+                    channel_mult=(1, 2), num_heads=2, dropout=0.1).to(DEV)
     with pytest.raises(EodError):
         UNetTrainer(m, 2, 16, 16, DEV)
     m = U.UNetModel(28, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
@@ -215,3 +216,30 @@ def test_fused_optimizer_classes_follow_torch():
         y1 = a(x, torch.tensor([3, 700], device=DEV))
         y2 = b(x, torch.tensor([3, 700], device=DEV))
     assert rel_l2(y1.cpu(), y2.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_training_step_factory_variants(prec):
+    """the options the UNetBig / UNet / UNetSmall presets turn on (unet_openai.py:783-922): FiLM (use_scale_shift_norm),
+    resblock_updown, use_new_attention_order, class conditioning -- every parameter gradient vs torch autograd"""
+    from eo_diffusion_amd.training import UNetTrainer
+    extra = dict(use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True, num_classes=5)
+    m, sd, cfg, x, noise, t = _setup(prec, 32, 32, (1, 2, 2), 1, 2, attn=(2,), heads=2, extra=extra)
+    y = torch.tensor([4, 1])
+    pred_ref, gref = _oracle_grads(sd, cfg, x, noise, t, y=y)
+    tr = UNetTrainer(m, 2, 32, 32, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
+    pred = tr.forward(x.to(DEV), t.to(DEV), y=y.to(DEV))
+    assert rel_l2(pred.cpu(), pred_ref) < (2e-5 if prec == "fp32" else 1e-2)
+    tr.backward(2.0 * (pred - noise.to(DEV)) / pred.numel())
+    torch.cuda.synchronize()
+    gmax = max(float(v.norm()) for v in gref.values())
+    worst, n_checked = ("", 0.0), 0
+    for name, p in m.named_parameters():
+        if name not in gref or float(gref[name].norm()) < 1e-5 * gmax:
+            continue
+        e = rel_l2(p.grad.cpu(), gref[name])
+        n_checked += 1
+        if e > worst[1]:
+            worst = (name, e)
+    assert n_checked > 40
+    assert worst[1] < GTOL[prec], f"worst gradient: {worst}"
