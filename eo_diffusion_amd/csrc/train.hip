@@ -765,3 +765,213 @@ extern "C" int eod_embedding_bwd(const float* dout, const int64_t* y, int N, int
     EOD_CHECK_LAUNCH("embedding_bwd");
     return EOD_OK;
 }
+
+// =============================================================================================
+// conv3x3_wgrad_kernel (fp16): backward-weights of a 3x3 / stride-1 / pad-1 conv WITHOUT transposed copies in HBM.
+//   dW[ky][kx][co][ci] = sum_{n,h,w} dY[n][h][w][co] * X[n][h+ky-1][w+kx-1][ci]
+// A workgroup owns a 128 (co) x 128 (ci) tile for ONE ky and all three kx, and walks a range of 64-pixel strips
+// (64 consecutive w of one image row).  Per strip it stages, pixel-major exactly as the tensors lie in HBM (LDS-DMA, 256-byte
+// rows = 128 channels):  dY[n][h][w0 .. w0+63][co tile]  and  X[n][h+ky-1][w0-1 .. w0+64][ci tile]  (zero outside the image);
+// the three kx taps are the same X strip read at row offsets 0 / 1 / 2.  The MFMA operands need the PIXEL axis as K, i.e. a
+// transposed view of those tiles: ds_read_b64_tr_b16 delivers it (each 16-lane group reads a 4-pixel x 16-channel block and
+// every lane receives one channel's 4 pixels).  Rows are XOR-swizzled at 16-byte granularity, swz(row) = ((row&3)<<2)|((row>>2)&3)
+// (MI355X guide, T10 layout (b)), applied on the SOURCE side of the DMA.
+// Arithmetic intensity: 3 x 128 x 128 x 64 MACs per 32.5 KiB staged = 193 FLOP/B (vs 64 for the generic NT GEMM over
+// transposed copies), and the transposes themselves disappear.
+// Output: fp32 partial tiles partial[split][ky*3+kx][co][ci] (same layout as the GEMM path -> eod_wgrad_reduce).
+// Requirements (checked on the host): fp16, Wo % 64 == 0, channel counts multiples of 8.
+// =============================================================================================
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct WgradP {
+    const char* dy;   // [N][Ho][Wo][Cy] fp16
+    const char* x;    // [N][H][W][Cx] fp16 (ups: the conv input is its nearest-2x upsampling)
+    float* partial;   // [S][9][Cout][ldp]
+    int N, H, W, Cx, Ho, Wo, Cy, Cout, ups, ldp, S;
+    int tiles_co, tiles_ci, strips_w, strips_total, strips_per;
+};
+
+__device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
+    constexpr int A_ROWS = 64, X_ROWS = 68, ROWB = 256;
+    constexpr int A_BYTES = A_ROWS * ROWB, X_BYTES = X_ROWS * ROWB, STAGE = A_BYTES + X_BYTES;  // 16 KiB + 17 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int b = blockIdx.x;
+    const int tile_ci = b % p.tiles_ci; b /= p.tiles_ci;
+    const int tile_co = b % p.tiles_co; b /= p.tiles_co;
+    const int ky = b % 3;
+    const int split = b / 3;
+    const int co0 = tile_co * 128, ci0 = tile_ci * 128;
+    const int s_begin = split * p.strips_per, s_end = min(p.strips_total, s_begin + p.strips_per);
+    const int Heff = p.ups ? 2 * p.H : p.H, Weff = p.ups ? 2 * p.W : p.W;
+
+    // ---- DMA slots: one instruction = 4 tile rows x 16 chunks; this lane: row (4*grp + lane/16), LDS slot lane%16 ----
+    const int drow = lane >> 4, dslot = lane & 15;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    auto issue_strip = [&](int strip, int stage) {
+        // strip -> (n, h, w0)
+        const int sw = strip % p.strips_w;
+        const int nh = strip / p.strips_w;
+        const int h = nh % p.Ho, n = nh / p.Ho;
+        const int w0 = sw * 64;
+        char* sa = smem + stage * STAGE;
+        char* sx = sa + A_BYTES;
+        // dY: groups wave, wave+4, wave+8, wave+12 (4 rows each)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave + 4 * i) * 4 + drow;
+            const int chunk = dslot ^ wg_swz(row);
+            const long long pix = ((long long)n * p.Ho + h) * p.Wo + w0 + row;
+            const int c = co0 + chunk * 8;
+            const unsigned v = c < p.Cy ? (unsigned)((pix * p.Cy + c) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(sa + (wave + 4 * i) * 1024), 16, v, 0, 0, 0);
+        }
+        // X: 17 groups of 4 rows (rows 0..67; staged row r = pixel column w0 - 1 + r of image row h + ky - 1)
+        const int hh = h + ky - 1;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int grp = wave + 4 * i;
+            if (grp < 17) {
+                const int row = grp * 4 + drow;
+                const int chunk = dslot ^ wg_swz(row);
+                int ww = w0 - 1 + row;
+                const int c = ci0 + chunk * 8;
+                bool ok = row < 66 && (unsigned)hh < (unsigned)Heff && (unsigned)ww < (unsigned)Weff && c < p.Cx;
+                int hs = hh, ws = ww;
+                if (p.ups) {
+                    hs >>= 1;
+                    ws >>= 1;
+                }
+                const long long pix = ((long long)n * p.H + hs) * p.W + ws;
+                const unsigned v = ok ? (unsigned)((pix * p.Cx + c) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t*)(sx + grp * 1024), 16, v, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- transposed-read addresses (bytes inside a stage), see the header comment ----
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    auto tr_addr = [&](int row, int col) {  // col = channel inside the 128-wide tile (multiple of 4)
+        return row * ROWB + (((col >> 3) ^ wg_swz(row)) << 4) + ((col >> 2) & 1) * 8;
+    };
+    int a_ad[2][2];     // [j][i]  : dY tile, K rows (g>>1)*8 + j*4 + q, M cols wm*64 + i*32 + (g&1)*16 + 4*pp
+    int b_ad[3][2][2];  // [kx][j][i2] : X tile, rows + kx
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (g >> 1) * 8 + j * 4 + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a_ad[j][i] = tr_addr(row, wm * 64 + i * 32 + (g & 1) * 16 + 4 * pp);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) b_ad[kx][j][i] = A_BYTES + tr_addr(row + kx, wn * 64 + i * 32 + (g & 1) * 16 + 4 * pp);
+        }
+    }
+
+    f32x16 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.0f;
+
+    if (s_begin < s_end) issue_strip(s_begin, 0);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int stage = (s - s_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < s_end) issue_strip(s + 1, stage ^ 1);
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // 16 pixels per MFMA; (row + 16) keeps swz(row): +4096 bytes per sub-step
+            half8 fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + a_ad[0][i] + ks * 4096));
+                const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + a_ad[1][i] + ks * 4096));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    fa[i][e] = (half_t)lo[e];
+                    fa[i][4 + e] = (half_t)hi[e];
+                }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                half8 fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[kx][0][i] + ks * 4096));
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[kx][1][i] + ks * 4096));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        fb[i][e] = (half_t)lo[e];
+                        fb[i][4 + e] = (half_t)hi[e];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[kx][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[kx][i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: C layout (lane&31 = ci column, regs = co rows) -> fp32 partial tile ----
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        float* base = p.partial + ((long long)split * 9 + ky * 3 + kx) * p.Cout * p.ldp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ci = ci0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (co < p.Cout && ci < p.Cx) base[(long long)co * p.ldp + ci] = acc[kx][i][j][r];
+                }
+            }
+    }
+}
+
+extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N, int H, int W, int Cx, int Ho, int Wo, int Cy, int Cout,
+                                 int ups, float* partial, int ldp, int S, void* stream) {
+    EOD_REQUIRE(dy && x && partial && N > 0 && H > 0 && W > 0 && Cx > 0 && Ho > 0 && Wo > 0 && Cy > 0 && Cout > 0 && S > 0 && ldp >= Cx,
+                "conv3x3_wgrad: bad args");
+    EOD_REQUIRE(dtype == EOD_F16, "conv3x3_wgrad: fp16 only (the transposed LDS read is a 16-bit instruction)");
+    EOD_REQUIRE(Wo % 64 == 0 && Cx % 8 == 0 && Cy % 8 == 0 && Cout <= Cy, "conv3x3_wgrad: needs Wo %% 64 == 0 and channel counts that are multiples of 8");
+    EOD_REQUIRE(Ho == (ups ? 2 * H : H) && Wo == (ups ? 2 * W : W), "conv3x3_wgrad: stride-1 / pad-1 geometry expected");
+    EOD_REQUIRE(eod_aligned16(dy) && eod_aligned16(x), "conv3x3_wgrad: 16-byte alignment");
+    EOD_REQUIRE((long long)N * Ho * Wo * Cy * 2 < 0x7fffffffLL && (long long)N * H * W * Cx * 2 < 0x7fffffffLL, "conv3x3_wgrad: tensors exceed the 2 GiB buffer window");
+    WgradP p;
+    p.dy = (const char*)dy; p.x = (const char*)x; p.partial = partial;
+    p.N = N; p.H = H; p.W = W; p.Cx = Cx; p.Ho = Ho; p.Wo = Wo; p.Cy = Cy; p.Cout = Cout; p.ups = ups; p.ldp = ldp; p.S = S;
+    p.tiles_co = (Cout + 127) / 128;
+    p.tiles_ci = (Cx + 127) / 128;
+    p.strips_w = Wo / 64;
+    p.strips_total = N * Ho * p.strips_w;
+    p.strips_per = (p.strips_total + S - 1) / S;
+    const long long grid = (long long)p.tiles_co * p.tiles_ci * 3 * S;
+    EOD_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_wgrad: grid too large");
+    const size_t lds = 2 * (size_t)(64 * 256 + 68 * 256);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
+    EOD_CHECK_LAUNCH("conv3x3_wgrad");
+    return EOD_OK;
+}

@@ -459,6 +459,26 @@ class UNetTrainer:
             self._call(L.eod_wgrad_reduce, ptr(partial), S, ks, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(dW))
             ci0 += cs_real
 
+    def _wgrad_direct(self, rec, dy, cout):
+        """3x3 / stride-1 backward-weights through conv3x3_wgrad_kernel (pixel-major staging + transposed LDS reads)"""
+        L, bp, dt = self.L, self.bprog, self.dt
+        conv = rec.conv
+        cin_total = conv.weight.shape[1]
+        dW = self._param_grad(conv.weight)
+        strips = dy.N * dy.H * (dy.W // 64)
+        ci0 = 0
+        for xs in rec.srcs:
+            cs = xs.C
+            cs_real = min(cs, cin_total - ci0)
+            ldp = round_up(cs, 4)
+            tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 3
+            S = max(1, min(strips, (1024 + tiles - 1) // tiles))
+            partial = bp.empty((S * 9 * cout * ldp,), torch.float32)
+            self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, int(bool(rec.upsample)),
+                       ptr(partial), ldp, S)
+            self._call(L.eod_wgrad_reduce, ptr(partial), S, 3, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(dW))
+            ci0 += cs_real
+
     def _conv_bwd(self, rec):
         L, bp, dt, es = self.L, self.bprog, self.dt, self.es
         dy = self._take_grad(rec.y)
@@ -483,7 +503,19 @@ class UNetTrainer:
         Kper = per_steps * BK
         ld = S * Kper
         shift_dy = None
-        if s1 and dy.C < sum(x.C for x in rec.srcs) and os.environ.get("EOD_WGRAD_SHIFT", "auto") != "x":
+        # dedicated backward-weights kernel (no transposed copies) where it applies; the GEMM path otherwise
+        direct = (s1 and self.prog.precision == "fp16" and Wo % 64 == 0 and dy.C % 8 == 0 and all(x.C % 8 == 0 for x in rec.srcs)
+                  and dy.t.numel() * es < 2**31 and all(x.t.numel() * es < 2**31 for x in rec.srcs)
+                  and os.environ.get("EOD_WGRAD", "direct") != "gemm")
+        if direct:
+            rp = 0
+            K = N * Ho * Wo
+            steps = (K + BK - 1) // BK
+            S, Kper = 1, steps * BK
+            ld = Kper
+            dYt = bp.empty((dy.C * ld + 16,))  # only for the bias / timestep-projection row sums
+            self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, 0)
+        elif s1 and dy.C < sum(x.C for x in rec.srcs) and os.environ.get("EOD_WGRAD_SHIFT", "auto") != "x":
             # inputs wider than the output: three dx-shifted copies of dY (pad rows, +-W margins) instead of three of each input
             ymargin = round_up(Wo, 8)
             yper = dy.C * ld + 2 * ymargin
@@ -505,7 +537,10 @@ class UNetTrainer:
         if rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
             off = rec.emb[2]
             self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wo, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
-        self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy)
+        if direct:
+            self._wgrad_direct(rec, dy, cout)
+        else:
+            self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy)
         if rec.res is not None:
             self._add_grad(rec.res, dy)
         if not rec.src_needs_grad:

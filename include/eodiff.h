@@ -285,6 +285,11 @@ int eod_colsum(const float* seg, int S, int C, float* out, void* stream); /* out
 /* dW_oihw[co][ci0+ci][tap] = scale * sum_s partial[s][tap][co][ci]  (partial: fp32 [S][taps][Cout][ldp]) */
 int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout, int nci, int ldp, int ci0, int Cin, float scale,
                      float* dw_oihw, void* stream);
+/* dedicated backward-weights kernel for 3x3 / stride-1 / pad-1 convs (fp16, Wo % 64 == 0, channels % 8 == 0): reads dY
+ * [N][Ho][Wo][Cy] and X [N][H][W][Cx] (ups: conv input = nearest-2x of X) in place -- no transposed copies -- and writes the
+ * fp32 partial tiles partial[S][9][Cout][ldp] that eod_wgrad_reduce sums (csrc/train.hip: conv3x3_wgrad_kernel) */
+int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N, int H, int W, int Cx, int Ho, int Wo, int Cy, int Cout,
+                      int ups, float* partial, int ldp, int S, void* stream);
 /* GroupNorm32 (+SiLU) backward (unet_openai.py:11-13,312-316): see csrc/train.hip for the algebra */
 int eod_gn_mean_rstd(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW, int groups,
                      float eps, float* mean_rstd, void* stream);

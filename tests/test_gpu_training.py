@@ -41,7 +41,8 @@ def _oracle_grads(sd, cfg, x, noise, t, y=None):
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 @pytest.mark.parametrize("arch", [(16, 32, (1, 2), 1, 2, (), 1), (32, 32, (1, 2, 2), 1, 3, (), 1), (16, 64, (1, 2), 2, 2, (), 1),
-                                  (16, 32, (1, 2), 1, 2, (1, 2), 2)])  # last: attention at both levels, 2 heads (d = 16 / 32)
+                                  (16, 32, (1, 2), 1, 2, (1, 2), 2),   # attention at both levels, 2 heads (d = 16 / 32)
+                                  (64, 32, (1, 2), 1, 1, (), 1)])      # 64-wide maps: the dedicated backward-weights kernel (fp16)
 def test_unet_training_step_gradients(prec, arch):
     from eo_diffusion_amd.training import UNetTrainer
     size, base, mults, nrb, N, attn, heads = arch
