@@ -70,6 +70,7 @@ SYMBOLS = {
     "eod_transpose_gather": (i32, [vp, i32, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_rowsum_segments": (i32, [vp, i32, i32, i64, i32, i64, f32, vp, i64, vp]),
     "eod_colsum": (i32, [vp, i32, i32, vp, vp]),
+    "eod_channel_sums_finish": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, i64, vp, vp]),
     "eod_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "eod_conv3x3_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "eod_gn_mean_rstd": (i32, [vp, i32, i32, vp, i32, i32, i32, i64, i32, f32, vp, vp]),

@@ -975,3 +975,30 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
     EOD_CHECK_LAUNCH("conv3x3_wgrad");
     return EOD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// bias / timestep-projection gradients straight from the NHWC gradient (no transposed copy): eod_gn_partial already
+// produces per-(image, slab, channel) sums  part[n][p][c][0];  this reduces them:
+//   dbias[c] = scale * sum_{n,p} part[n][p][c][0],   demb[n][c] = sum_p part[n][p][c][0]   (fixed order)
+// ---------------------------------------------------------------------------------------------
+__global__ void channel_sums_finish_kernel(const float* __restrict__ part, int N, int P, int C, int cvalid, float scale, float* __restrict__ pern,
+                                           float* __restrict__ demb, long long demb_ld) {
+    // grid (channel blocks, N): one image per block row; per-image totals go to pern[n][c] (scaled) for the bias gradient
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (c >= cvalid) return;
+    float a = 0.0f;
+    for (int p = 0; p < P; ++p) a += part[(((long long)n * P + p) * C + c) * 2];
+    if (demb) demb[(long long)n * demb_ld + c] = a;
+    if (pern) pern[(long long)n * cvalid + c] = a * scale;
+}
+
+extern "C" int eod_channel_sums_finish(const float* part, int N, int P, int C, int cvalid, float scale, float* dbias, float* demb,
+                                       int64_t demb_ld, float* scratch, void* stream) {
+    EOD_REQUIRE(part && N > 0 && P > 0 && C > 0 && cvalid > 0 && cvalid <= C && (dbias || demb) && N <= 65535, "channel_sums_finish: bad args");
+    EOD_REQUIRE(!dbias || scratch, "channel_sums_finish: the bias gradient needs a scratch of N*cvalid floats");
+    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((cvalid + 63) / 64, N), dim3(64), 0, (hipStream_t)stream, part, N, P, C, cvalid, scale,
+                       dbias ? scratch : nullptr, demb, (long long)demb_ld);
+    if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3((cvalid + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, N, cvalid, dbias);
+    EOD_CHECK_LAUNCH("channel_sums_finish");
+    return EOD_OK;
+}

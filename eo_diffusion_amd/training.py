@@ -472,7 +472,7 @@ class UNetTrainer:
             cs_real = min(cs, cin_total - ci0)
             ldp = round_up(cs, 4)
             tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 3
-            S = max(1, min(strips, (1024 + tiles - 1) // tiles))
+            S = max(1, min(strips, (int(os.environ.get("EOD_WGRAD_WGS", "640")) + tiles - 1) // tiles))
             partial = bp.empty((S * 9 * cout * ldp,), torch.float32)
             self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, int(bool(rec.upsample)),
                        ptr(partial), ldp, S)
@@ -508,13 +508,17 @@ class UNetTrainer:
                   and dy.t.numel() * es < 2**31 and all(x.t.numel() * es < 2**31 for x in rec.srcs)
                   and os.environ.get("EOD_WGRAD", "direct") != "gemm")
         if direct:
-            rp = 0
-            K = N * Ho * Wo
-            steps = (K + BK - 1) // BK
-            S, Kper = 1, steps * BK
-            ld = Kper
-            dYt = bp.empty((dy.C * ld + 16,))  # only for the bias / timestep-projection row sums
-            self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, 0)
+            # bias / timestep-projection gradients = per-channel sums of dY, taken from the NHWC tensor in place
+            HW = Ho * Wo
+            Pn = max(1, min(256, HW // 64))
+            csum = bp.empty((N, Pn, dy.C, 2), torch.float32)
+            self._call(L.eod_gn_partial, ptr(dy.t), dt, N, HW, dy.C, ptr(csum), Pn, dy.C, 0)
+            if conv.bias is not None or rec.emb is not None:
+                self._call(L.eod_channel_sums_finish, ptr(csum), N, Pn, dy.C, cout, self.inv_scale,
+                           ptr(self._param_grad(conv.bias)) if conv.bias is not None else 0,
+                           (ptr(self.dout_cat) + rec.emb[2] * 4) if rec.emb is not None else 0, self.ctx.J,
+                           ptr(bp.empty((N, cout), torch.float32)))
+            self._wgrad_direct(rec, dy, cout)
         elif s1 and dy.C < sum(x.C for x in rec.srcs) and os.environ.get("EOD_WGRAD_SHIFT", "auto") != "x":
             # inputs wider than the output: three dx-shifted copies of dY (pad rows, +-W margins) instead of three of each input
             ymargin = round_up(Wo, 8)
@@ -528,18 +532,16 @@ class UNetTrainer:
         else:
             dYt = bp.empty((dy.C * ld + 16,))
             self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, rp)
-        if conv.bias is not None:  # bias gradient = row sums of dYt, in two levels (enough blocks to fill the chip)
+        if not direct and conv.bias is not None:  # bias gradient = row sums of dYt, in two levels (enough blocks to fill the chip)
             units = ld // BK
             nseg = max(dv for dv in range(1, min(units, 128) + 1) if units % dv == 0)
             tmp = bp.empty((nseg, cout), torch.float32)
             self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, nseg, ld // nseg, self.inv_scale, ptr(tmp), cout)
             self._call(L.eod_colsum, ptr(tmp), nseg, cout, ptr(self._param_grad(conv.bias)))
-        if rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
+        if not direct and rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
             off = rec.emb[2]
             self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wo, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
-        if direct:
-            self._wgrad_direct(rec, dy, cout)
-        else:
+        if not direct:
             self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy)
         if rec.res is not None:
             self._add_grad(rec.res, dy)

@@ -282,6 +282,10 @@ int eod_transpose_gather(const void* src, int dtype, int N, int H, int W, int C,
 int eod_rowsum_segments(const void* x, int dtype, int C, int64_t ld, int nseg, int64_t seg_len, float scale, float* seg,
                         int64_t seg_ld, void* stream);
 int eod_colsum(const float* seg, int S, int C, float* out, void* stream); /* out[c] = sum_s seg[s][c] */
+/* the same gradients from eod_gn_partial's per-(image, slab, channel) sums of the NHWC gradient (no transposed copy):
+ * dbias[c] = scale * sum_{n,p} part[n][p][c][0] (c < cvalid), demb[n][c] = sum_p part[n][p][c][0]; either may be NULL */
+int eod_channel_sums_finish(const float* part, int N, int P, int C, int cvalid, float scale, float* dbias, float* demb,
+                            int64_t demb_ld, float* scratch /* N*cvalid floats when dbias != NULL */, void* stream);
 /* dW_oihw[co][ci0+ci][tap] = scale * sum_s partial[s][tap][co][ci]  (partial: fp32 [S][taps][Cout][ldp]) */
 int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout, int nci, int ldp, int ci0, int Cin, float scale,
                      float* dw_oihw, void* stream);
