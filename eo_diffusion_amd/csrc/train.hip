@@ -794,8 +794,13 @@ struct WgradP {
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+// WS = image-row width covered by a strip (64: one 64-pixel segment of a row; 32 / 16: 2 / 4 whole rows of a 32- / 16-wide map).
+// Pixel k of the strip lies in image row r = k / WS; its X row for tap kx is staged at  k + 16*r + kx  (every image row gets its own
+// left / right halo, and the 16-row pitch keeps swz(row) invariant under the k -> k + 16 steps of the MFMA sub-steps).
+template <int WS>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
-    constexpr int A_ROWS = 64, X_ROWS = 68, ROWB = 256;
+    constexpr int RPS = 64 / WS, RPITCH = WS + 16;                    // image rows per strip, staged-row pitch of an image row
+    constexpr int A_ROWS = 64, X_ROWS = ((RPS - 1) * RPITCH + WS + 2 + 3) / 4 * 4, ROWB = 256, XG = X_ROWS / 4;
     constexpr int A_BYTES = A_ROWS * ROWB, X_BYTES = X_ROWS * ROWB, STAGE = A_BYTES + X_BYTES;  // 16 KiB + 17 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][STAGE]
 
@@ -817,11 +822,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, 0x7fffffff, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     auto issue_strip = [&](int strip, int stage) {
-        // strip -> (n, h, w0)
-        const int sw = strip % p.strips_w;
-        const int nh = strip / p.strips_w;
-        const int h = nh % p.Ho, n = nh / p.Ho;
-        const int w0 = sw * 64;
+        // strip -> (n, h, w0): 64 consecutive pixels of one image in raster order
+        const int spi = p.Ho * p.Wo / 64;  // strips per image
+        const int n = strip / spi;
+        const int pix0 = (strip - n * spi) * 64;
+        const int h = pix0 / p.Wo, w0 = pix0 - h * p.Wo;
         char* sa = smem + stage * STAGE;
         char* sx = sa + A_BYTES;
         // dY: groups wave, wave+4, wave+8, wave+12 (4 rows each)
@@ -829,22 +834,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
         for (int i = 0; i < 4; ++i) {
             const int row = (wave + 4 * i) * 4 + drow;
             const int chunk = dslot ^ wg_swz(row);
-            const long long pix = ((long long)n * p.Ho + h) * p.Wo + w0 + row;
+            const long long pix = (long long)n * p.Ho * p.Wo + pix0 + row;
             const int c = co0 + chunk * 8;
             const unsigned v = c < p.Cy ? (unsigned)((pix * p.Cy + c) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(sa + (wave + 4 * i) * 1024), 16, v, 0, 0, 0);
         }
-        // X: 17 groups of 4 rows (rows 0..67; staged row r = pixel column w0 - 1 + r of image row h + ky - 1)
-        const int hh = h + ky - 1;
+        // X: XG groups of 4 staged rows; staged row -> (image row r of the strip, column w0 - 1 + rr)
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < (XG + 3) / 4; ++i) {
             const int grp = wave + 4 * i;
-            if (grp < 17) {
+            if (grp < XG) {
                 const int row = grp * 4 + drow;
                 const int chunk = dslot ^ wg_swz(row);
-                int ww = w0 - 1 + row;
+                const int r = row / RPITCH, rr = row - r * RPITCH;
+                const int hh = h + r + ky - 1, ww = w0 - 1 + rr;
                 const int c = ci0 + chunk * 8;
-                bool ok = row < 66 && (unsigned)hh < (unsigned)Heff && (unsigned)ww < (unsigned)Weff && c < p.Cx;
+                const bool ok = r < RPS && rr < WS + 2 && (unsigned)hh < (unsigned)Heff && (unsigned)ww < (unsigned)Weff && c < p.Cx;
                 int hs = hh, ws = ww;
                 if (p.ups) {
                     hs >>= 1;
@@ -894,6 +899,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
         const char* sb = smem + stage * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {  // 16 pixels per MFMA; (row + 16) keeps swz(row): +4096 bytes per sub-step
+            const int xoff = (ks + (ks * 16) / WS) * 4096;  // X rows: + 16 staged rows per image row of the strip
             half8 fa[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -910,8 +916,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
                 half8 fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[kx][0][i] + ks * 4096));
-                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[kx][1][i] + ks * 4096));
+                    const fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[kx][0][i] + xoff));
+                    const fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[kx][1][i] + xoff));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         fb[i][e] = (half_t)lo[e];
@@ -951,7 +957,9 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
     EOD_REQUIRE(dy && x && partial && N > 0 && H > 0 && W > 0 && Cx > 0 && Ho > 0 && Wo > 0 && Cy > 0 && Cout > 0 && S > 0 && ldp >= Cx,
                 "conv3x3_wgrad: bad args");
     EOD_REQUIRE(dtype == EOD_F16, "conv3x3_wgrad: fp16 only (the transposed LDS read is a 16-bit instruction)");
-    EOD_REQUIRE(Wo % 64 == 0 && Cx % 8 == 0 && Cy % 8 == 0 && Cout <= Cy, "conv3x3_wgrad: needs Wo %% 64 == 0 and channel counts that are multiples of 8");
+    const int ws = Wo % 64 == 0 ? 64 : Wo;
+    EOD_REQUIRE((ws == 64 || ws == 32 || ws == 16) && (Ho * Wo) % 64 == 0 && Cx % 8 == 0 && Cy % 8 == 0 && Cout <= Cy,
+                "conv3x3_wgrad: needs Wo %% 64 == 0 (or Wo = 32 / 16 with Ho*Wo %% 64 == 0) and channel counts that are multiples of 8");
     EOD_REQUIRE(Ho == (ups ? 2 * H : H) && Wo == (ups ? 2 * W : W), "conv3x3_wgrad: stride-1 / pad-1 geometry expected");
     EOD_REQUIRE(eod_aligned16(dy) && eod_aligned16(x), "conv3x3_wgrad: 16-byte alignment");
     EOD_REQUIRE((long long)N * Ho * Wo * Cy * 2 < 0x7fffffffLL && (long long)N * H * W * Cx * 2 < 0x7fffffffLL, "conv3x3_wgrad: tensors exceed the 2 GiB buffer window");
@@ -960,18 +968,21 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
     p.N = N; p.H = H; p.W = W; p.Cx = Cx; p.Ho = Ho; p.Wo = Wo; p.Cy = Cy; p.Cout = Cout; p.ups = ups; p.ldp = ldp; p.S = S;
     p.tiles_co = (Cout + 127) / 128;
     p.tiles_ci = (Cx + 127) / 128;
-    p.strips_w = Wo / 64;
-    p.strips_total = N * Ho * p.strips_w;
+    p.strips_w = 0;
+    p.strips_total = N * (Ho * Wo / 64);
     p.strips_per = (p.strips_total + S - 1) / S;
     const long long grid = (long long)p.tiles_co * p.tiles_ci * 3 * S;
     EOD_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_wgrad: grid too large");
-    const size_t lds = 2 * (size_t)(64 * 256 + 68 * 256);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+    const int rps = 64 / ws, xrows = ((rps - 1) * (ws + 16) + ws + 2 + 3) / 4 * 4;
+    const size_t lds = 2 * (size_t)(64 * 256 + xrows * 256);
+    void (*kern)(const WgradP) = ws == 64 ? conv3x3_wgrad_kernel<64> : ws == 32 ? conv3x3_wgrad_kernel<32> : conv3x3_wgrad_kernel<16>;
+    static bool attr_done[3] = {false, false, false};
+    const int vi = ws == 64 ? 0 : ws == 32 ? 1 : 2;
+    if (!attr_done[vi]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[vi] = true;
     }
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     EOD_CHECK_LAUNCH("conv3x3_wgrad");
     return EOD_OK;
 }

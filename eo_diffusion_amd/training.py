@@ -465,7 +465,7 @@ class UNetTrainer:
         conv = rec.conv
         cin_total = conv.weight.shape[1]
         dW = self._param_grad(conv.weight)
-        strips = dy.N * dy.H * (dy.W // 64)
+        strips = dy.N * (dy.H * dy.W // 64)
         ci0 = 0
         for xs in rec.srcs:
             cs = xs.C
@@ -504,7 +504,8 @@ class UNetTrainer:
         ld = S * Kper
         shift_dy = None
         # dedicated backward-weights kernel (no transposed copies) where it applies; the GEMM path otherwise
-        direct = (s1 and self.prog.precision == "fp16" and Wo % 64 == 0 and dy.C % 8 == 0 and all(x.C % 8 == 0 for x in rec.srcs)
+        direct = (s1 and self.prog.precision == "fp16" and (Wo % 64 == 0 or (Wo in (16, 32) and (Ho * Wo) % 64 == 0))
+                  and dy.C % 8 == 0 and all(x.C % 8 == 0 for x in rec.srcs)
                   and dy.t.numel() * es < 2**31 and all(x.t.numel() * es < 2**31 for x in rec.srcs)
                   and os.environ.get("EOD_WGRAD", "direct") != "gemm")
         if direct:
