@@ -472,7 +472,7 @@ class UNetTrainer:
             cs_real = min(cs, cin_total - ci0)
             ldp = round_up(cs, 4)
             tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 3
-            S = max(1, min(strips, (int(os.environ.get("EOD_WGRAD_WGS", "640")) + tiles - 1) // tiles))
+            S = max(1, min(strips, (int(os.environ.get("EOD_WGRAD_WGS", "512")) + tiles - 1) // tiles))
             partial = bp.empty((S * 9 * cout * ldp,), torch.float32)
             self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, int(bool(rec.upsample)),
                        ptr(partial), ldp, S)
