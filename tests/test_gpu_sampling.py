@@ -5,8 +5,8 @@ import pytest
 import torch
 
 from tests.gpu_util import DEV, load_into
-from tests.helpers import gt, rel_l2, unet_cfgs
-from tests.synth import synth_state_dict
+from tests.helpers import bits_equal, gt, rel_l2, unet_cfgs
+from tests.synth import synth_input, synth_state_dict
 
 pytestmark = pytest.mark.gpu
 TRAJ_TOL = {"fp32": 2e-5, "fp16": 1e-2}  # 10-20 recursive steps through the UNet
@@ -175,3 +175,19 @@ def test_repaint_keeps_known_region_statistics():
     kept = mask.expand_as(gt0) > 0
     expect = m.sqrt_alphas_cumprod[0] * gt0
     assert torch.allclose(m.model.last_x[kept], expect[kept], rtol=0, atol=1e-6)
+
+
+def test_hipgraph_replay_is_bit_identical():
+    """UNetModel.enable_graph(): the launch program captured into one hipGraph returns the same bits as the plain replay,
+    for changing inputs / timesteps (static input buffers are refreshed before every replay)"""
+    m = _model("fp16")
+    x1, x2 = synth_input("gx1", (2, 3, 16, 16), 1).to(DEV), synth_input("gx2", (2, 3, 16, 16), 2).to(DEV)
+    t1, t2 = torch.tensor([3, 17], device=DEV), torch.tensor([19, 0], device=DEV)
+    with torch.no_grad():
+        ref1, ref2 = m.model(x1, t1).clone(), m.model(x2, t2).clone()
+        m.model.enable_graph(True)
+        g1 = m.model(x1, t1).clone()
+        g2 = m.model(x2, t2).clone()
+        g1b = m.model(x1, t1).clone()
+        m.model.enable_graph(False)
+    assert bits_equal(g1, ref1) and bits_equal(g2, ref2) and bits_equal(g1b, ref1)
