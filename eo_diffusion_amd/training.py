@@ -257,31 +257,34 @@ class UNetTrainer:
 
     def _attention(self, blk, x):
         """x + proj_out(attention(qkv(GN(x)))), unet_openai.py:427-433, in a form whose every piece has a backward here:
-        qkv / proj_out as 1x1 convs, scores and P.V as batched NT GEMMs on qkv and its transpose, P kept for the backward"""
+        qkv / proj_out as 1x1 convs, scores and P.V as batched NT GEMMs on qkv and its transpose, P kept for the backward.
+        Sequence lengths that are not a multiple of one 16-byte chunk (T = 196 at 14x14) are pitched to Tp >= T: the pad
+        columns of P / dS and of the transposed operands are zeros, so they drop out of every contraction."""
         prog = self.prog
         if isinstance(x, tuple):
             raise EodError("training: AttentionBlock over a virtual concat is not supported")
         Cc, nh = blk.channels, blk.num_heads
         d = Cc // nh
         N, T = x.N, x.H * x.W
-        if d % prog.epc or T % prog.epc:
-            raise EodError(f"training: attention needs head dim {d} and sequence {T} to be multiples of {prog.epc}")
+        if d % prog.epc:
+            raise EodError(f"training: attention needs the head dim {d} to be a multiple of {prog.epc}")
+        Tp = round_up(T, prog.epc)
         # channel layout of qkv: legacy [h][q|k|v][d] (unet_openai.py:474), new order [q|k|v][h][d] (:506-514)
         qo, ko, vo, hs = (0, Cc, 2 * Cc, d) if blk.attention.new_order else (0, d, 2 * d, 3 * d)
         xn = self._gn_fwd([x], blk.norm, silu=False)
         qkv = self._conv_fwd([xn], blk.qkv, ksize=1, stats=False)          # [N][T][3C]
         BK = 128 // self.es
-        ldT = round_up(N * T, BK)
-        qkvT = prog.empty((3 * Cc * ldT,), zero=True)
-        self._transpose_op(prog, qkv.t, N, T, 3 * Cc, qkvT, ldT)
-        S = self._shared("attn_S", N * nh * T * T, torch.float32)  # only P is kept for the backward
-        prog.gemm(qkv.t, qkv.t, S, T, T, d, 3 * Cc, 3 * Cc, T, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
-                  sa=(T * 3 * Cc, hs), sb=(T * 3 * Cc, hs), sc=(nh * T * T, T * T), a_off=qo, b_off=ko)
-        P = prog.empty((N * nh, T, T))
-        prog.softmax_rows(S, T, P, T, N * nh * T, T)
+        ldT = round_up(N * Tp, BK)
+        qkvT = prog.empty((3 * Cc * ldT,), zero=True)                        # [3C][n*Tp + t]
+        prog._small(OP_TRANSPOSE, p=(ptr(qkv.t), ptr(qkvT)), l=(ldT, 0, 0, 0), i=(self.dt, N, 1, T, 3 * Cc, 1, Tp, 1, 0, 0))
+        S = self._shared("attn_S", N * nh * T * Tp, torch.float32)  # only P is kept for the backward
+        prog.gemm(qkv.t, qkv.t, S, T, T, d, 3 * Cc, 3 * Cc, Tp, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
+                  sa=(T * 3 * Cc, hs), sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), a_off=qo, b_off=ko)
+        P = prog.empty((N * nh, T, Tp), zero=True)
+        prog.softmax_rows(S, Tp, P, Tp, N * nh * T, T)
         a = prog.act(N, x.H, x.W, Cc)
         # a[n][t][h*d + j] = sum_s P[n,h][t][s] * v[n][s][h][j]  with v^T rows taken from qkvT
-        prog.gemm(P, qkvT, a.t, T, d, T, T, ldT, Cc, nb0=N, nb1=nh, sa=(nh * T * T, T * T), sb=(T, hs * ldT),
+        prog.gemm(P, qkvT, a.t, T, d, Tp, Tp, ldT, Cc, nb0=N, nb1=nh, sa=(nh * T * Tp, T * Tp), sb=(Tp, hs * ldT),
                   sc=(T * Cc, d), b_off=vo * ldT)
         self.recs.append(_AttnRec(qkv, qkvT, ldT, P, a, nh, d, (qo, ko, vo, hs)))
         return self._conv_fwd([a], blk.proj_out, ksize=1, res=x, stats=True)
@@ -294,32 +297,33 @@ class UNetTrainer:
         qkv, qkvT, ldT, P, nh, d = rec.qkv, rec.qkvT, rec.ldT, rec.P, rec.nh, rec.d
         qo, ko, vo, hs = rec.lay
         N, T, Cc = qkv.N, qkv.H * qkv.W, rec.a.C
+        Tp = round_up(T, self.prog.epc)
         B = N * nh
         alpha = 1.0 / math.sqrt(d)
         BK = 128 // es
         # dP[b][t][s] = sum_j da[n][t][h*d+j] * v[n][s][h][j]
-        dP = self._shared("attn_dP", B * T * T, torch.float32)
-        self._bop(lambda: bp.gemm(da.t, qkv.t, dP, T, T, d, Cc, 3 * Cc, T, c_f32=True, nb0=N, nb1=nh, sa=(T * Cc, d),
-                                  sb=(T * 3 * Cc, hs), sc=(nh * T * T, T * T), b_off=vo))
-        dS = self._shared("attn_dS", B * T * T)
-        self._call(L.eod_softmax_bwd_rows, ptr(P), T, ptr(dP), T, ptr(dS), dt, B * T, T)
-        ldB = round_up(B * T, BK)
-        dST = self._shared("attn_dST", T * ldB)   # [s][b*T + t]; the transposes write every column up to ldB
-        PT = self._shared("attn_PT", T * ldB)
-        self._call(L.eod_transpose_gather, ptr(dS), dt, B, 1, T, T, ptr(dST), ldB, 1, T, 1, 0, 0, 0, 0, 0)
-        self._call(L.eod_transpose_gather, ptr(P), dt, B, 1, T, T, ptr(PT), ldB, 1, T, 1, 0, 0, 0, 0, 0)
-        daT = self._shared("attn_daT", Cc * ldT)  # [h*d + j][n*T + t]
-        self._call(L.eod_transpose_gather, ptr(da.t), dt, N, 1, T, Cc, ptr(daT), ldT, 1, T, 1, 0, 0, 0, 0, 0)
+        dP = self._shared("attn_dP", B * T * Tp, torch.float32)
+        self._bop(lambda: bp.gemm(da.t, qkv.t, dP, T, T, d, Cc, 3 * Cc, Tp, c_f32=True, nb0=N, nb1=nh, sa=(T * Cc, d),
+                                  sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), b_off=vo))
+        dS = self._shared("attn_dS", B * T * Tp)
+        self._call(L.eod_softmax_bwd_rows, ptr(P), Tp, ptr(dP), Tp, ptr(dS), dt, B * T, T)
+        ldB = round_up(B * Tp, BK)
+        dST = self._shared("attn_dST", Tp * ldB)   # [s][b*Tp + t]; the transposes write every column up to ldB
+        PT = self._shared("attn_PT", Tp * ldB)
+        self._call(L.eod_transpose_gather, ptr(dS), dt, B, 1, T, Tp, ptr(dST), ldB, 1, Tp, 1, 0, 0, 0, 0, 0)
+        self._call(L.eod_transpose_gather, ptr(P), dt, B, 1, T, Tp, ptr(PT), ldB, 1, Tp, 1, 0, 0, 0, 0, 0)
+        daT = self._shared("attn_daT", Cc * ldT)  # [h*d + j][n*Tp + t]
+        self._call(L.eod_transpose_gather, ptr(da.t), dt, N, 1, T, Cc, ptr(daT), ldT, 1, Tp, 1, 0, 0, 0, 0, 0)
         dqkv = bp.act(qkv.N, qkv.H, qkv.W, 3 * Cc)
         # dq[n][t][h][j] = alpha * sum_s dS[b][t][s] * k[n][s][h][j]      (k^T rows from qkvT)
-        self._bop(lambda: bp.gemm(dS, qkvT, dqkv.t, T, d, T, T, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T * T, T * T),
-                                  sb=(T, hs * ldT), sc=(T * 3 * Cc, hs), b_off=ko * ldT, c_off=qo))
+        self._bop(lambda: bp.gemm(dS, qkvT, dqkv.t, T, d, Tp, Tp, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T * Tp, T * Tp),
+                                  sb=(Tp, hs * ldT), sc=(T * 3 * Cc, hs), b_off=ko * ldT, c_off=qo))
         # dk[n][s][h][j] = alpha * sum_t dS[b][t][s] * q[n][t][h][j]      (dS^T and q^T)
-        self._bop(lambda: bp.gemm(dST, qkvT, dqkv.t, T, d, T, ldB, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T, T),
-                                  sb=(T, hs * ldT), sc=(T * 3 * Cc, hs), b_off=qo * ldT, c_off=ko))
+        self._bop(lambda: bp.gemm(dST, qkvT, dqkv.t, T, d, Tp, ldB, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * Tp, Tp),
+                                  sb=(Tp, hs * ldT), sc=(T * 3 * Cc, hs), b_off=qo * ldT, c_off=ko))
         # dv[n][s][h][j] = sum_t P[b][t][s] * da[n][t][h*d+j]
-        self._bop(lambda: bp.gemm(PT, daT, dqkv.t, T, d, T, ldB, ldT, 3 * Cc, nb0=N, nb1=nh, sa=(nh * T, T),
-                                  sb=(T, d * ldT), sc=(T * 3 * Cc, hs), c_off=vo))
+        self._bop(lambda: bp.gemm(PT, daT, dqkv.t, T, d, Tp, ldB, ldT, 3 * Cc, nb0=N, nb1=nh, sa=(nh * Tp, Tp),
+                                  sb=(Tp, d * ldT), sc=(T * 3 * Cc, hs), c_off=vo))
         self._add_grad(qkv, dqkv)
 
     def _seq(self, seq, h):
@@ -409,13 +413,13 @@ class UNetTrainer:
         self._temb_bwd()
         bp.finalize()
 
-    def _wgrad(self, rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy=None):
+    def _wgrad(self, rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy=None, Wp=None):
         """dW of one conv from the transposed output gradient dYt [rows][ld] (see csrc/train.hip).
         shift_dy = (buffer, per, margin): 3x3 / stride-1 convs whose inputs are wider than their output shift the OUTPUT gradient
         instead of the input (three dx-shifted copies of dY, ONE copy of every input source; the dy taps are the -+W offsets
         of the dY copies)."""
         L, bp, dt, es = self.L, self.bprog, self.dt, self.es
-        N, Ho, Wo = dy.N, dy.H, dy.W
+        N, Ho, Wo = dy.N, dy.H, (Wp or dy.W)  # Wo = pitch of a pixel row in the transposed operands
         ks, stride = rec.ksize, rec.stride
         taps = ks * ks
         conv = rec.conv
@@ -488,11 +492,12 @@ class UNetTrainer:
         conv = rec.conv
         cout = rec.cout_rows or conv.out_channels
         ks, stride = rec.ksize, rec.stride
-        if Wo * es % 16:
-            raise EodError(f"training: map width {Wo} is not a multiple of {16 // es} (weight-gradient GEMM alignment)")
         s1 = ks == 3 and stride == 1
         rp = 1 if s1 else 0
-        K = N * (Ho + 2 * rp) * Wo
+        # GEMM path: pixel rows of the transposed operands are pitched to whole 16-byte chunks (Wp >= Wo); the pad columns
+        # are zero in the un-shifted operand of every product, so they never contribute
+        Wp = round_up(Wo, 16 // es)
+        K = N * (Ho + 2 * rp) * Wp
         BK = 128 // es
         steps = (K + BK - 1) // BK
         cin_max = max(s.C for s in rec.srcs)
@@ -522,17 +527,17 @@ class UNetTrainer:
             self._wgrad_direct(rec, dy, cout)
         elif s1 and dy.C < sum(x.C for x in rec.srcs) and os.environ.get("EOD_WGRAD_SHIFT", "auto") != "x":
             # inputs wider than the output: three dx-shifted copies of dY (pad rows, +-W margins) instead of three of each input
-            ymargin = round_up(Wo, 8)
+            ymargin = round_up(Wp, 8)
             yper = dy.C * ld + 2 * ymargin
             ybuf = bp.empty((3 * yper,), zero=True)
             for kx in range(3):  # dYs_kx[co][(n, hp, w)] = dY[n][hp-1][w - (kx-1)]
-                self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(ybuf) + (kx * yper + ymargin) * es, ld, Ho, Wo,
+                self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(ybuf) + (kx * yper + ymargin) * es, ld, Ho, Wp,
                            1, 1, 1, 2 - kx, 0, rp)
             shift_dy = (ybuf, yper, ymargin)
             dYt = ybuf[yper + ymargin:]  # the un-shifted copy (kx = 1) doubles as the plain transpose for the row sums
         else:
             dYt = bp.empty((dy.C * ld + 16,))
-            self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wo, 1, 0, 0, 0, 0, rp)
+            self._call(L.eod_transpose_gather, ptr(dy.t), dt, N, Ho, Wo, dy.C, ptr(dYt), ld, Ho, Wp, 1, 0, 0, 0, 0, rp)
         if not direct and conv.bias is not None:  # bias gradient = row sums of dYt, in two levels (enough blocks to fill the chip)
             units = ld // BK
             nseg = max(dv for dv in range(1, min(units, 128) + 1) if units % dv == 0)
@@ -541,9 +546,9 @@ class UNetTrainer:
             self._call(L.eod_colsum, ptr(tmp), nseg, cout, ptr(self._param_grad(conv.bias)))
         if not direct and rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
             off = rec.emb[2]
-            self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wo, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
+            self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wp, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
         if not direct:
-            self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy)
+            self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy, Wp)
         if rec.res is not None:
             self._add_grad(rec.res, dy)
         if not rec.src_needs_grad:

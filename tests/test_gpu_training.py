@@ -99,10 +99,10 @@ def test_training_rejects_unbuilt_variants():
                     channel_mult=(1, 2), num_heads=2, dropout=0.1).to(DEV)
     with pytest.raises(EodError):
         UNetTrainer(m, 2, 16, 16, DEV)
-    m = U.UNetModel(28, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
-                    channel_mult=(2, 4)).to(DEV)  # 28 -> 14 -> 7: odd maps are not built yet
+    m = U.UNetModel(20, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
+                    channel_mult=(2, 4, 4, 4)).to(DEV)  # 20 -> 10 -> 5 -> 3: the stride-2 conv of an ODD map is not built yet
     with pytest.raises(EodError):
-        UNetTrainer(m, 2, 28, 28, DEV)
+        UNetTrainer(m, 2, 20, 20, DEV)
 
 
 def test_reference_training_loop_drop_in():
@@ -244,3 +244,21 @@ def test_training_step_factory_variants(prec):
             worst = (name, e)
     assert n_checked > 40
     assert worst[1] < GTOL[prec], f"worst gradient: {worst}"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_training_step_mnist_shape(prec):
+    """BASELINE config 1 shape (28x28, base 32, mults [2,4], scripts/train_mnist.py): map widths 28 / 14 are not multiples of
+    a 16-byte chunk -> pitched pixel rows in the weight-gradient GEMM path; the 14x14 middle attention has T = 196"""
+    from eo_diffusion_amd.training import UNetTrainer
+    m, sd, cfg, x, noise, t = _setup(prec, 28, 32, (2, 4), 1, 2)
+    pred_ref, gref = _oracle_grads(sd, cfg, x, noise, t)
+    tr = UNetTrainer(m, 2, 28, 28, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
+    pred = tr.forward(x.to(DEV), t.to(DEV))
+    assert rel_l2(pred.cpu(), pred_ref) < (2e-5 if prec == "fp32" else 1e-2)
+    tr.backward(2.0 * (pred - noise.to(DEV)) / pred.numel())
+    torch.cuda.synchronize()
+    gmax = max(float(v.norm()) for v in gref.values())
+    worst = max(((n, rel_l2(p.grad.cpu(), gref[n])) for n, p in m.named_parameters() if n in gref and float(gref[n].norm()) > 1e-5 * gmax),
+                key=lambda kv: kv[1])
+    assert worst[1] < GTOL[prec], worst
