@@ -254,9 +254,93 @@ __global__ void softmax_rows_kernel(const float* __restrict__ s, long long lds, 
     for (int i = lane; i < (int)ldp; i += 64) pr[i] = (i < n) ? (T)(expf(sr[i] - m) * inv) : (T)0.0f;
 }
 
+// Long rows (attention over thousands of keys): ONE workgroup per row, the whole row lives in registers (V4 float4 per thread,
+// 256 threads), so the scores are read once, exponentiated once and written once (the wave-per-row kernel above makes three
+// passes over the row and evaluates exp twice per element).  fp16 output uses the fast exp (the result is rounded to 11 bits).
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    const float a = red[0], b = red[1], c = red[2], d = red[3];
+    return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+template <typename T, int V4>
+__global__ __launch_bounds__(256) void softmax_row_block_kernel(const float* __restrict__ s, long long lds, T* __restrict__ p, long long ldp, int n) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const float* sr = s + row * lds;
+    f32x4 v[V4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c + 3 < n) {
+            v[i] = *reinterpret_cast<const f32x4*>(sr + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = (c + e < n) ? sr[c + e] : -INFINITY;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m = fmaxf(m, v[i][e]);
+    }
+    m = block_reduce(m, red, true);
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[i][e] - m;
+            const float ex = sizeof(T) == 2 ? __expf(x) : expf(x);  // exp(-inf) = 0 for the masked tail
+            v[i][e] = ex;
+            sum += ex;
+        }
+    sum = block_reduce(sum, red, false);
+    const float inv = 1.0f / sum;
+    T* pr = p + row * ldp;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c >= ldp) continue;
+        T o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (c + e < n) ? (T)(v[i][e] * inv) : (T)0.0f;
+        if (c + 3 < ldp) {
+            if constexpr (sizeof(T) == 2)
+                *reinterpret_cast<unsigned long long*>(pr + c) = *reinterpret_cast<const unsigned long long*>(o);
+            else
+                *reinterpret_cast<f32x4*>(pr + c) = *reinterpret_cast<const f32x4*>(o);
+        } else {
+            for (int e = 0; e < 4 && c + e < ldp; ++e) pr[c + e] = o[e];
+        }
+    }
+}
+
+template <typename T>
+static bool launch_softmax_block(const float* s, long long lds, T* p, long long ldp, long long rows, int n, hipStream_t st) {
+    // needs aligned rows (16-byte loads, 8- / 16-byte stores) and a row that fits V4 <= 16 float4 per thread
+    if (lds % 4 || ldp % 4 || (reinterpret_cast<uintptr_t>(s) & 15) || (reinterpret_cast<uintptr_t>(p) & 15) || ldp > 16384 || n < 1024 || rows > 0x7fffffffLL)
+        return false;
+    const int need = (int)((ldp + 1023) / 1024);
+    const dim3 grid((unsigned)rows), block(256);
+    if (need <= 1) hipLaunchKernelGGL((softmax_row_block_kernel<T, 1>), grid, block, 0, st, s, lds, p, ldp, n);
+    else if (need <= 2) hipLaunchKernelGGL((softmax_row_block_kernel<T, 2>), grid, block, 0, st, s, lds, p, ldp, n);
+    else if (need <= 4) hipLaunchKernelGGL((softmax_row_block_kernel<T, 4>), grid, block, 0, st, s, lds, p, ldp, n);
+    else if (need <= 8) hipLaunchKernelGGL((softmax_row_block_kernel<T, 8>), grid, block, 0, st, s, lds, p, ldp, n);
+    else hipLaunchKernelGGL((softmax_row_block_kernel<T, 16>), grid, block, 0, st, s, lds, p, ldp, n);
+    return true;
+}
+
 extern "C" int eod_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int dtype, int64_t rows, int n,
                                 void* stream) {
     EOD_REQUIRE(s && p && rows > 0 && n > 0 && ldp >= n && lds >= n, "softmax: bad args");
+    if (dtype == EOD_F16 ? launch_softmax_block<half_t>(s, (long long)lds, (half_t*)p, (long long)ldp, (long long)rows, n, (hipStream_t)stream)
+                         : launch_softmax_block<float>(s, (long long)lds, (float*)p, (long long)ldp, (long long)rows, n, (hipStream_t)stream)) {
+        EOD_CHECK_LAUNCH("softmax_rows");
+        return EOD_OK;
+    }
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (dtype == EOD_F16)
         hipLaunchKernelGGL(softmax_rows_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, (long long)lds, (half_t*)p, (long long)ldp, (long long)rows, n);

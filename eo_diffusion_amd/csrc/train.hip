@@ -17,6 +17,11 @@
 #include "common.h"
 
 template <typename T> __device__ __forceinline__ T cvt_to(float v) { return (T)v; }
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // weights for backward-data: OIHW fp32 -> [tap'][ci - ci0][cout_pad], tap' = taps-1-tap (180-degree flip), i.e. the
@@ -643,9 +648,90 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const T* __restri
     for (int j = lane; j < (int)ldp; j += 64) o_[j] = j < n ? (T)((float)p[j] * (g[j] - acc)) : (T)0.0f;
 }
 
+// long rows: one workgroup per row, P and dP held in registers (read once), see softmax_row_block_kernel in norm.hip
+template <typename T, int V4>
+__global__ __launch_bounds__(256) void softmax_bwd_row_block_kernel(const T* __restrict__ P, long long ldp, const float* __restrict__ dP, long long lds,
+                                                                    T* __restrict__ dS, int n) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const T* pr = P + row * ldp;
+    const float* gr = dP + row * lds;
+    float pv[V4][4], gv[V4][4];
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[i][e] = gv[i][e] = 0.0f;
+        if (c + 3 < n) {
+            T t4[4];
+            if constexpr (sizeof(T) == 2)
+                *reinterpret_cast<unsigned long long*>(t4) = *reinterpret_cast<const unsigned long long*>(pr + c);
+            else
+                *reinterpret_cast<f32x4*>(t4) = *reinterpret_cast<const f32x4*>(pr + c);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pv[i][e] = (float)t4[e];
+                gv[i][e] = g4[e];
+            }
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (c + e < n) {
+                    pv[i][e] = (float)pr[c + e];
+                    gv[i][e] = gr[c + e];
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += gv[i][e] * pv[i][e];
+    }
+    acc = wave_sum_t(acc);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = acc;
+    __syncthreads();
+    acc = (red[0] + red[1]) + (red[2] + red[3]);
+    T* o_ = dS + row * ldp;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c >= ldp) continue;
+        T o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (c + e < n) ? (T)(pv[i][e] * (gv[i][e] - acc)) : (T)0.0f;
+        if (c + 3 < ldp) {
+            if constexpr (sizeof(T) == 2)
+                *reinterpret_cast<unsigned long long*>(o_ + c) = *reinterpret_cast<const unsigned long long*>(o);
+            else
+                *reinterpret_cast<f32x4*>(o_ + c) = *reinterpret_cast<const f32x4*>(o);
+        } else {
+            for (int e = 0; e < 4 && c + e < ldp; ++e) o_[c + e] = o[e];
+        }
+    }
+}
+
+template <typename T>
+static bool launch_softmax_bwd_block(const T* P, long long ldp, const float* dP, long long lds, T* dS, long long rows, int n, hipStream_t st) {
+    if (lds % 4 || ldp % 4 || (reinterpret_cast<uintptr_t>(P) & 15) || (reinterpret_cast<uintptr_t>(dP) & 15) || (reinterpret_cast<uintptr_t>(dS) & 15) ||
+        ldp > 16384 || n < 1024 || rows > 0x7fffffffLL)
+        return false;
+    const int need = (int)((ldp + 1023) / 1024);
+    const dim3 grid((unsigned)rows), block(256);
+    if (need <= 1) hipLaunchKernelGGL((softmax_bwd_row_block_kernel<T, 1>), grid, block, 0, st, P, ldp, dP, lds, dS, n);
+    else if (need <= 2) hipLaunchKernelGGL((softmax_bwd_row_block_kernel<T, 2>), grid, block, 0, st, P, ldp, dP, lds, dS, n);
+    else if (need <= 4) hipLaunchKernelGGL((softmax_bwd_row_block_kernel<T, 4>), grid, block, 0, st, P, ldp, dP, lds, dS, n);
+    else if (need <= 8) hipLaunchKernelGGL((softmax_bwd_row_block_kernel<T, 8>), grid, block, 0, st, P, ldp, dP, lds, dS, n);
+    else hipLaunchKernelGGL((softmax_bwd_row_block_kernel<T, 16>), grid, block, 0, st, P, ldp, dP, lds, dS, n);
+    return true;
+}
+
 extern "C" int eod_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lds, void* dS, int dtype, int64_t rows, int n,
                                     void* stream) {
     EOD_REQUIRE(P && dP && dS && rows > 0 && n > 0 && ldp >= n && lds >= n, "softmax_bwd_rows: bad args");
+    if (dtype == EOD_F16 ? launch_softmax_bwd_block<half_t>((const half_t*)P, (long long)ldp, dP, (long long)lds, (half_t*)dS, (long long)rows, n, (hipStream_t)stream)
+                         : launch_softmax_bwd_block<float>((const float*)P, (long long)ldp, dP, (long long)lds, (float*)dS, (long long)rows, n, (hipStream_t)stream)) {
+        EOD_CHECK_LAUNCH("softmax_bwd_rows");
+        return EOD_OK;
+    }
     const long long blocks = (rows + 3) / 4;
     EOD_REQUIRE(blocks <= 0x7fffffffLL, "softmax_bwd_rows: too many rows");
     if (dtype == EOD_F16)

@@ -249,3 +249,33 @@ def test_head_conv_nchw_f32(prec, dims, fused_gn):
     hin = F.silu(F.group_norm(x, 32, gam, bet, eps=1e-5)) if fused_gn else x
     ref = F.conv2d(hin, w, b, padding=1)
     assert rel_l2(out.cpu(), ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("n,ld", [(1024, 1024), (1500, 1504), (4096, 4096), (16384, 16384)])
+def test_softmax_long_rows_forward_and_backward(prec, n, ld):
+    """attention rows of thousands of keys: the one-workgroup-per-row kernels (row in registers, one pass) for the softmax
+    (unet_openai.py:479) and its backward, ragged length with zeroed pad columns"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    rows = 9
+    dt = _lib.EOD_F16 if prec == "fp16" else _lib.EOD_F32
+    tdt = torch.float16 if prec == "fp16" else torch.float32
+    s = synth_input(f"sl{n}", (rows, ld), 5, scale=3.0)
+    sd = s.to(DEV)
+    p = torch.full((rows, ld), 7.0, dtype=tdt, device=DEV)
+    st = current_stream_ptr(torch.device(DEV))
+    _lib.check(L.eod_softmax_rows(sd.data_ptr(), ld, p.data_ptr(), ld, dt, rows, n, st), "softmax")
+    ref = torch.softmax(s[:, :n].double(), -1)
+    assert rel_l2(p.float().cpu()[:, :n], ref.float()) < (2e-6 if prec == "fp32" else 2e-3)
+    assert float(p.float().cpu()[:, n:].abs().max() if ld > n else 0.0) == 0.0
+    # backward: dS = P * (dP - sum(dP * P)) with the P the kernel stored
+    dp = synth_input(f"sg{n}", (rows, ld), 6).to(DEV)
+    ds = torch.full((rows, ld), 3.0, dtype=tdt, device=DEV)
+    _lib.check(L.eod_softmax_bwd_rows(p.data_ptr(), ld, dp.data_ptr(), ld, ds.data_ptr(), dt, rows, n, st), "softmax_bwd")
+    pf = p.float().cpu()[:, :n].double()
+    g = dp.cpu()[:, :n].double()
+    ref_ds = pf * (g - (g * pf).sum(-1, keepdim=True))
+    assert rel_l2(ds.float().cpu()[:, :n], ref_ds.float()) < (2e-6 if prec == "fp32" else 2e-3)
+    assert float(ds.float().cpu()[:, n:].abs().max() if ld > n else 0.0) == 0.0
