@@ -1099,3 +1099,146 @@ extern "C" int eod_channel_sums_finish(const float* part, int N, int P, int C, i
     EOD_CHECK_LAUNCH("channel_sums_finish");
     return EOD_OK;
 }
+
+// =============================================================================================
+// gemm_tn_kernel (fp16): C[m][n] = alpha * sum_k A[k][m] * B[k][n]  with BOTH operands stored K-major (row k holds the m / n
+// values contiguously) -- the layout of the attention backward's  dV = P^T dO  and  dK = dS^T Q  (P, dS are [query][key],
+// dO / Q are [query][channel]): K = queries.  Same machinery as conv3x3_wgrad_kernel: 64-row K strips staged row-major by
+// LDS-DMA (256-byte rows = 128 columns), operand fragments through ds_read_b64_tr_b16, so the T x T matrices are never
+// transposed in HBM.  128 x 128 tile per workgroup (columns beyond N are zero-filled by the buffer bounds check), two-level
+// batch strides, fp16 output.
+// =============================================================================================
+struct GemmTnP {
+    const char* a;
+    const char* b;
+    char* c;
+    long long lda, ldb, ldc, sa0, sa1, sb0, sb1, sc0, sc1;  // elements
+    int M, N, K, nb1, tiles_m, tiles_n;
+    float alpha;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnP p) {
+    constexpr int ROWS = 64, ROWB = 256, TILE = ROWS * ROWB, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A tile | B tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bidx = blockIdx.x;
+    const int tile_n = bidx % p.tiles_n; bidx /= p.tiles_n;
+    const int tile_m = bidx % p.tiles_m;
+    const int z = bidx / p.tiles_m;
+    const int b0 = z / p.nb1, b1 = z - b0 * p.nb1;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const char* A = p.a + (b0 * p.sa0 + b1 * p.sa1) * 2;
+    const char* B = p.b + (b0 * p.sb0 + b1 * p.sb1) * 2;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(B), 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int drow = lane >> 4, dslot = lane & 15;
+    auto issue = [&](int strip, int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave + 4 * i) * 4 + drow;
+            const int chunk = dslot ^ wg_swz(row);
+            const long long k = (long long)strip * 64 + row;
+            const int cm = m0 + chunk * 8, cn = n0 + chunk * 8;
+            const unsigned va = (k < p.K && cm < p.M) ? (unsigned)((k * p.lda + cm) * 2) : OOB;
+            const unsigned vb = (k < p.K && cn < p.N) ? (unsigned)((k * p.ldb + cn) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sa + (wave + 4 * i) * 1024), 16, va, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + (wave + 4 * i) * 1024), 16, vb, 0, 0, 0);
+        }
+    };
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    auto tr_addr = [&](int row, int col) { return row * ROWB + (((col >> 3) ^ wg_swz(row)) << 4) + ((col >> 2) & 1) * 8; };
+    int a_ad[2][2], b_ad[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (g >> 1) * 8 + j * 4 + q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a_ad[j][i] = tr_addr(row, wm * 64 + i * 32 + (g & 1) * 16 + 4 * pp);
+            b_ad[j][i] = TILE + tr_addr(row, wn * 64 + i * 32 + (g & 1) * 16 + 4 * pp);
+        }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int strips = (p.K + 63) / 64;
+    issue(0, 0);
+    for (int s = 0; s < strips; ++s) {
+        const int stage = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < strips) issue(s + 1, stage ^ 1);
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const fp16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + a_ad[0][i] + ks * 4096));
+                const fp16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + a_ad[1][i] + ks * 4096));
+                const fp16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[0][i] + ks * 4096));
+                const fp16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(sb + b_ad[1][i] + ks * 4096));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    fa[i][e] = (half_t)alo[e];
+                    fa[i][4 + e] = (half_t)ahi[e];
+                    fb[i][e] = (half_t)blo[e];
+                    fb[i][4 + e] = (half_t)bhi[e];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    half_t* C = reinterpret_cast<half_t*>(p.c) + b0 * p.sc0 + b1 * p.sc1;
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M && n < p.N) C[(long long)m * p.ldc + n] = (half_t)(acc[i][j][r] * p.alpha);
+            }
+        }
+}
+
+extern "C" int eod_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc, int dtype, int M, int N, int K,
+                           float alpha, int nb0, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1,
+                           void* stream) {
+    EOD_REQUIRE(a && b && c && M > 0 && N > 0 && K > 0 && nb0 > 0 && nb1 > 0, "gemm_tn: bad args");
+    EOD_REQUIRE(dtype == EOD_F16, "gemm_tn: fp16 only (transposed LDS reads are 16-bit)");
+    EOD_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && M % 8 == 0 && N % 8 == 0 && sa0 % 8 == 0 && sa1 % 8 == 0 && sb0 % 8 == 0 && sb1 % 8 == 0 &&
+                    eod_aligned16(a) && eod_aligned16(b),
+                "gemm_tn: leading dimensions, M, N and batch strides must be multiples of 8 elements, pointers 16-byte aligned");
+    EOD_REQUIRE((long long)K * lda * 2 < 0x7fffffffLL && (long long)K * ldb * 2 < 0x7fffffffLL, "gemm_tn: one batch operand exceeds the 2 GiB window");
+    GemmTnP p;
+    p.a = (const char*)a; p.b = (const char*)b; p.c = (char*)c;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sa0 = sa0; p.sa1 = sa1; p.sb0 = sb0; p.sb1 = sb1; p.sc0 = sc0; p.sc1 = sc1;
+    p.M = M; p.N = N; p.K = K; p.nb1 = nb1; p.alpha = alpha;
+    p.tiles_m = (M + 127) / 128;
+    p.tiles_n = (N + 127) / 128;
+    const long long grid = (long long)p.tiles_m * p.tiles_n * nb0 * nb1;
+    EOD_REQUIRE(grid <= 0x7fffffffLL, "gemm_tn: grid too large");
+    const size_t lds = 2 * 2 * 64 * 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
+    EOD_CHECK_LAUNCH("gemm_tn");
+    return EOD_OK;
+}

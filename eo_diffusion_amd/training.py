@@ -307,23 +307,31 @@ class UNetTrainer:
                                   sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), b_off=vo))
         dS = self._shared("attn_dS", B * T * Tp)
         self._call(L.eod_softmax_bwd_rows, ptr(P), Tp, ptr(dP), Tp, ptr(dS), dt, B * T, T)
-        ldB = round_up(B * Tp, BK)
-        dST = self._shared("attn_dST", Tp * ldB)   # [s][b*Tp + t]; the transposes write every column up to ldB
-        PT = self._shared("attn_PT", Tp * ldB)
-        self._call(L.eod_transpose_gather, ptr(dS), dt, B, 1, T, Tp, ptr(dST), ldB, 1, Tp, 1, 0, 0, 0, 0, 0)
-        self._call(L.eod_transpose_gather, ptr(P), dt, B, 1, T, Tp, ptr(PT), ldB, 1, Tp, 1, 0, 0, 0, 0, 0)
-        daT = self._shared("attn_daT", Cc * ldT)  # [h*d + j][n*Tp + t]
-        self._call(L.eod_transpose_gather, ptr(da.t), dt, N, 1, T, Cc, ptr(daT), ldT, 1, Tp, 1, 0, 0, 0, 0, 0)
         dqkv = bp.act(qkv.N, qkv.H, qkv.W, 3 * Cc)
         # dq[n][t][h][j] = alpha * sum_s dS[b][t][s] * k[n][s][h][j]      (k^T rows from qkvT)
         self._bop(lambda: bp.gemm(dS, qkvT, dqkv.t, T, d, Tp, Tp, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T * Tp, T * Tp),
                                   sb=(Tp, hs * ldT), sc=(T * 3 * Cc, hs), b_off=ko * ldT, c_off=qo))
-        # dk[n][s][h][j] = alpha * sum_t dS[b][t][s] * q[n][t][h][j]      (dS^T and q^T)
-        self._bop(lambda: bp.gemm(dST, qkvT, dqkv.t, T, d, Tp, ldB, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * Tp, Tp),
-                                  sb=(Tp, hs * ldT), sc=(T * 3 * Cc, hs), b_off=qo * ldT, c_off=ko))
-        # dv[n][s][h][j] = sum_t P[b][t][s] * da[n][t][h*d+j]
-        self._bop(lambda: bp.gemm(PT, daT, dqkv.t, T, d, Tp, ldB, ldT, 3 * Cc, nb0=N, nb1=nh, sa=(nh * Tp, Tp),
-                                  sb=(Tp, d * ldT), sc=(T * 3 * Cc, hs), c_off=vo))
+        if self.prog.precision == "fp16" and T % 8 == 0 and os.environ.get("EOD_ATTN_BWD", "tn") != "nt":
+            # dk = alpha * dS^T q and dv = P^T da: both operands are query-major as stored -> gemm_tn_kernel (transposed LDS
+            # reads), the T x T matrices are not transposed in HBM
+            self._call(L.eod_gemm_tn, ptr(dS), Tp, ptr(qkv.t) + qo * es, 3 * Cc, ptr(dqkv.t) + ko * es, 3 * Cc, dt, T, d, T, alpha,
+                       N, nh, nh * T * Tp, T * Tp, T * 3 * Cc, hs, T * 3 * Cc, hs)
+            self._call(L.eod_gemm_tn, ptr(P), Tp, ptr(da.t), Cc, ptr(dqkv.t) + vo * es, 3 * Cc, dt, T, d, T, 1.0,
+                       N, nh, nh * T * Tp, T * Tp, T * Cc, d, T * 3 * Cc, hs)
+        else:
+            ldB = round_up(B * Tp, BK)
+            dST = self._shared("attn_dST", Tp * ldB)   # [s][b*Tp + t]; the transposes write every column up to ldB
+            PT = self._shared("attn_PT", Tp * ldB)
+            self._call(L.eod_transpose_gather, ptr(dS), dt, B, 1, T, Tp, ptr(dST), ldB, 1, Tp, 1, 0, 0, 0, 0, 0)
+            self._call(L.eod_transpose_gather, ptr(P), dt, B, 1, T, Tp, ptr(PT), ldB, 1, Tp, 1, 0, 0, 0, 0, 0)
+            daT = self._shared("attn_daT", Cc * ldT)  # [h*d + j][n*Tp + t]
+            self._call(L.eod_transpose_gather, ptr(da.t), dt, N, 1, T, Cc, ptr(daT), ldT, 1, Tp, 1, 0, 0, 0, 0, 0)
+            # dk[n][s][h][j] = alpha * sum_t dS[b][t][s] * q[n][t][h][j]      (dS^T and q^T)
+            self._bop(lambda: bp.gemm(dST, qkvT, dqkv.t, T, d, Tp, ldB, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * Tp, Tp),
+                                      sb=(Tp, hs * ldT), sc=(T * 3 * Cc, hs), b_off=qo * ldT, c_off=ko))
+            # dv[n][s][h][j] = sum_t P[b][t][s] * da[n][t][h*d+j]
+            self._bop(lambda: bp.gemm(PT, daT, dqkv.t, T, d, Tp, ldB, ldT, 3 * Cc, nb0=N, nb1=nh, sa=(nh * Tp, Tp),
+                                      sb=(Tp, d * ldT), sc=(T * 3 * Cc, hs), c_off=vo))
         self._add_grad(qkv, dqkv)
 
     def _seq(self, seq, h):

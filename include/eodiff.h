@@ -310,6 +310,10 @@ int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, co
 int eod_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
 /* softmax backward on rows (QKVAttention, unet_openai.py:479): dS[r][j] = P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]),
  * P / dS storage dtype with row stride ldp, dP fp32 with row stride lds; columns n..ldp-1 of dS are written as zeros */
+/* C[m][n] = alpha * sum_k A[k][m] * B[k][n], both operands K-major ([K][lda], [K][ldb]), fp16, batched with two stride levels
+ * (batch z = b0*nb1 + b1): dV = P^T dO and dK = dS^T Q of the attention backward without transposing the T x T matrices */
+int eod_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc, int dtype, int M, int N, int K, float alpha,
+                int nb0, int nb1, int64_t sa0, int64_t sa1, int64_t sb0, int64_t sb1, int64_t sc0, int64_t sc1, void* stream);
 int eod_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t lds, void* dS, int dtype, int64_t rows, int n,
                          void* stream);
 /* dense layers of the timestep-embedding MLP (unet_openai.py:597-602,329-335), fp32: dW, db (scaled) and / or din;
