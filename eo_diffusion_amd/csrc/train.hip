@@ -1242,3 +1242,35 @@ extern "C" int eod_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ld
     EOD_CHECK_LAUNCH("gemm_tn");
     return EOD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// D[i0][i1][i2] = sum_{j<d} a[off + j] * b[off + j],  off = i0*s0 + i1*s1 + i2*s2: per-(image, head, query) dot product of
+// the attention output and its gradient (= rowsum(dP * P), the softmax-backward row term, without forming dP)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rowdot_kernel(const T* __restrict__ a, const T* __restrict__ b, long long n0, long long n1, long long n2, long long s0, long long s1,
+                              long long s2, int d, float* __restrict__ out) {
+    const long long total = n0 * n1 * n2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long i2 = i % n2, r = i / n2;
+        const long long i1 = r % n1, i0 = r / n1;
+        const long long off = i0 * s0 + i1 * s1 + i2 * s2;
+        float acc = 0.0f;
+        for (int j = 0; j < d; ++j) acc += (float)a[off + j] * (float)b[off + j];
+        out[i] = acc;
+    }
+}
+
+extern "C" int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, int64_t n1, int64_t n2, int64_t s0, int64_t s1, int64_t s2, int d,
+                          float* out, void* stream) {
+    EOD_REQUIRE(a && b && out && n0 > 0 && n1 > 0 && n2 > 0 && d > 0, "rowdot: bad args");
+    const long long total = (long long)n0 * n1 * n2;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(rowdot_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b, (long long)n0, (long long)n1, (long long)n2, (long long)s0, (long long)s1, (long long)s2, d, out);
+    else
+        hipLaunchKernelGGL(rowdot_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (long long)n0, (long long)n1, (long long)n2, (long long)s0, (long long)s1, (long long)s2, d, out);
+    EOD_CHECK_LAUNCH("rowdot");
+    return EOD_OK;
+}

@@ -301,12 +301,20 @@ class UNetTrainer:
         B = N * nh
         alpha = 1.0 / math.sqrt(d)
         BK = 128 // es
-        # dP[b][t][s] = sum_j da[n][t][h*d+j] * v[n][s][h][j]
-        dP = self._shared("attn_dP", B * T * Tp, torch.float32)
-        self._bop(lambda: bp.gemm(da.t, qkv.t, dP, T, T, d, Cc, 3 * Cc, Tp, c_f32=True, nb0=N, nb1=nh, sa=(T * Cc, d),
-                                  sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), b_off=vo))
         dS = self._shared("attn_dS", B * T * Tp)
-        self._call(L.eod_softmax_bwd_rows, ptr(P), Tp, ptr(dP), Tp, ptr(dS), dt, B * T, T)
+        if Tp == T and os.environ.get("EOD_ATTN_BWD", "tn") != "nt":
+            # dS = P * (dP - D) with dP = da v^T formed in the GEMM's accumulators only: D[n][h][t] = sum_j da*a (= rowsum(dP*P))
+            # first, then the GEMM epilogue (bias_mode 3) subtracts D and multiplies by P -- the fp32 T x T dP never exists
+            D = self._shared("attn_D", B * T, torch.float32)
+            self._call(L.eod_rowdot, ptr(da.t), ptr(rec.a.t), dt, N, nh, T, T * Cc, d, Cc, d, ptr(D))
+            self._bop(lambda: bp.gemm(da.t, qkv.t, dS, T, T, d, Cc, 3 * Cc, Tp, bias=D, bias_mode=3, res=P, nb0=N, nb1=nh,
+                                      sa=(T * Cc, d), sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), b_off=vo))
+        else:
+            # dP[b][t][s] = sum_j da[n][t][h*d+j] * v[n][s][h][j], then the row-wise softmax backward
+            dP = self._shared("attn_dP", B * T * Tp, torch.float32)
+            self._bop(lambda: bp.gemm(da.t, qkv.t, dP, T, T, d, Cc, 3 * Cc, Tp, c_f32=True, nb0=N, nb1=nh, sa=(T * Cc, d),
+                                      sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), b_off=vo))
+            self._call(L.eod_softmax_bwd_rows, ptr(P), Tp, ptr(dP), Tp, ptr(dS), dt, B * T, T)
         dqkv = bp.act(qkv.N, qkv.H, qkv.W, 3 * Cc)
         # dq[n][t][h][j] = alpha * sum_s dS[b][t][s] * k[n][s][h][j]      (k^T rows from qkvT)
         self._bop(lambda: bp.gemm(dS, qkvT, dqkv.t, T, d, Tp, Tp, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T * Tp, T * Tp),

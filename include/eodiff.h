@@ -107,7 +107,8 @@ typedef struct {
     int32_t dtype;     /* dtype of a, b (and res / c unless c_f32) */
     int32_t M, N, K;   /* K must be a multiple of 16 bytes worth of elements */
     int32_t nb0, nb1;
-    int32_t bias_mode; /* 0 none, 1 per column n, 2 per row m */
+    int32_t bias_mode; /* 0 none, 1 per column n, 2 per row m, 3 = softmax-backward epilogue: bias is [batch][M], and
+                          c = res * (alpha*acc - bias[z][m])  (dS = P * (dP - rowsum(dP*P)), unet_openai.py:479) */
     int32_t c_f32;     /* 1: store c as fp32 regardless of dtype */
     float alpha;
 } eod_gemm_desc;
@@ -308,6 +309,10 @@ int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, float* dgam
 int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype,
                      int N, int HW, int C, int Ctot, int coff, int silu, void* dx, void* stream);
 int eod_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
+/* out[(i0*n1 + i1)*n2 + i2] = sum_{j<d} a[off + j] * b[off + j], off = i0*s0 + i1*s1 + i2*s2 (elements): the attention
+ * backward's D[n][head][t] = sum_j dO * O over one head's channels (rowsum(dP * P) without forming dP) */
+int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, int64_t n1, int64_t n2, int64_t s0, int64_t s1, int64_t s2, int d,
+               float* out, void* stream);
 /* softmax backward on rows (QKVAttention, unet_openai.py:479): dS[r][j] = P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]),
  * P / dS storage dtype with row stride ldp, dP fp32 with row stride lds; columns n..ldp-1 of dS are written as zeros */
 /* C[m][n] = alpha * sum_k A[k][m] * B[k][n], both operands K-major ([K][lda], [K][ldb]), fp16, batched with two stride levels
