@@ -39,7 +39,7 @@ class TembDesc(C.Structure):
 
 
 class AttnDesc(C.Structure):
-    _fields_ = [("qk", vp), ("vT", vp), ("out", vp), ("ld_qk", i64), ("ldt", i64), ("dtype", i32), ("N", i32), ("T", i32),
+    _fields_ = [("qk", vp), ("vT", vp), ("out", vp), ("lse", vp), ("ld_qk", i64), ("ldt", i64), ("dtype", i32), ("N", i32), ("T", i32),
                 ("C", i32), ("heads", i32), ("d", i32), ("dpad", i32), ("k_off", i32)]
 
 

@@ -24,6 +24,7 @@ struct AttnP {
     const half_t* qk;
     const half_t* vT;
     half_t* out;
+    float* lse;
     long long ld_qk, ldt;
     int N, T, C, heads, d, dpad, k_off;
     float scale_log2;  // log2(e) / sqrt(d)
@@ -199,6 +200,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const AttnP p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + lr;
+    if (p.lse && lh == 0 && q < p.T)  // natural-log log-sum-exp of the (scaled) scores of this query: (m + log2 l) * ln 2
+        p.lse[((long long)n * p.heads + h) * p.T + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     if (q < p.T) {
         half_t* op = p.out + ((long long)n * p.T + q) * p.C + h * p.d;
 #pragma unroll
@@ -232,6 +235,7 @@ extern "C" int eod_attention_fwd(const eod_attn_desc* d, void* stream) {
     p.qk = (const half_t*)d->qk;
     p.vT = (const half_t*)d->vT;
     p.out = (half_t*)d->out;
+    p.lse = d->lse;
     p.ld_qk = d->ld_qk;
     p.ldt = d->ldt;
     p.N = d->N; p.T = d->T; p.C = d->C; p.heads = d->heads; p.d = d->d; p.dpad = d->dpad; p.k_off = d->k_off;

@@ -292,7 +292,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                 if (p.bias && p.bias_mode >= 2) {
                     const long long m = (long long)g.tile_m * BM + wm * WM + rw;
                     // mode 3 (softmax-backward epilogue): one value per (batch, row), SUBTRACTED; the result is then multiplied by res
-                    const float br = m < p.M ? (p.bias_mode == 3 ? -p.bias[(long long)blockIdx.y * p.M + m] : p.bias[m]) : 0.0f;
+                    // (mode 4, softmax rebuild: the same subtraction, then exp)
+                    const float br = m < p.M ? (p.bias_mode >= 3 ? -p.bias[(long long)blockIdx.y * p.M + m] : p.bias[m]) : 0.0f;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) cb[j] = br;
                 }
@@ -329,7 +330,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
             OT rr[EPO];
             *reinterpret_cast<i32x4*>(rr) = rv[it];
 #pragma unroll
-            for (int e = 0; e < EPO; ++e) o_[e] = (OT)((!CONV && p.bias_mode == 3) ? v[e] * (float)rr[e] : v[e] + (float)rr[e]);
+            for (int e = 0; e < EPO; ++e) {
+                float ov = v[e] + (float)rr[e];
+                if constexpr (!CONV) {
+                    if (p.bias_mode == 3) ov = v[e] * (float)rr[e];
+                    if (p.bias_mode == 4) ov = sizeof(T) == 2 ? __expf(v[e]) : expf(v[e]);
+                }
+                o_[e] = (OT)ov;
+            }
         }
         if (!ok[it]) continue;
         OT* yo = reinterpret_cast<OT*>(p.y) + off[it];
@@ -1310,7 +1318,8 @@ extern "C" int eod_gemm_nt(const eod_gemm_desc* d, void* stream) {
     p.b = (const char*)d->b;
     p.bias = d->bias;
     p.bias_mode = d->bias ? d->bias_mode : 0;
-    EOD_REQUIRE(d->bias_mode >= 0 && d->bias_mode <= 3 && (d->bias_mode != 3 || (d->bias && d->res)), "gemm: bias_mode %d (mode 3 needs bias and res)", d->bias_mode);
+    EOD_REQUIRE(d->bias_mode >= 0 && d->bias_mode <= 4 && (d->bias_mode != 3 || (d->bias && d->res)) && (d->bias_mode != 4 || (d->bias && !d->res)),
+                "gemm: bias_mode %d (mode 3 needs bias and res, mode 4 bias and no res)", d->bias_mode);
     p.res = (const char*)d->res;
     p.y = (char*)d->c;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc;

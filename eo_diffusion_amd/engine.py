@@ -256,11 +256,11 @@ class Program:
         ss = self.gn_stats(srcs, gamma, beta, eps=eps, groups=groups, film=film, film_stride=film_stride)
         return self.gn_apply(srcs, ss, silu=silu)
 
-    def attention(self, qk, vT, out, N, T, Cc, heads, d, dpad, ld_qk, ldt, k_off):
-        """fused flash-style attention (fp16, head dim <= 64): eod_attention_fwd"""
+    def attention(self, qk, vT, out, N, T, Cc, heads, d, dpad, ld_qk, ldt, k_off, lse=None):
+        """fused flash-style attention (fp16, head dim <= 64): eod_attention_fwd; lse: optional fp32 [N][heads][T] output"""
         op, idx = self._push(OP_ATTN)
         a = op.u.attn
-        a.qk, a.vT, a.out = ptr(qk), ptr(vT), ptr(out)
+        a.qk, a.vT, a.out, a.lse = ptr(qk), ptr(vT), ptr(out), ptr(lse)
         a.ld_qk, a.ldt = ld_qk, ldt
         a.dtype, a.N, a.T, a.C, a.heads, a.d, a.dpad, a.k_off = self.dt, N, T, Cc, heads, d, dpad, k_off
         return idx

@@ -62,8 +62,9 @@ class _PoolRec:
 class _AttnRec:
     """softmax(q k^T / sqrt(d)) v on the natural [N][T][heads x (q|k|v) x d] layout of qkv (QKVAttentionLegacy, :465-481)"""
 
-    def __init__(self, qkv, qkvT, ldT, P, a, nh, d, lay):
+    def __init__(self, qkv, qkvT, ldT, P, a, nh, d, lay, lse=None):
         self.qkv, self.qkvT, self.ldT, self.P, self.a, self.nh, self.d = qkv, qkvT, ldT, P, a, nh, d
+        self.lse = lse  # flash forward: P is NOT kept; the backward rebuilds it from the scores and this log-sum-exp
         self.lay = lay  # (q offset, k offset, v offset, head stride) in channels of the 3C-wide qkv tensor
 
 
@@ -277,6 +278,40 @@ class UNetTrainer:
         ldT = round_up(N * Tp, BK)
         qkvT = prog.empty((3 * Cc * ldT,), zero=True)                        # [3C][n*Tp + t]
         prog._small(OP_TRANSPOSE, p=(ptr(qkv.t), ptr(qkvT)), l=(ldT, 0, 0, 0), i=(self.dt, N, 1, T, 3 * Cc, 1, Tp, 1, 0, 0))
+        flash = (prog.precision == "fp16" and Tp == T and d % 8 == 0 and d <= 64 and os.environ.get("EOD_ATTN_TRAIN", "flash") != "gemm")
+        if flash:
+            # forward = the inference path's fused flash kernel (T x T never materialised) on its own packed q|k / v^T
+            # projections; it also returns the log-sum-exp of every score row, from which the backward rebuilds P
+            qk_rows, v_rows, _, dpad = blk._row_maps(prog.epc)
+            Cq = nh * dpad
+            w2d = blk.qkv.weight.view(3 * Cc, Cc)
+            rm_qk = prog.own(torch.tensor(qk_rows, dtype=torch.int32, device=self.device))
+            rm_v = prog.own(torch.tensor(v_rows, dtype=torch.int32, device=self.device))
+            wqk, wv = prog.empty((len(qk_rows), Cc)), prog.empty((len(v_rows), Cc))
+            bqk, bv = prog.empty((len(qk_rows),), torch.float32), prog.empty((len(v_rows),), torch.float32)
+            idx_qk = torch.tensor([r if r >= 0 else 3 * Cc for r in qk_rows], device=self.device)
+            idx_v = torch.tensor(v_rows, device=self.device)
+
+            def refresh(w2d=w2d, blk=blk):
+                wsrc = blk.qkv.weight.detach().view(3 * Cc, Cc)
+                st = current_stream_ptr(self.device)
+                check(self.L.eod_pack_rows(ptr(wsrc), wsrc.stride(0), ptr(rm_qk), ptr(wqk), Cc, self.dt, len(qk_rows), Cc, st), "pack_rows")
+                check(self.L.eod_pack_rows(ptr(wsrc), wsrc.stride(0), ptr(rm_v), ptr(wv), Cc, self.dt, len(v_rows), Cc, st), "pack_rows")
+                b0 = torch.cat([blk.qkv.bias.detach().float(), blk.qkv.bias.new_zeros(1).float()])
+                torch.index_select(b0, 0, idx_qk, out=bqk)
+                torch.index_select(b0, 0, idx_v, out=bv)
+
+            refresh()
+            self.repack.append(refresh)
+            qk = prog.empty((N * T, 2 * Cq))
+            prog.gemm(xn.t, wqk, qk, N * T, 2 * Cq, Cc, Cc, Cc, 2 * Cq, bias=bqk, bias_mode=1)
+            vT = prog.empty((N, Cc, T), zero=True)
+            prog.gemm(wv, xn.t, vT, Cc, T, Cc, Cc, Cc, T, bias=bv, bias_mode=2, nb0=N, sa=(0, 0), sb=(T * Cc, 0), sc=(Cc * T, 0))
+            lse = prog.empty((N, nh, T), torch.float32)
+            a = prog.act(N, x.H, x.W, Cc)
+            prog.attention(qk, vT, a.t, N, T, Cc, nh, d, dpad, 2 * Cq, T, Cq, lse=lse)
+            self.recs.append(_AttnRec(qkv, qkvT, ldT, None, a, nh, d, (qo, ko, vo, hs), lse))
+            return self._conv_fwd([a], blk.proj_out, ksize=1, res=x, stats=True)
         S = self._shared("attn_S", N * nh * T * Tp, torch.float32)  # only P is kept for the backward
         prog.gemm(qkv.t, qkv.t, S, T, T, d, 3 * Cc, 3 * Cc, Tp, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
                   sa=(T * 3 * Cc, hs), sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), a_off=qo, b_off=ko)
@@ -301,6 +336,10 @@ class UNetTrainer:
         B = N * nh
         alpha = 1.0 / math.sqrt(d)
         BK = 128 // es
+        if P is None:  # flash forward: P = exp(q k^T / sqrt(d) - lse), one GEMM with the exp in its epilogue (bias_mode 4)
+            P = self._shared("attn_P", B * T * Tp)
+            self._bop(lambda: bp.gemm(qkv.t, qkv.t, P, T, T, d, 3 * Cc, 3 * Cc, Tp, alpha=alpha, bias=rec.lse, bias_mode=4, nb0=N, nb1=nh,
+                                      sa=(T * 3 * Cc, hs), sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), a_off=qo, b_off=ko))
         dS = self._shared("attn_dS", B * T * Tp)
         if Tp == T and os.environ.get("EOD_ATTN_BWD", "tn") != "nt":
             # dS = P * (dP - D) with dP = da v^T formed in the GEMM's accumulators only: D[n][h][t] = sum_j da*a (= rowsum(dP*P))

@@ -108,7 +108,8 @@ typedef struct {
     int32_t M, N, K;   /* K must be a multiple of 16 bytes worth of elements */
     int32_t nb0, nb1;
     int32_t bias_mode; /* 0 none, 1 per column n, 2 per row m, 3 = softmax-backward epilogue: bias is [batch][M], and
-                          c = res * (alpha*acc - bias[z][m])  (dS = P * (dP - rowsum(dP*P)), unet_openai.py:479) */
+                          c = res * (alpha*acc - bias[z][m])  (dS = P * (dP - rowsum(dP*P)), unet_openai.py:479);
+                          4 = softmax-rebuild epilogue: c = exp(alpha*acc - bias[z][m])  (P from the scores and their log-sum-exp) */
     int32_t c_f32;     /* 1: store c as fp32 regardless of dtype */
     float alpha;
 } eod_gemm_desc;
@@ -161,6 +162,8 @@ typedef struct {
     const void* qk;
     const void* vT;
     void* out;
+    float* lse;          /* optional OUT [N][heads][T]: log-sum-exp of every score row (natural log) -- what the training path
+                            needs to rebuild P = exp(S - lse) in the backward without keeping the T x T matrix */
     int64_t ld_qk, ldt;
     int32_t dtype, N, T, C, heads, d, dpad, k_off;
 } eod_attn_desc;
