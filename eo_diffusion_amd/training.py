@@ -19,8 +19,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib
-from ._lib import OP_TRANSPOSE, ConvDesc, EodError, check, ptr
+from ._lib import OP_TRANSPOSE, EodError, check, ptr
 from .engine import Act, Program, current_stream_ptr, round_up
 
 
@@ -162,12 +161,6 @@ class UNetTrainer:
             self._scratch_all.append(cur)
         return cur[:numel]
 
-    def _pack(self, fn, param):
-        """packed weight buffer that is re-packed from `param` before every forward"""
-        buf = fn()
-        self.repack.append(fn)
-        return buf
-
     # ------------------------------------------------------------------ forward emission (training form)
     def _conv_fwd(self, srcs, conv, *, ksize=3, stride=1, upsample=False, res=None, emb=None, stats=True, src_needs_grad=True):
         prog = self.prog
@@ -251,10 +244,6 @@ class UNetTrainer:
         if isinstance(layer, U.AttentionBlock):
             return self._attention(layer, h)
         raise EodError(f"training: unsupported layer {type(layer).__name__}")
-
-    def _transpose_op(self, prog, src, N, T, C, dst, ld):
-        """[N][T][C] -> [C][ld] (column n*T + t), as an executor op"""
-        prog._small(OP_TRANSPOSE, p=(ptr(src), ptr(dst)), l=(ld, 0, 0, 0), i=(self.dt, N, 1, T, C, 1, T, 1, 0, 0))
 
     def _attention(self, blk, x):
         """x + proj_out(attention(qkv(GN(x)))), unet_openai.py:427-433, in a form whose every piece has a backward here:

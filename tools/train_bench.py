@@ -4,7 +4,7 @@
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from bench import ARCHS, build_model
+from bench import build_model
 from eo_diffusion_amd.training import UNetTrainer
 
 ap = argparse.ArgumentParser()
