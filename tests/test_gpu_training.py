@@ -262,3 +262,55 @@ def test_training_step_mnist_shape(prec):
     worst = max(((n, rel_l2(p.grad.cpu(), gref[n])) for n, p in m.named_parameters() if n in gref and float(gref[n].norm()) > 1e-5 * gmax),
                 key=lambda kv: kv[1])
     assert worst[1] < GTOL[prec], worst
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    """{"model": model.state_dict(), "model_ema": model_ema.state_dict()} (train.py:137-138) written after a few fused-optimizer
+    steps loads back the way train.py:94-98 and inference.py:79-87 do it; the EMA class keeps AveragedModel's key layout
+    ("n_averaged", "module.<key>"), and the reloaded model reproduces the trained one bit for bit"""
+    import torch.nn as nn
+    from torch.optim.swa_utils import AveragedModel
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    from eo_diffusion_amd.optim import AdamW, ExponentialMovingAverage
+    from tests.helpers import bits_equal
+
+    def make():
+        torch.manual_seed(0)
+        u = U.UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
+                        channel_mult=(1, 2), num_heads=1)
+        for p in u.parameters():
+            if float(p.detach().abs().sum()) == 0.0:
+                nn.init.normal_(p, std=0.02)
+        return EODiffusion(u, timesteps=50, image_size=16, in_channels=3).to(DEV)
+
+    model = make()
+    ema = ExponentialMovingAverage(model, device=DEV, decay=0.9)
+    opt = AdamW(model.parameters(), lr=1e-3)
+    image = synth_input("ck_img", (2, 3, 16, 16), 5, uniform=True).to(DEV)
+    model.train()
+    for step in range(3):
+        torch.manual_seed(step)
+        noise = torch.randn_like(image)
+        loss = nn.functional.mse_loss(model(image, noise), noise)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        ema.update_parameters(model)
+    ckpt = {"model": model.state_dict(), "model_ema": ema.state_dict()}
+    ref_keys = set(AveragedModel(make(), DEV, use_buffers=True).state_dict().keys())
+    assert set(ckpt["model_ema"].keys()) == ref_keys
+    path = tmp_path / "steps_00000003.pt"
+    torch.save(ckpt, path)
+    loaded = torch.load(path)
+    model2, ema2 = make(), ExponentialMovingAverage(make(), device=DEV, decay=0.9)
+    ema2.load_state_dict(loaded["model_ema"])      # train.py:96
+    model2.load_state_dict(loaded["model"])        # train.py:97 / inference.py:86
+    x = synth_input("ck_x", (2, 3, 16, 16), 6).to(DEV)
+    t = torch.tensor([3, 40], device=DEV)
+    model.eval(); model2.eval(); ema.eval(); ema2.eval()
+    with torch.no_grad():
+        assert bits_equal(model.model(x, t), model2.model(x, t))
+        assert bits_equal(ema.module.model(x, t), ema2.module.model(x, t))
+    torch_ema = AveragedModel(make(), DEV, use_buffers=True)   # torch's own class reads the same file
+    torch_ema.load_state_dict(loaded["model_ema"])
