@@ -773,6 +773,8 @@ def unet_train_forward(unet, x, timesteps, cond=None, y=None):
     if tr is None:
         import os
         scale = float(os.environ.get("EOD_LOSS_SCALE", "1024" if unet.precision == "fp16" else "1"))
+        while len(cache) >= 2:  # a trainer owns every saved activation of its shape (tens of GiB at 256x256x16): keep two shapes
+            cache.pop(next(iter(cache)))
         tr = cache[key] = UNetTrainer(unet, N, H, W, x.device, cond_channels=ccond, loss_scale=scale)
     params = [p for p in unet.parameters()]
     return _UNetTrainFn.apply(tr, x.detach(), timesteps, None if cond is None else cond.detach(), y, *params)
