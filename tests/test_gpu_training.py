@@ -105,7 +105,8 @@ def test_training_rejects_unbuilt_variants():
         UNetTrainer(m, 2, 20, 20, DEV)
 
 
-def test_reference_training_loop_drop_in():
+@pytest.mark.parametrize("use_fp16", [False, True])
+def test_reference_training_loop_drop_in(use_fp16):
     """the reference loop verbatim (train.py:109-124): pred = model(image, noise); loss = MSELoss(pred, noise);
     loss.backward(); optimizer.step(); EMA update via AveragedModel (deep copy of the whole EODiffusion, utils.py:56-67).
     Gradients arrive through torch.autograd (accumulating into .grad), the loss falls, sampling from the EMA copy works."""
@@ -115,7 +116,7 @@ def test_reference_training_loop_drop_in():
     from eo_diffusion_amd.diffusion.model import EODiffusion
     torch.manual_seed(0)
     unet = U.UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
-                       channel_mult=(1, 2), num_heads=1)
+                       channel_mult=(1, 2), num_heads=1, use_fp16=use_fp16)  # use_fp16: fp16 storage / MFMA, static loss scale
     for p in unet.parameters():  # zero_module layers re-drawn, else the first predictions are identically 0
         if float(p.detach().abs().sum()) == 0.0:
             nn.init.normal_(p, std=0.02)
