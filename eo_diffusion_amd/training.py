@@ -325,12 +325,20 @@ class UNetTrainer:
         B = N * nh
         alpha = 1.0 / math.sqrt(d)
         BK = 128 // es
+        if P is None and T % 128 == 0 and os.environ.get("EOD_ATTN_BWD", "flash") == "flash":
+            # flash-style backward: P is rebuilt tile by tile in registers from q, k and the forward's log-sum-exp
+            D = self._shared("attn_D", B * T, torch.float32)
+            self._call(L.eod_rowdot, ptr(da.t), ptr(rec.a.t), dt, N, nh, T, T * Cc, d, Cc, d, ptr(D))
+            dqkv = bp.act(qkv.N, qkv.H, qkv.W, 3 * Cc)
+            self._call(L.eod_attention_bwd, ptr(qkv.t), ptr(da.t), ptr(rec.lse), ptr(D), ptr(dqkv.t), dt, N, T, Cc, nh, d, qo, ko, vo, hs)
+            self._add_grad(qkv, dqkv)
+            return
         if P is None:  # flash forward: P = exp(q k^T / sqrt(d) - lse), one GEMM with the exp in its epilogue (bias_mode 4)
             P = self._shared("attn_P", B * T * Tp)
             self._bop(lambda: bp.gemm(qkv.t, qkv.t, P, T, T, d, 3 * Cc, 3 * Cc, Tp, alpha=alpha, bias=rec.lse, bias_mode=4, nb0=N, nb1=nh,
                                       sa=(T * 3 * Cc, hs), sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), a_off=qo, b_off=ko))
         dS = self._shared("attn_dS", B * T * Tp)
-        if Tp == T and os.environ.get("EOD_ATTN_BWD", "tn") != "nt":
+        if Tp == T and os.environ.get("EOD_ATTN_BWD", "flash") != "nt":
             # dS = P * (dP - D) with dP = da v^T formed in the GEMM's accumulators only: D[n][h][t] = sum_j da*a (= rowsum(dP*P))
             # first, then the GEMM epilogue (bias_mode 3) subtracts D and multiplies by P -- the fp32 T x T dP never exists
             D = self._shared("attn_D", B * T, torch.float32)
@@ -347,7 +355,7 @@ class UNetTrainer:
         # dq[n][t][h][j] = alpha * sum_s dS[b][t][s] * k[n][s][h][j]      (k^T rows from qkvT)
         self._bop(lambda: bp.gemm(dS, qkvT, dqkv.t, T, d, Tp, Tp, ldT, 3 * Cc, alpha=alpha, nb0=N, nb1=nh, sa=(nh * T * Tp, T * Tp),
                                   sb=(Tp, hs * ldT), sc=(T * 3 * Cc, hs), b_off=ko * ldT, c_off=qo))
-        if self.prog.precision == "fp16" and T % 8 == 0 and os.environ.get("EOD_ATTN_BWD", "tn") != "nt":
+        if self.prog.precision == "fp16" and T % 8 == 0 and os.environ.get("EOD_ATTN_BWD", "flash") != "nt":
             # dk = alpha * dS^T q and dv = P^T da: both operands are query-major as stored -> gemm_tn_kernel (transposed LDS
             # reads), the T x T matrices are not transposed in HBM
             self._call(L.eod_gemm_tn, ptr(dS), Tp, ptr(qkv.t) + qo * es, 3 * Cc, ptr(dqkv.t) + ko * es, 3 * Cc, dt, T, d, T, alpha,

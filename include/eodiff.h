@@ -318,6 +318,11 @@ int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, int64_t n1, 
                float* out, void* stream);
 /* softmax backward on rows (QKVAttention, unet_openai.py:479): dS[r][j] = P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]),
  * P / dS storage dtype with row stride ldp, dP fp32 with row stride lds; columns n..ldp-1 of dS are written as zeros */
+/* flash-style attention backward (fp16, head dim <= 64, T % 128 == 0): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /
+ * k_off / v_off + head*head_stride + j), dO [N][T][C], the forward's log-sum-exp lse [N][heads][T] (eod_attn_desc.lse) and
+ * D[n][h][t] = sum_j dO*O (eod_rowdot).  P is rebuilt tile by tile in registers: nothing T x T touches HBM (csrc/attn_bwd.hip) */
+int eod_attention_bwd(const void* qkv, const void* dO, const float* lse, const float* D, void* dqkv, int dtype, int N, int T, int C,
+                      int heads, int d, int q_off, int k_off, int v_off, int head_stride, void* stream);
 /* C[m][n] = alpha * sum_k A[k][m] * B[k][n], both operands K-major ([K][lda], [K][ldb]), fp16, batched with two stride levels
  * (batch z = b0*nb1 + b1): dV = P^T dO and dK = dS^T Q of the attention backward without transposing the T x T matrices */
 int eod_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc, int dtype, int M, int N, int K, float alpha,
