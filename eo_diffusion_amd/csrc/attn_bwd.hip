@@ -38,12 +38,12 @@ __device__ __forceinline__ int ab_off(int row, int c) { return row * AB_ROWB + (
 // stage `rows` consecutive sequence positions (starting at t0) of one head's d channels into an LDS tile (rows x 128 B):
 // one DMA instruction = 8 rows x 8 chunks; group g covers rows 8g..8g+7
 __device__ __forceinline__ void ab_stage(const __amdgpu_buffer_rsrc_t rs, long long row_stride_b, long long base_b, int t0, int ngroups, int d,
-                                         char* tile, int wave, int lane, int nwaves) {
+                                         char* tile, int wave, int lane, int nwaves, int T = 0x7fffffff) {
     const int r8 = lane >> 3, slot = lane & 7;
     for (int g = wave; g < ngroups; g += nwaves) {
         const int row = g * 8 + r8;
         const int c = slot ^ ab_swz(row);
-        const unsigned v = c * 8 < d ? (unsigned)(base_b + (long long)(t0 + row) * row_stride_b + c * 16) : 0x80000000u;
+        const unsigned v = (c * 8 < d && t0 + row < T) ? (unsigned)(base_b + (long long)(t0 + row) * row_stride_b + c * 16) : 0x80000000u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_b*)(tile + g * 1024), 16, v, 0, 0, 0);
     }
 }
@@ -295,6 +295,155 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
             }
         }
     }
+}
+
+// =============================================================================================
+// Forward on the NATURAL qkv layout (no packed q|k / transposed v operands): same structure as attn_bwd_q_kernel.  A workgroup owns
+// 128 queries (one wave = 32, lane & 31 = query), walks the key tiles:  S^T = K Q^T (registers = keys), online softmax per lane,
+// O^T += V^T P^T with V^T fetched by transposed LDS reads from the row-major V tile and P^T fed from the accumulator registers
+// (C[m = channel][n = query]: the rescale factor of the online softmax is a per-lane scalar).  Any T (keys beyond T are masked,
+// rows beyond T are zero-filled and not stored); optional log-sum-exp output for the training path.
+// =============================================================================================
+struct AttnFwdP {
+    const char* qkv;
+    char* out;
+    float* lse;
+    int N, T, C, heads, d, q_off, k_off, v_off, hs;
+    float scale_log2;
+};
+
+template <int DS, int DT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;                   // [128][128 B]
+    char* sK = smem + 128 * AB_ROWB;   // [2][64][128 B]
+    char* sV = sK + 2 * 64 * AB_ROWB;  // [2][64][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.y, n = b / p.heads, h = b - n * p.heads;
+    const int q0 = blockIdx.x * 128;
+    const long long rs3 = (long long)3 * p.C * 2;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.qkv) + (long long)n * p.T * rs3, 0, 0x7fffffff, 0x00020000);
+    const long long qb = (long long)(p.q_off + h * p.hs) * 2, kb_ = (long long)(p.k_off + h * p.hs) * 2, vb = (long long)(p.v_off + h * p.hs) * 2;
+    ab_stage(rq, rs3, qb, q0, 16, p.d, sQ, wave, lane, 4, p.T);
+    auto stage_k = [&](int kt, int buf) {
+        ab_stage(rq, rs3, kb_, kt * 64, 8, p.d, sK + buf * 64 * AB_ROWB, wave, lane, 4, p.T);
+        ab_stage(rq, rs3, vb, kt * 64, 8, p.d, sV + buf * 64 * AB_ROWB, wave, lane, 4, p.T);
+    };
+    stage_k(0, 0);
+    f32x16 o[DT];  // O^T tiles: registers = output channel j, lane & 31 = query
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;  // running max (log2 domain) / this lane's share of the running sum
+    const int nkt = (p.T + 63) / 64;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nkt) stage_k(kt + 1, buf ^ 1);
+        const char* tK = sK + buf * 64 * AB_ROWB;
+        const char* tV = sV + buf * 64 * AB_ROWB;
+        f32x16 s[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[mt][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < DS; ++ks) {
+            const half8 fq = ab_row_frag(sQ, wave * 32, ks, lane);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) s[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_row_frag(tK, mt * 32, ks, lane), fq, s[mt], 0, 0, 0);
+        }
+        // ---- online softmax over this tile's 64 keys (32 in this lane's registers, 32 in lane ^ 32) ----
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float t = s[mt][r] * p.scale_log2;
+                t = key < p.T ? t : -INFINITY;
+                s[mt][r] = t;
+                mloc = fmaxf(mloc, t);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);   // finite: every tile has at least one valid key
+        const float alpha = exp2f(m_run - m_new);  // 0 on the first tile
+        m_run = m_new;
+        float lsum = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(s[mt][r] - m_new);
+                s[mt][r] = e;
+                lsum += e;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // ---- O^T += V^T P^T: A = V^T fragment (transposed read of the row-major V tile, permuted key order), B = P^T from registers ----
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const half8 fp = ab_acc_frag(s[mt], kb);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_tr_frag(tV, mt * 32 + 16 * kb, t * 32, lane), fp, o[t], 0, 0, 0);
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + wave * 32 + lr;
+    if (q < p.T) {
+        if (p.lse && lh == 0) p.lse[((long long)n * p.heads + h) * p.T + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+        half_t* op = reinterpret_cast<half_t*>(p.out) + ((long long)n * p.T + q) * p.C + h * p.d;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int j0 = t * 32 + 8 * g4 + 4 * lh;  // registers 4*g4 .. 4*g4+3 = 4 consecutive output channels
+                if (j0 + 3 < p.d) {
+                    half4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (half_t)(o[t][4 * g4 + e] * inv);
+                    *reinterpret_cast<half4*>(op + j0) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j0 + e < p.d) op[j0 + e] = (half_t)(o[t][4 * g4 + e] * inv);
+                }
+            }
+    }
+}
+
+extern "C" int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off,
+                                     int k_off, int v_off, int head_stride, void* stream) {
+    EOD_REQUIRE(qkv && out && N > 0 && T > 0 && heads > 0 && d > 0 && C == heads * d, "attention_fwd_nat: bad args");
+    EOD_REQUIRE(dtype == EOD_F16, "attention_fwd_nat: fp16 only");
+    EOD_REQUIRE(d % 8 == 0 && d <= 64, "attention_fwd_nat: the head dim must be a multiple of 8 and <= 64");
+    EOD_REQUIRE(q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && head_stride % 8 == 0 && eod_aligned16(qkv) && ((uintptr_t)out & 7) == 0,
+                "attention_fwd_nat: alignment of the head slices");
+    EOD_REQUIRE((long long)T * 3 * C * 2 < 0x7fffffffLL, "attention_fwd_nat: one image of qkv exceeds the 2 GiB window");
+    AttnFwdP p;
+    p.qkv = (const char*)qkv; p.out = (char*)out; p.lse = lse;
+    p.N = N; p.T = T; p.C = C; p.heads = heads; p.d = d; p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.hs = head_stride;
+    p.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+    const dim3 grid((T + 127) / 128, N * heads);
+    const size_t lds = (size_t)(128 + 256) * AB_ROWB;
+    hipStream_t st = (hipStream_t)stream;
+    const int ds = (d + 15) / 16;
+    if (ds == 1) hipLaunchKernelGGL((attn_fwd_nat_kernel<1, 1>), grid, dim3(256), lds, st, p);
+    else if (ds == 2) hipLaunchKernelGGL((attn_fwd_nat_kernel<2, 1>), grid, dim3(256), lds, st, p);
+    else if (ds == 3) hipLaunchKernelGGL((attn_fwd_nat_kernel<3, 2>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_nat_kernel<4, 2>), grid, dim3(256), lds, st, p);
+    EOD_CHECK_LAUNCH("attention_fwd_nat");
+    return EOD_OK;
 }
 
 extern "C" int eod_attention_bwd(const void* qkv, const void* dO, const float* lse, const float* D, void* dqkv, int dtype, int N, int T, int C,

@@ -332,3 +332,28 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order):
         for h in range(heads):
             a, b_ = g[:, :, off + h * hs: off + h * hs + d], ref_in.grad[:, :, off + h * hs: off + h * hs + d]
             assert rel_l2(a, b_) < 6e-3, (name, h, rel_l2(a, b_))
+
+
+@pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
+                                                 (64, 4, 8, False)])
+def test_attention_forward_natural_layout(T, heads, d, new_order):
+    """eod_attention_fwd_nat: fused attention straight on the qkv conv output (both channel orders), ragged sequence lengths,
+    with the log-sum-exp output -- vs torch softmax(q k^T / sqrt(d)) v"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    N, C = 2, heads * d
+    qkv = synth_input(f"fn{T}{d}", (N, T, 3 * C), 9, scale=0.8).half()
+    qo, ko, vo, hs = (0, C, 2 * C, d) if new_order else (0, d, 2 * d, 3 * d)
+    pick = lambda off: torch.stack([qkv.float()[:, :, off + h * hs: off + h * hs + d] for h in range(heads)], 1)
+    q, k, v = pick(qo), pick(ko), pick(vo)
+    S = q @ k.transpose(-1, -2) / math.sqrt(d)
+    ref = (torch.softmax(S, -1) @ v).permute(0, 2, 1, 3).reshape(N, T, C)
+    qd = qkv.to(DEV)
+    out = torch.full((N, T, C), 9.0, dtype=torch.float16, device=DEV)
+    lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs,
+                                       current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < 3e-3
+    assert float((lse.cpu() - torch.logsumexp(S, -1)).abs().max()) < 2e-3
