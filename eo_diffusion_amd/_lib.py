@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeodiff.so")
 
 EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
- OP_POOL, OP_ATTN, OP_TRANSPOSE) = range(1, 13)
+ OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT) = range(1, 14)
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 

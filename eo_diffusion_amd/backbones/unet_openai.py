@@ -406,6 +406,21 @@ class AttentionBlock(_Emitter):
         Cc, nh = self.channels, self.num_heads
         assert x.C == Cc
         N, T = x.N, x.HW
+        d_nat = Cc // nh
+        if (prog.precision == "fp16" and d_nat % 8 == 0 and d_nat <= 64 and os.environ.get("EOD_ATTN", "nat") == "nat"):
+            # fused attention straight on the qkv projection's natural channel layout (legacy [h][q|k|v][d], new [q|k|v][h][d]):
+            # one projection GEMM, no packed q|k / transposed v operands (eod_attention_fwd_nat)
+            qo, ko, vo, hs = (0, Cc, 2 * Cc, d_nat) if self.attention.new_order else (0, d_nat, 2 * d_nat, 3 * d_nat)
+            wqkv = prog.pack_rows(self.qkv.weight.view(3 * Cc, Cc))
+            xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps)
+            qkv = prog.empty((N * T, 3 * Cc))
+            prog.gemm(xn.t, wqkv, qkv, N * T, 3 * Cc, Cc, Cc, Cc, 3 * Cc, bias=prog.f32(self.qkv.bias), bias_mode=1)
+            a = prog.empty((N * T, Cc))
+            prog.attention_nat(qkv, a, N, T, Cc, nh, d_nat, qo, ko, vo, hs)
+            out = prog.act(N, x.H, x.W, Cc)
+            prog.gemm(a, prog.pack_rows(self.proj_out.weight.view(Cc, Cc)), out.t, N * T, Cc, Cc, Cc, Cc, Cc, bias=prog.f32(self.proj_out.bias),
+                      bias_mode=1, res=x.t)
+            return out
         qk_rows, v_rows, d, dpad = self._row_maps(prog.epc)
         Cq = nh * dpad
         w2d = self.qkv.weight.view(3 * Cc, Cc)
@@ -429,7 +444,7 @@ class AttentionBlock(_Emitter):
         prog.gemm(wv, xn.t, vT, Cc, T, Cc, Cc, Cc, ldt, bias=bv, bias_mode=2, nb0=N, sa=(0, 0), sb=(T * Cc, 0),
                   sc=(Cc * ldt, 0))
         a = prog.empty((N * T, Cc))
-        fused = prog.precision == "fp16" and dpad <= 64 and d % 4 == 0 and os.environ.get("EOD_ATTN", "flash") != "gemm"
+        fused = prog.precision == "fp16" and dpad <= 64 and d % 4 == 0 and os.environ.get("EOD_ATTN", "nat") != "gemm"
         if fused:
             # flash-style fused kernel: online softmax, the T x T matrix never exists
             prog.attention(qk, vT, a, N, T, Cc, nh, d, dpad, 2 * Cq, ldt, Cq)

@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (OP_ATTN, OP_CONV, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
+from ._lib import (OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
                    OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
 
 PRECISIONS = {"fp32": torch.float32, "fp16": torch.float16}
@@ -265,6 +265,10 @@ class Program:
         a.dtype, a.N, a.T, a.C, a.heads, a.d, a.dpad, a.k_off = self.dt, N, T, Cc, heads, d, dpad, k_off
         return idx
 
+    def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None):
+        """fused attention on the natural qkv layout [N][T][3C] (fp16, head dim % 8 == 0 and <= 64, any T): eod_attention_fwd_nat"""
+        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse)), i=(self.dt, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride))
+
     def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):
         return self._small(OP_SOFTMAX, p=(ptr(s_f32), ptr(p_out)), l=(lds, ldp, rows), i=(self.dt, n))
 
@@ -378,6 +382,11 @@ class Program:
                 a = op.u.attn
                 out.append(dict(kind="attention", flops=4.0 * a.N * a.T * a.T * a.C,
                                 bytes=es * a.N * a.T * a.C * 4, label=f"attn T={a.T} h={a.heads} d={a.d}"))
+            elif k == OP_ATTN_NAT:
+                s = op.u.small
+                n_, t_, c_ = s.i[1], s.i[2], s.i[3]
+                out.append(dict(kind="attention", flops=4.0 * n_ * t_ * t_ * c_, bytes=es * n_ * t_ * c_ * 4,
+                                label=f"attn(nat) T={t_} h={s.i[4]} d={s.i[5]}"))
             elif k == OP_SOFTMAX:
                 s = op.u.small
                 out.append(dict(kind="softmax", flops=0.0, bytes=s.l[2] * (4 * s.i[1] + es * s.l[1]), label="softmax"))

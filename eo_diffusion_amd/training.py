@@ -269,36 +269,11 @@ class UNetTrainer:
         prog._small(OP_TRANSPOSE, p=(ptr(qkv.t), ptr(qkvT)), l=(ldT, 0, 0, 0), i=(self.dt, N, 1, T, 3 * Cc, 1, Tp, 1, 0, 0))
         flash = (prog.precision == "fp16" and Tp == T and d % 8 == 0 and d <= 64 and os.environ.get("EOD_ATTN_TRAIN", "flash") != "gemm")
         if flash:
-            # forward = the inference path's fused flash kernel (T x T never materialised) on its own packed q|k / v^T
-            # projections; it also returns the log-sum-exp of every score row, from which the backward rebuilds P
-            qk_rows, v_rows, _, dpad = blk._row_maps(prog.epc)
-            Cq = nh * dpad
-            w2d = blk.qkv.weight.view(3 * Cc, Cc)
-            rm_qk = prog.own(torch.tensor(qk_rows, dtype=torch.int32, device=self.device))
-            rm_v = prog.own(torch.tensor(v_rows, dtype=torch.int32, device=self.device))
-            wqk, wv = prog.empty((len(qk_rows), Cc)), prog.empty((len(v_rows), Cc))
-            bqk, bv = prog.empty((len(qk_rows),), torch.float32), prog.empty((len(v_rows),), torch.float32)
-            idx_qk = torch.tensor([r if r >= 0 else 3 * Cc for r in qk_rows], device=self.device)
-            idx_v = torch.tensor(v_rows, device=self.device)
-
-            def refresh(w2d=w2d, blk=blk):
-                wsrc = blk.qkv.weight.detach().view(3 * Cc, Cc)
-                st = current_stream_ptr(self.device)
-                check(self.L.eod_pack_rows(ptr(wsrc), wsrc.stride(0), ptr(rm_qk), ptr(wqk), Cc, self.dt, len(qk_rows), Cc, st), "pack_rows")
-                check(self.L.eod_pack_rows(ptr(wsrc), wsrc.stride(0), ptr(rm_v), ptr(wv), Cc, self.dt, len(v_rows), Cc, st), "pack_rows")
-                b0 = torch.cat([blk.qkv.bias.detach().float(), blk.qkv.bias.new_zeros(1).float()])
-                torch.index_select(b0, 0, idx_qk, out=bqk)
-                torch.index_select(b0, 0, idx_v, out=bv)
-
-            refresh()
-            self.repack.append(refresh)
-            qk = prog.empty((N * T, 2 * Cq))
-            prog.gemm(xn.t, wqk, qk, N * T, 2 * Cq, Cc, Cc, Cc, 2 * Cq, bias=bqk, bias_mode=1)
-            vT = prog.empty((N, Cc, T), zero=True)
-            prog.gemm(wv, xn.t, vT, Cc, T, Cc, Cc, Cc, T, bias=bv, bias_mode=2, nb0=N, sa=(0, 0), sb=(T * Cc, 0), sc=(Cc * T, 0))
+            # forward = the inference path's fused kernel on the natural qkv layout (T x T never materialised); it also returns the
+            # log-sum-exp of every score row, from which the backward rebuilds P
             lse = prog.empty((N, nh, T), torch.float32)
             a = prog.act(N, x.H, x.W, Cc)
-            prog.attention(qk, vT, a.t, N, T, Cc, nh, d, dpad, 2 * Cq, T, Cq, lse=lse)
+            prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d, qo, ko, vo, hs, lse=lse)
             self.recs.append(_AttnRec(qkv, qkvT, ldT, None, a, nh, d, (qo, ko, vo, hs), lse))
             return self._conv_fwd([a], blk.proj_out, ksize=1, res=x, stats=True)
         S = self._shared("attn_S", N * nh * T * Tp, torch.float32)  # only P is kept for the backward

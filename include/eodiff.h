@@ -235,7 +235,8 @@ enum {
     EOD_OP_CONV = 1, EOD_OP_GEMM = 2, EOD_OP_GN_PARTIAL = 3, EOD_OP_GN_FINALIZE = 4,
     EOD_OP_GN_APPLY = 5, EOD_OP_SOFTMAX = 6, EOD_OP_TEMB = 7, EOD_OP_TO_NHWC = 8, EOD_OP_TO_NCHW = 9,
     EOD_OP_POOL = 10, EOD_OP_ATTN = 11,
-    EOD_OP_TRANSPOSE = 12 /* eod_transpose_gather (training forward: transposed q|k|v for the attention GEMMs) */
+    EOD_OP_TRANSPOSE = 12, /* eod_transpose_gather (training forward: transposed q|k|v for the attention GEMMs) */
+    EOD_OP_ATTN_NAT = 13   /* eod_attention_fwd_nat */
 };
 typedef struct {
     const void* p[6];
