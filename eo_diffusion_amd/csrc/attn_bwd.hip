@@ -359,34 +359,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
         }
         // ---- online softmax over this tile's 64 keys (32 in this lane's registers, 32 in lane ^ 32) ----
         float mloc = -INFINITY;
+        const bool ragged = (kt + 1) * 64 > p.T;  // wave-uniform: only the last tile of a ragged sequence needs the key mask
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float t = s[mt][r] * p.scale_log2;
-                t = key < p.T ? t : -INFINITY;
+                if (ragged) {
+                    const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    t = key < p.T ? t : -INFINITY;
+                }
                 s[mt][r] = t;
                 mloc = fmaxf(mloc, t);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);   // finite: every tile has at least one valid key
-        const float alpha = exp2f(m_run - m_new);  // 0 on the first tile
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // raw v_exp_f32: arguments are <= 0; 0 on the first tile
         m_run = m_new;
         float lsum = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[mt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(s[mt][r] - m_new);
                 s[mt][r] = e;
                 lsum += e;
             }
         l_run = l_run * alpha + lsum;
+        if (__any(alpha != 1.0f)) {  // wave-uniform skip: once the running maxima have settled nothing needs rescaling
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
         // ---- O^T += V^T P^T: A = V^T fragment (transposed read of the row-major V tile, permuted key order), B = P^T from registers ----
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
