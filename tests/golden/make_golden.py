@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training]
 
 The reference never travels to the GPU box; only the .npz / .json data written here does.
 Harness-side adaptations (NOT reference behaviour):
@@ -351,11 +351,56 @@ def gen_sampler():
     save("ddim_steps_S250_T1000", **arrs)
 
 
+def gen_training():
+    """Training step of the reference (train.py:109-118): pred = UNet(x, t); loss = nn.MSELoss()(pred, noise); loss.backward().
+    Full gradients would be several MB per config, so the fixture keeps, per parameter tensor, its L2 norm and its dot product
+    with a fixed synthetic direction (two numbers that pin every tensor of the gradient), plus loss and pred."""
+    print("training")
+    for name in ("u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls", "u_mnist"):
+        kw = UNETS[name]
+        u = R.UNetModel(**kw).train()
+        load_synth(u, 7)
+        n, hw, cin, cout = 2, kw["image_size"], kw["in_channels"], kw["out_channels"]
+        t = torch.tensor([3, 17], dtype=torch.int64)
+        cond = y = None
+        if name == "u_cond_cls":
+            x = synth_input(name + "_tr", (n, 3, hw, hw), 2)
+            cond = synth_input(name + "_trc", (n, 4, hw, hw), 2, uniform=True)
+            y = torch.tensor([1, 4])
+        else:
+            x = synth_input(name + "_tr", (n, cin, hw, hw), 2)
+        noise = synth_input(name + "_trn", (n, cout, hw, hw), 3)
+        pred = u(x, t, cond=cond, y=y)
+        loss = torch.nn.MSELoss(reduction="mean")(pred, noise)
+        loss.backward()
+        arrs = dict(x=x, t=t, noise=noise, pred=pred.detach(), loss=loss.detach().reshape(1))
+        if cond is not None:
+            arrs.update(cond=cond, y=y)
+        names, norms, dots = [], [], []
+        for k, p in u.named_parameters():
+            if p.grad is None:
+                continue
+            g = p.grad.detach().double().flatten()
+            direction = synth_input("dir:" + k, (g.numel(),), 5).double()
+            names.append(k)
+            norms.append(float(g.norm()))
+            dots.append(float((g * direction).sum()))
+        arrs.update(grad_norm=np.asarray(norms), grad_dot=np.asarray(dots))
+        save("train_grads_" + name, **arrs)
+        with open(os.path.join(HERE, "train_grads_" + name + "_keys.json"), "w") as f:
+            json.dump(names, f)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 2 and sys.argv[2] == "training":
+        gen_training()
+        print("done")
+        sys.exit(0)
     gen_schedules()
     gen_modules()
     gen_unets()
     gen_keys()
     gen_sampler()
+    gen_training()
     print("done")

@@ -315,3 +315,45 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
         assert bits_equal(ema.module.model(x, t), ema2.module.model(x, t))
     torch_ema = AveragedModel(make(), DEV, use_buffers=True)   # torch's own class reads the same file
     torch_ema.load_state_dict(loaded["model_ema"])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("name", ["u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls", "u_mnist"])
+def test_training_gradients_vs_reference_golden(prec, name):
+    """HIP forward + backward vs gradients computed by the REFERENCE itself (tests/golden/train_grads_*.npz, generated by
+    importing /root/reference: per-parameter L2 norm and projection on a fixed synthetic direction, loss, prediction)"""
+    import json
+    import os
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from eo_diffusion_amd.training import UNetTrainer
+    from tests.helpers import GOLDEN, gload, unet_cfgs
+    g = gload("train_grads_" + name)
+    keys = json.load(open(os.path.join(GOLDEN, f"train_grads_{name}_keys.json")))
+    cfg = unet_cfgs()[name]
+    m = U.UNetModel(**cfg).set_precision(prec)
+    m.load_state_dict(synth_state_dict(U.unet_param_shapes(**cfg), 7))
+    m = m.to(DEV).train()
+    tt = lambda k: torch.from_numpy(g[k]).to(DEV)
+    has_cond, has_y = "cond" in g, "y" in g
+    tr = UNetTrainer(m, 2, cfg["image_size"], cfg["image_size"], DEV, cond_channels=(g["cond"].shape[1] if has_cond else 0),
+                     loss_scale=(256.0 if prec == "fp16" else 1.0))
+    pred = tr.forward(tt("x"), tt("t"), cond=tt("cond") if has_cond else None, y=tt("y") if has_y else None)
+    assert rel_l2(pred.cpu(), torch.from_numpy(g["pred"])) < (2e-5 if prec == "fp32" else 1e-2)
+    noise = tt("noise")
+    tr.backward(2.0 * (pred - noise) / pred.numel())
+    torch.cuda.synchronize()
+    tol = GTOL[prec]
+    params = dict(m.named_parameters())
+    gmax = float(g["grad_norm"].max())
+    checked = 0
+    for i, k in enumerate(keys):
+        ref_n, ref_d = float(g["grad_norm"][i]), float(g["grad_dot"][i])
+        gr = params[k].grad.double().flatten().cpu()
+        if ref_n < 1e-5 * gmax:
+            assert float(gr.norm()) < 1e-3 * gmax, k
+            continue
+        direction = synth_input("dir:" + k, (gr.numel(),), 5).double()
+        assert abs(float(gr.norm()) - ref_n) < tol * ref_n, (k, float(gr.norm()), ref_n)
+        assert abs(float((gr * direction).sum()) - ref_d) < tol * ref_n * float(direction.norm()), k
+        checked += 1
+    assert checked > 20

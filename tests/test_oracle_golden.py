@@ -260,3 +260,34 @@ def test_train_ref_mse_and_ema_vs_torch():
     assert np.allclose(d, ar.grad.numpy(), rtol=1e-6, atol=1e-10)
     avg = TR.ema_update(a.numpy(), b.numpy(), 0.99)
     assert np.allclose(avg, (0.99 * a + (1 - 0.99) * b).numpy(), rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls", "u_mnist"])
+def test_oracle_training_gradients_vs_reference(name):
+    """torch autograd through the oracle UNet + MSE loss (train.py:116-118) vs the gradients of the REFERENCE itself
+    (tests/golden/train_grads_*.npz: per-parameter L2 norm and projection on a fixed direction): pins the training oracle"""
+    import json
+    import os
+    from oracle import unet_ref as UR
+    from tests.helpers import GOLDEN, gload, unet_cfgs
+    from tests.synth import synth_input, synth_state_dict
+    from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
+    g = gload("train_grads_" + name)
+    keys = json.load(open(os.path.join(GOLDEN, f"train_grads_{name}_keys.json")))
+    cfg = unet_cfgs()[name]
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth_state_dict(unet_param_shapes(**cfg), 7).items()}
+    tt = lambda k: torch.from_numpy(g[k])
+    pred = UR.unet_forward(sd, cfg, tt("x"), tt("t"), cond=tt("cond") if "cond" in g else None, y=tt("y") if "y" in g else None)
+    loss = torch.nn.functional.mse_loss(pred, tt("noise"))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"][0])) < 1e-5 * float(g["loss"][0])
+    gmax = float(g["grad_norm"].max())
+    for i, k in enumerate(keys):
+        ref_n, ref_d = float(g["grad_norm"][i]), float(g["grad_dot"][i])
+        gr = sd[k].grad.double().flatten()
+        direction = synth_input("dir:" + k, (gr.numel(),), 5).double()
+        if ref_n < 1e-5 * gmax:
+            assert float(gr.norm()) < 1e-3 * gmax, k
+            continue
+        assert abs(float(gr.norm()) - ref_n) < 1e-4 * ref_n, k
+        assert abs(float((gr * direction).sum()) - ref_d) < 1e-4 * ref_n * float(direction.norm()), k
