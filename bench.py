@@ -279,8 +279,7 @@ def train_main(args, world, rank, dev, use_dist):
         x_t = m._forward_diffusion(x, t, noise)
         pred = tr.forward(x_t, t)
         loss, dpred = mse_loss(pred, noise)
-        tr.backward(dpred)
-        tr.allreduce_grads()
+        tr.backward(dpred, allreduce=True)  # bucketed gradient all-reduce overlapped with the backward (no-op for one rank)
         opt.step()
         return loss
 

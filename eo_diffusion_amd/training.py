@@ -123,6 +123,37 @@ class UNetTrainer:
             off += (p.numel() + 3) // 4 * 4  # 16-byte aligned views
         self.flat_grad = torch.zeros((off,), dtype=torch.float32, device=self.device)
 
+    def _plan_buckets(self, n_buckets=4):
+        """gradient buckets for the OVERLAPPED data-parallel reduction: the flat buffer is cut into n_buckets contiguous ranges;
+        a bucket is complete once the last backward launch that writes into it has been enqueued (found by scanning the launch
+        list for pointers into the range) -- its all-reduce is issued right there and runs on RCCL's stream under the rest of the
+        backward.  Parameters are laid out in forward order and the backward finishes them last-to-first, so the buckets
+        complete from the back of the buffer to the front."""
+        base, total = self.flat_grad.data_ptr(), self.flat_grad.numel()
+        starts = sorted(self._grad_offsets.values())  # bucket boundaries sit ON parameter boundaries: no tensor straddles two buckets
+        cuts = [0]
+        te = [self._grad_offsets[p_] for p_ in self.unet.time_embed.parameters()]
+        after_te = min(o for o in starts if o > max(te)) if te else 0
+        if after_te:  # the timestep MLP's gradients are the last ones to be final: keep them in their own tiny bucket
+            cuts.append(after_te)
+        for k in range(1, n_buckets):
+            c = min(starts, key=lambda o: abs(o - k * total // n_buckets))
+            if c > cuts[-1]:
+                cuts.append(c)
+        cuts.append(total)
+        bounds = list(zip(cuts[:-1], cuts[1:]))
+        ready = [-1] * len(bounds)
+        for i, item in enumerate(self.bwd):
+            if item[0] != "call":
+                continue
+            for a in item[2]:
+                if isinstance(a, int) and base <= a < base + total * 4:
+                    off = (a - base) // 4
+                    for k, (lo, hi) in enumerate(bounds):
+                        if lo <= off < hi:
+                            ready[k] = max(ready[k], i)
+        self._buckets = sorted(zip(ready, bounds), key=lambda rb: rb[0])
+
     def allreduce_grads(self, group=None):
         """data-parallel step (config 5: one rank per GPU): average the gradients of all ranks, one bucket = everything
         (55-88 M fp32 values, a few ms over xGMI)"""
@@ -216,9 +247,9 @@ class UNetTrainer:
         emb_view = self.ctx.out[:, off:]
         if blk.use_scale_shift_norm:  # FiLM (:377-381): emb_out = [scale | shift] modulates the second GroupNorm
             h1 = self._conv_fwd([a1], conv1)
-            a2 = self._gn_fwd([h1], gn2, film=(emb_view, self.ctx.J, off))
+            a2 = self._gn_fwd([h1], gn2, film=(emb_view, self.ctx.J, off, blk.emb_layers[1]))
         else:
-            h1 = self._conv_fwd([a1], conv1, emb=(emb_view, self.ctx.J, off))
+            h1 = self._conv_fwd([a1], conv1, emb=(emb_view, self.ctx.J, off, blk.emb_layers[1]))
             a2 = self._gn_fwd([h1], gn2)
         if isinstance(blk.skip_connection, nn.Identity):
             if len(srcs) != 1:
@@ -551,6 +582,8 @@ class UNetTrainer:
                            ptr(self._param_grad(conv.bias)) if conv.bias is not None else 0,
                            (ptr(self.dout_cat) + rec.emb[2] * 4) if rec.emb is not None else 0, self.ctx.J,
                            ptr(bp.empty((N, cout), torch.float32)))
+            if rec.emb is not None:
+                self._emb_layer_wgrad(rec.emb[2], rec.emb[3])
             self._wgrad_direct(rec, dy, cout)
         elif s1 and dy.C < sum(x.C for x in rec.srcs) and os.environ.get("EOD_WGRAD_SHIFT", "auto") != "x":
             # inputs wider than the output: three dx-shifted copies of dY (pad rows, +-W margins) instead of three of each input
@@ -574,6 +607,7 @@ class UNetTrainer:
         if not direct and rec.emb is not None:  # timestep-embedding projection: per-image sums of the same gradient (kept loss-scaled)
             off = rec.emb[2]
             self._call(L.eod_rowsum_segments, ptr(dYt), dt, cout, ld, N, (Ho + 2 * rp) * Wp, 1.0, ptr(self.dout_cat) + off * 4, self.ctx.J)
+            self._emb_layer_wgrad(off, rec.emb[3])
         if not direct:
             self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy, Wp)
         if rec.res is not None:
@@ -621,9 +655,10 @@ class UNetTrainer:
             self._call(L.eod_gn_bwd_partial, ptr(s.t), ptr(dy.t), ptr(rec.ss), dt, N, HW, s.C, ptr(part), P, ctot, coff, int(rec.silu))
             coff += s.C
         if rec.film is not None:  # d[scale | shift] of the FiLM go to this block's columns of the emb_layers gradient (loss-scaled)
-            fv, fj, foff = rec.film
+            fv, fj, foff = rec.film[:3]
             self._call(L.eod_gn_bwd_finalize, ptr(part), P, ctot, N, HW, groups, ptr(mr), ptr(self.prog.f32(gn.weight)), ptr(self.prog.f32(gn.bias)),
                        ptr(fv), fj, ptr(self.dout_cat) + foff * 4, self.ctx.J, ptr(coef), ptr(gb))
+            self._emb_layer_wgrad(foff, rec.film[3])
         else:
             self._call(L.eod_gn_bwd_finalize, ptr(part), P, ctot, N, HW, groups, ptr(mr), ptr(self.prog.f32(gn.weight)), 0, 0, 0, 0, 0,
                        ptr(coef), ptr(gb))
@@ -636,6 +671,13 @@ class UNetTrainer:
                        N, HW, s.C, ctot, coff, int(rec.silu), ptr(dx.t))
             self._add_grad(s, dx)
             coff += s.C
+
+    def _emb_layer_wgrad(self, off, lin):
+        """weight / bias gradient of one ResBlock's emb_layers Linear, issued as soon as the block's columns of the concatenated
+        gradient exist (so that its parameters are final early and their bucket can be all-reduced under the rest of the backward)"""
+        n = lin.out_features
+        self._call(self.L.eod_linear_bwd_small, ptr(self.dout_cat) + off * 4, self.ctx.J, ptr(self.emb), 0, 0, ptr(self.wcat) + off * self.E * 4, 0,
+                   self.N, self.E, n, 1, self.inv_scale, ptr(self._param_grad(lin.weight)), ptr(self._param_grad(lin.bias)), 0, 0)
 
     def _pool_bwd(self, rec):
         dy = self._take_grad(rec.y)
@@ -656,15 +698,8 @@ class UNetTrainer:
         pre1 = bp.empty((N, E), torch.float32)
         self._t_slot = torch.zeros((N,), dtype=torch.int64, device=self.device)
         tp = self._t_slot.data_ptr()
-        # emb_layers of every ResBlock (rows of the concatenated [J][E] matrix): out = Linear(SiLU(emb));
-        # weight / bias gradients per block (straight into the flat gradient buffer), input gradient for all blocks at once
-        off = 0
-        for blk in self.ctx.blocks:
-            lin = blk.emb_layers[1]
-            n = lin.out_features
-            self._call(L.eod_linear_bwd_small, ptr(self.dout_cat) + off * 4, J, ptr(self.emb), 0, 0, ptr(self.wcat) + off * E * 4, 0, N, E, n, 1, inv,
-                       ptr(self._param_grad(lin.weight)), ptr(self._param_grad(lin.bias)), 0, 0)
-            off += n
+        # emb_layers of every ResBlock: the weight / bias gradients were issued per block (_emb_layer_wgrad); here the gradient
+        # w.r.t. the shared embedding, over all blocks' columns at once
         scratch = bp.empty((32, N, E), torch.float32)
         self._call(L.eod_linear_bwd_small, ptr(self.dout_cat), J, ptr(self.emb), 0, 0, ptr(self.wcat), ptr(self.emb), N, E, J, 1, inv,
                    0, 0, ptr(demb), ptr(scratch))
@@ -704,17 +739,37 @@ class UNetTrainer:
         self.prog.run()
         return self.pred
 
-    def backward(self, dpred, assign=True):
+    def backward(self, dpred, assign=True, allreduce=False, group=None):
         """dpred = dLoss/dpred (NCHW fp32).  assign=True: sets `param.grad` (fp32) of every UNet parameter;
-        assign=False: returns the gradients in `unet.parameters()` order (clones, for torch.autograd accumulation)."""
+        assign=False: returns the gradients in `unet.parameters()` order (clones, for torch.autograd accumulation).
+        allreduce=True (data-parallel training): the gradient buckets are averaged over the ranks of `group`, each bucket's
+        all-reduce is issued as soon as the bucket is complete and overlaps the remaining backward launches."""
         st = current_stream_ptr(self.device)
         torch.mul(dpred, self.loss_scale, out=self.dpred)
         L = self.L
-        for item in self.bwd:
+        pending, world, works = [], 1, []
+        if allreduce:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                world = dist.get_world_size(group)
+            if world > 1 or os.environ.get("EOD_FORCE_ALLREDUCE") == "1":
+                if not hasattr(self, "_buckets"):
+                    self._plan_buckets()
+                pending = list(self._buckets)
+        for i, item in enumerate(self.bwd):
             if item[0] == "op":
                 check(L.eod_program_run(C.byref(item[1]), 1, st), "backward op")
             else:
                 check(item[1](*item[2], st), item[1].__name__)
+            while pending and pending[0][0] <= i:
+                _, (lo, hi) = pending.pop(0)
+                works.append(dist.all_reduce(self.flat_grad[lo:hi], group=group, async_op=True))
+        for _, (lo, hi) in pending:  # buckets nobody writes (cannot happen for a UNet, kept for safety)
+            works.append(dist.all_reduce(self.flat_grad[lo:hi], group=group, async_op=True))
+        for w in works:
+            w.wait()
+        if works and world > 1:
+            self.flat_grad.div_(world)
         if not assign:
             return [self.pgrad[p].to(p.dtype).clone() if p in self.pgrad else torch.zeros_like(p) for p in self.unet.parameters()]
         for p, g in self.pgrad.items():

@@ -357,3 +357,38 @@ def test_training_gradients_vs_reference_golden(prec, name):
         assert abs(float((gr * direction).sum()) - ref_d) < tol * ref_n * float(direction.norm()), k
         checked += 1
     assert checked > 20
+
+
+def test_bucketed_allreduce_overlap_single_rank(monkeypatch):
+    """the overlapped gradient reduction of data-parallel training: bucket plan covers the whole flat gradient buffer, every bucket
+    becomes ready at some backward launch, and driving the real RCCL all-reduce path with a single-rank group (mean over one rank)
+    leaves the gradients unchanged"""
+    import torch.distributed as dist
+    from eo_diffusion_amd.training import UNetTrainer
+    m, sd, cfg, x, noise, t = _setup("fp32", 16, 32, (1, 2), 1, 2)
+    tr = UNetTrainer(m, 2, 16, 16, DEV)
+    xg, ng, tg = x.to(DEV), noise.to(DEV), t.to(DEV)
+    pred = tr.forward(xg, tg)
+    dpred = 2.0 * (pred - ng) / pred.numel()
+    tr.backward(dpred)
+    ref = tr.flat_grad.clone()
+    tr._plan_buckets()
+    spans = sorted(b for _, b in tr._buckets)
+    assert spans[0][0] == 0 and spans[-1][1] == tr.flat_grad.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert all(0 <= r < len(tr.bwd) for r, _ in tr._buckets)
+    created = False
+    if not dist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        monkeypatch.setenv("EOD_FORCE_ALLREDUCE", "1")
+        tr.forward(xg, tg)
+        tr.backward(dpred, allreduce=True)
+        torch.cuda.synchronize()
+        assert torch.equal(tr.flat_grad, ref)
+    finally:
+        if created:
+            dist.destroy_process_group()
