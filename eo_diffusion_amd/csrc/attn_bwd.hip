@@ -13,7 +13,8 @@
 // operand (rows of dO / Q / K, staged row-major in LDS as they lie in HBM) is fetched in the same permuted order with two
 // ds_read_b64_tr_b16 (4 consecutive rows each).  So P / dS never leave the registers.
 // Layout of the operands: qkv [N][T][3C] as produced by the qkv conv (channel = q_off/k_off/v_off + head*head_stride + j),
-// dO / O [N][T][C], lse / D [N][heads][T] fp32, dqkv [N][T][3C].  Requires T % 128 == 0, d % 8 == 0, d <= 64.
+// dO / O [N][T][C], lse / D [N][heads][T] fp32, dqkv [N][T][3C].  Any T (rows / keys beyond T are zero-filled and masked through
+// lse = +inf / P = 0), d % 8 == 0, d <= 64.
 #include "common.h"
 
 typedef __fp16 fp16x4b __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -106,14 +107,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
     const float* lse = p.lse + ((long long)n * p.heads + h) * p.T;
     const float* Dv = p.D + ((long long)n * p.heads + h) * p.T;
 
-    ab_stage(rq, rs3, kb_, s0, 16, p.d, sK, wave, lane, 4);
-    ab_stage(rq, rs3, vb, s0, 16, p.d, sV, wave, lane, 4);
+    ab_stage(rq, rs3, kb_, s0, 16, p.d, sK, wave, lane, 4, p.T);
+    ab_stage(rq, rs3, vb, s0, 16, p.d, sV, wave, lane, 4, p.T);
     auto stage_q = [&](int qt, int buf) {
-        ab_stage(rq, rs3, qb, qt * 64, 8, p.d, sQ + buf * 64 * AB_ROWB, wave, lane, 4);
-        ab_stage(ro, rsC, ob, qt * 64, 8, p.d, sO + buf * 64 * AB_ROWB, wave, lane, 4);
-        if (tid < 64) {
-            sL[buf * 64 + tid] = lse[qt * 64 + tid];
-            sL[128 + buf * 64 + tid] = Dv[qt * 64 + tid];
+        ab_stage(rq, rs3, qb, qt * 64, 8, p.d, sQ + buf * 64 * AB_ROWB, wave, lane, 4, p.T);
+        ab_stage(ro, rsC, ob, qt * 64, 8, p.d, sO + buf * 64 * AB_ROWB, wave, lane, 4, p.T);
+        if (tid < 64) {  // rows beyond T: lse = +inf makes their P exactly 0
+            const bool in = qt * 64 + tid < p.T;
+            sL[buf * 64 + tid] = in ? lse[qt * 64 + tid] : INFINITY;
+            sL[128 + buf * 64 + tid] = in ? Dv[qt * 64 + tid] : 0.0f;
         }
     };
     stage_q(0, 0);
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dv[t][r] = dk[t][r] = 0.0f;
 
-    const int nqt = p.T / 64;
+    const int nqt = (p.T + 63) / 64;
+    const bool key_ok = s0 + wave * 32 + lr < p.T;  // this lane's key column exists (ragged last key tile)
     for (int qt = 0; qt < nqt; ++qt) {
         const int buf = qt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(tD + qrow);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = __expf(s[mt][4 * g4 + e] * p.alpha - l4[e]);
+                    const float pe = key_ok ? __expf(s[mt][4 * g4 + e] * p.alpha - l4[e]) : 0.0f;
                     s[mt][4 * g4 + e] = pe;
                     dp[mt][4 * g4 + e] = pe * (dp[mt][4 * g4 + e] - d4[e]);
                 }
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int srow = s0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (srow >= p.T) continue;
                 half_t* row = out + (long long)srow * 3 * p.C;
                 row[p.v_off + h * p.hs + j] = (half_t)dv[t][r];
                 row[p.k_off + h * p.hs + j] = (half_t)(dk[t][r] * p.alpha);
@@ -221,14 +225,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
     const long long qb = (long long)(p.q_off + h * p.hs) * 2, kb_ = (long long)(p.k_off + h * p.hs) * 2, vb = (long long)(p.v_off + h * p.hs) * 2;
     const long long ob = (long long)h * p.d * 2;
     const int myq = q0 + wave * 32 + lr;
-    const float my_lse = p.lse[((long long)n * p.heads + h) * p.T + myq];
-    const float my_D = p.D[((long long)n * p.heads + h) * p.T + myq];
+    const float my_lse = myq < p.T ? p.lse[((long long)n * p.heads + h) * p.T + myq] : INFINITY;  // +inf: P = 0 for rows beyond T
+    const float my_D = myq < p.T ? p.D[((long long)n * p.heads + h) * p.T + myq] : 0.0f;
 
-    ab_stage(rq, rs3, qb, q0, 16, p.d, sQ, wave, lane, 4);
-    ab_stage(ro, rsC, ob, q0, 16, p.d, sO, wave, lane, 4);
+    ab_stage(rq, rs3, qb, q0, 16, p.d, sQ, wave, lane, 4, p.T);
+    ab_stage(ro, rsC, ob, q0, 16, p.d, sO, wave, lane, 4, p.T);
     auto stage_k = [&](int kt, int buf) {
-        ab_stage(rq, rs3, kb_, kt * 64, 8, p.d, sK + buf * 64 * AB_ROWB, wave, lane, 4);
-        ab_stage(rq, rs3, vb, kt * 64, 8, p.d, sV + buf * 64 * AB_ROWB, wave, lane, 4);
+        ab_stage(rq, rs3, kb_, kt * 64, 8, p.d, sK + buf * 64 * AB_ROWB, wave, lane, 4, p.T);
+        ab_stage(rq, rs3, vb, kt * 64, 8, p.d, sV + buf * 64 * AB_ROWB, wave, lane, 4, p.T);
     };
     stage_k(0, 0);
     f32x16 dq[DT];
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[t][r] = 0.0f;
 
-    const int nkt = p.T / 64;
+    const int nkt = (p.T + 63) / 64;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -267,7 +271,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pe = __expf(s[mt][r] * p.alpha - my_lse);
+                float pe = __expf(s[mt][r] * p.alpha - my_lse);
+                if ((kt + 1) * 64 > p.T) {  // wave-uniform: ragged last key tile, keys beyond T contribute nothing
+                    const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pe = key < p.T ? pe : 0.0f;
+                }
                 dp[mt][r] = pe * (dp[mt][r] - my_D);  // dS^T
             }
         // ---- dQ += dS K  (contraction over the 64 keys held in registers, permuted order; B = K rows via transposed reads) ----
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qrow = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (qrow >= p.T) continue;
                 out[(long long)qrow * 3 * p.C + p.q_off + h * p.hs + j] = (half_t)(dq[t][r] * p.alpha);
             }
         }
@@ -455,7 +464,7 @@ extern "C" int eod_attention_bwd(const void* qkv, const void* dO, const float* l
                                  int heads, int d, int q_off, int k_off, int v_off, int head_stride, void* stream) {
     EOD_REQUIRE(qkv && dO && lse && D && dqkv && N > 0 && T > 0 && heads > 0 && d > 0 && C == heads * d, "attention_bwd: bad args");
     EOD_REQUIRE(dtype == EOD_F16, "attention_bwd: fp16 only");
-    EOD_REQUIRE(T % 128 == 0 && d % 8 == 0 && d <= 64, "attention_bwd: needs T %% 128 == 0 and a head dim that is a multiple of 8 and <= 64");
+    EOD_REQUIRE(d % 8 == 0 && d <= 64, "attention_bwd: needs a head dim that is a multiple of 8 and <= 64");
     EOD_REQUIRE(q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && head_stride % 8 == 0 && eod_aligned16(qkv) && eod_aligned16(dO),
                 "attention_bwd: 16-byte alignment of the head slices");
     EOD_REQUIRE((long long)T * 3 * C * 2 < 0x7fffffffLL, "attention_bwd: one image of qkv exceeds the 2 GiB window");
@@ -463,7 +472,7 @@ extern "C" int eod_attention_bwd(const void* qkv, const void* dO, const float* l
     p.qkv = (const char*)qkv; p.dO = (const char*)dO; p.lse = lse; p.D = D; p.dqkv = (char*)dqkv;
     p.N = N; p.T = T; p.C = C; p.heads = heads; p.d = d; p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.hs = head_stride;
     p.alpha = 1.0f / sqrtf((float)d);
-    const dim3 grid(T / 128, N * heads);
+    const dim3 grid((T + 127) / 128, N * heads);
     const size_t lds_kv = (size_t)(256 + 256) * AB_ROWB + 4 * 64 * sizeof(float);
     const size_t lds_q = (size_t)(256 + 256) * AB_ROWB;
     hipStream_t st = (hipStream_t)stream;

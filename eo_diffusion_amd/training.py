@@ -298,7 +298,7 @@ class UNetTrainer:
         ldT = round_up(N * Tp, BK)
         qkvT = prog.empty((3 * Cc * ldT,), zero=True)                        # [3C][n*Tp + t]
         prog._small(OP_TRANSPOSE, p=(ptr(qkv.t), ptr(qkvT)), l=(ldT, 0, 0, 0), i=(self.dt, N, 1, T, 3 * Cc, 1, Tp, 1, 0, 0))
-        flash = (prog.precision == "fp16" and Tp == T and d % 8 == 0 and d <= 64 and os.environ.get("EOD_ATTN_TRAIN", "flash") != "gemm")
+        flash = (prog.precision == "fp16" and d % 8 == 0 and d <= 64 and os.environ.get("EOD_ATTN_TRAIN", "flash") != "gemm")
         if flash:
             # forward = the inference path's fused kernel on the natural qkv layout (T x T never materialised); it also returns the
             # log-sum-exp of every score row, from which the backward rebuilds P
@@ -331,7 +331,7 @@ class UNetTrainer:
         B = N * nh
         alpha = 1.0 / math.sqrt(d)
         BK = 128 // es
-        if P is None and T % 128 == 0 and os.environ.get("EOD_ATTN_BWD", "flash") == "flash":
+        if P is None and os.environ.get("EOD_ATTN_BWD", "flash") == "flash":
             # flash-style backward: P is rebuilt tile by tile in registers from q, k and the forward's log-sum-exp
             D = self._shared("attn_D", B * T, torch.float32)
             self._call(L.eod_rowdot, ptr(da.t), ptr(rec.a.t), dt, N, nh, T, T * Cc, d, Cc, d, ptr(D))

@@ -324,7 +324,7 @@ int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, int64_t n1, 
  * [N][heads][T].  K / V tiles staged row-major by LDS-DMA, V^T through transposed LDS reads (csrc/attn_bwd.hip) */
 int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off, int k_off,
                           int v_off, int head_stride, void* stream);
-/* flash-style attention backward (fp16, head dim <= 64, T % 128 == 0): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /
+/* flash-style attention backward (fp16, head dim a multiple of 8 and <= 64, any T): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /
  * k_off / v_off + head*head_stride + j), dO [N][T][C], the forward's log-sum-exp lse [N][heads][T] (eod_attn_desc.lse) and
  * D[n][h][t] = sum_j dO*O (eod_rowdot).  P is rebuilt tile by tile in registers: nothing T x T touches HBM (csrc/attn_bwd.hip) */
 int eod_attention_bwd(const void* qkv, const void* dO, const float* lse, const float* D, void* dqkv, int dtype, int N, int T, int C,

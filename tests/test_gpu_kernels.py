@@ -281,7 +281,8 @@ def test_softmax_long_rows_forward_and_backward(prec, n, ld):
     assert float(ds.float().cpu()[:, n:].abs().max() if ld > n else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("T,heads,d,new_order", [(128, 2, 16, False), (256, 2, 32, True), (256, 1, 48, False), (384, 2, 64, False), (128, 3, 8, True)])
+@pytest.mark.parametrize("T,heads,d,new_order", [(128, 2, 16, False), (256, 2, 32, True), (256, 1, 48, False), (384, 2, 64, False), (128, 3, 8, True),
+                                                 (49, 2, 16, False), (196, 1, 32, True), (200, 2, 48, False), (64, 2, 64, False)])
 def test_flash_attention_backward_vs_autograd(T, heads, d, new_order):
     """eod_attention_fwd (with log-sum-exp) + eod_rowdot + eod_attention_bwd against torch autograd of
     softmax(q k^T / sqrt(d)) v on the natural qkv layout (legacy [h][q|k|v][d] and new [q|k|v][h][d] orders)"""
@@ -303,19 +304,13 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order):
     P = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), -1)
     O = (P @ v).permute(0, 2, 1, 3).reshape(N, T, C)
     O.backward(dO.half().float())
-    # HIP path: O and lse from the flash forward on packed operands built here, then the backward on the natural layout
+    # HIP path: O and lse from the fused forward on the natural layout, then the backward
     st = current_stream_ptr(torch.device(DEV))
     qd = qh.to(DEV)
-    qn, kn, vn = split(qd)
-    qk = torch.cat([qn.permute(0, 2, 1, 3).reshape(N * T, C), kn.permute(0, 2, 1, 3).reshape(N * T, C)], 1).contiguous()
-    vT = vn.permute(0, 1, 3, 2).reshape(N, C, T).contiguous()
     out = torch.empty((N * T, C), dtype=torch.float16, device=DEV)
     lse = torch.empty((N, heads, T), dtype=torch.float32, device=DEV)
-    desc = _lib.AttnDesc()
-    desc.qk, desc.vT, desc.out, desc.lse = qk.data_ptr(), vT.data_ptr(), out.data_ptr(), lse.data_ptr()
-    desc.ld_qk, desc.ldt = 2 * C, T
-    desc.dtype, desc.N, desc.T, desc.C, desc.heads, desc.d, desc.dpad, desc.k_off = _lib.EOD_F16, N, T, C, heads, d, d, C
-    _lib.check(L.eod_attention_fwd(_lib.C.byref(desc), st), "attention_fwd")
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, st),
+               "attention_fwd_nat")
     assert rel_l2(out.float().cpu().reshape(N, T, C), O.detach()) < 3e-3
     lse_ref = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) / math.sqrt(d), -1)
     assert float((lse.cpu() - lse_ref).abs().max()) < 2e-3
