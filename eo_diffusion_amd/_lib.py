@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libeodiff.so")
 
 EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
- OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT) = range(1, 14)
+ OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT, OP_DROPOUT) = range(1, 15)
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -79,6 +79,7 @@ SYMBOLS = {
     "eod_gn_bwd_params": (i32, [vp, i32, i32, f32, vp, vp, vp]),
     "eod_gn_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "eod_add": (i32, [vp, vp, vp, i32, i64, vp]),
+    "eod_dropout": (i32, [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "eod_rowdot": (i32, [vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
     "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

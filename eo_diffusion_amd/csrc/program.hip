@@ -124,6 +124,9 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
                 rc = eod_attention_fwd_nat(s.p[0], (void*)s.p[1], (float*)s.p[2], s.i[0], s.i[1], s.i[2], s.i[3], s.i[4], s.i[5], s.i[6], s.i[7], s.i[8],
                                            s.i[9], stream);
                 break;
+            case EOD_OP_DROPOUT:
+                rc = eod_dropout(s.p[0], (void*)s.p[1], s.i[0], s.l[0], s.f[0], (uint64_t)s.l[1], (uint32_t)s.i[1], (uint32_t)s.i[2], stream);
+                break;
             case EOD_OP_TRANSPOSE:
                 rc = eod_transpose_gather(s.p[0], s.i[0], s.i[1], s.i[2], s.i[3], s.i[4], (void*)s.p[1], s.l[0], s.i[5], s.i[6], s.i[7], s.i[8],
                                           s.i[9], (int)s.l[1], (int)s.l[2], (int)s.l[3], stream);

@@ -1274,3 +1274,50 @@ extern "C" int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, i
     EOD_CHECK_LAUNCH("rowdot");
     return EOD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// nn.Dropout (ResBlock.out_layers[2], unet_openai.py:339): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p).
+// The mask is a pure function of (seed, layer, step, element) through Philox4x32-10 -- the backward re-derives it from the
+// same key (same kernel applied to the gradient), nothing is stored.  One Philox call = 4 elements.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tr_philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, unsigned keep_thr, float scale, unsigned long long seed,
+                               unsigned layer, unsigned step) {
+    const long long quads = (n + 3) / 4;
+    for (long long qd = (long long)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (long long)gridDim.x * blockDim.x) {
+        unsigned r[4];
+        tr_philox4((unsigned)qd, (unsigned)(qd >> 32), layer, step, (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long e = qd * 4 + j;
+            if (e < n) y[e] = (T)(r[j] < keep_thr ? (float)x[e] * scale : 0.0f);
+        }
+    }
+}
+
+extern "C" int eod_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, uint32_t layer, uint32_t step, void* stream) {
+    EOD_REQUIRE(x && y && n > 0 && p >= 0.0f && p < 1.0f, "dropout: bad args (0 <= p < 1)");
+    const double keep = 1.0 - (double)p;
+    const unsigned thr = keep >= 1.0 ? 0xFFFFFFFFu : (unsigned)(keep * 4294967296.0);
+    long long blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(dropout_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (long long)n, thr, (float)(1.0 / keep), (unsigned long long)seed, layer, step);
+    else
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, (long long)n, thr, (float)(1.0 / keep), (unsigned long long)seed, layer, step);
+    EOD_CHECK_LAUNCH("dropout");
+    return EOD_OK;
+}

@@ -10,8 +10,9 @@ unchanged on them.
 
 Scope of this first version: ResBlock (plain), AttentionBlock (legacy qkv order), Upsample / Downsample with conv,
 first / head conv, the timestep MLP, class conditioning, and the factory variants use_scale_shift_norm (FiLM),
-resblock_updown, use_new_attention_order.  Not yet: dropout > 0, odd spatial sizes, Up/Downsample without conv outside
-resblock_updown, the 3x3 -> 7x7 pad hack -- these raise EodError (never a silent fallback)."""
+resblock_updown, use_new_attention_order, dropout (Philox mask, recomputed in the backward).  Not yet: stride-2 convs of odd
+maps, Up/Downsample without conv outside resblock_updown, the 3x3 -> 7x7 pad hack -- these raise EodError (never a silent
+fallback)."""
 import ctypes as C
 import math
 import os
@@ -19,7 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ._lib import OP_TRANSPOSE, EodError, check, ptr
+from ._lib import OP_DROPOUT, OP_TRANSPOSE, EodError, check, ptr
 from .engine import Act, Program, current_stream_ptr, round_up
 
 
@@ -51,6 +52,13 @@ class _GNRec:
         self.film = film  # (view of the [N][J] emb_layers output at this block's columns, J, column offset) or None
 
 
+class _DropRec:
+    """nn.Dropout of ResBlock.out_layers (:339): y = x * mask / (1 - p), mask = Philox(seed; layer, step) -- recomputed, never stored"""
+
+    def __init__(self, src, y, layer, p):
+        self.src, self.y, self.layer, self.p = src, y, layer, p
+
+
 class _PoolRec:
     """2x resampling without conv (resblock_updown, unet_openai.py:320-325): mode 0 = average pool, 1 = nearest"""
 
@@ -74,7 +82,7 @@ class UNetTrainer:
         tr.backward(dpred)                       # dpred NCHW fp32 = dLoss/dpred; fills p.grad for every parameter
     """
 
-    def __init__(self, unet, N, H, W, device, *, cond_channels=0, loss_scale=1.0):
+    def __init__(self, unet, N, H, W, device, *, cond_channels=0, loss_scale=1.0, dropout_seed=None):
         from .backbones import unet_openai as U
         self.U = U
         self.unet = unet
@@ -94,6 +102,8 @@ class UNetTrainer:
         self.recs = []
         self._keep = []
         self._scratch, self._scratch_all = {}, []
+        self.dropout_seed = int(torch.initial_seed() if dropout_seed is None else dropout_seed) & (2**63 - 1)
+        self._drop_ops = []  # forward executor ops whose `step` field is refreshed every forward
         self._alloc_flat_grad()
         self._build(cond_channels)
 
@@ -222,6 +232,34 @@ class UNetTrainer:
         self.recs.append(_GNRec(srcs, gn, ss, parts, y, silu, film))
         return y
 
+    def _dropout_fwd(self, src, p):
+        prog = self.prog
+        layer = len(self._drop_ops)
+        y = prog.act(src.N, src.H, src.W, src.C)
+        idx = prog._small(OP_DROPOUT, p=(ptr(src.t), ptr(y.t)), l=(src.t.numel(), self.dropout_seed), i=(self.dt, layer, 0), f=(float(p),))
+        self._drop_ops.append(idx)
+        self.recs.append(_DropRec(src, y, layer, float(p)))
+        return y
+
+    def _dropout_bwd(self, rec):
+        dy = self._take_grad(rec.y)
+        if dy is None:
+            raise EodError("training: a dropout output has no gradient (graph bug)")
+        dx = self.bprog.act(dy.N, dy.H, dy.W, dy.C)
+        # same key as the forward of THIS step (step_id is read when the backward runs)
+        self.bwd.append(("dyn", lambda st, a=ptr(dy.t), b=ptr(dx.t), n=dy.t.numel(), r=rec: check(
+            self.L.eod_dropout(a, b, self.dt, n, r.p, self.dropout_seed, r.layer, self.step_id, st), "eod_dropout")))
+        self._add_grad(rec.src, dx)
+
+    def dropout_mask(self, layer, like):
+        """mask / (1 - p) of dropout layer `layer` for the most recent forward (test / inspection helper)"""
+        rec = [r for r in self.recs if isinstance(r, _DropRec)][layer]
+        ones = torch.ones_like(like)
+        out = torch.empty_like(like)
+        check(self.L.eod_dropout(ptr(ones), ptr(out), self.dt, ones.numel(), rec.p, self.dropout_seed, rec.layer, self.step_id,
+                                 current_stream_ptr(self.device)), "eod_dropout")
+        return out
+
     def _pool_fwd(self, src, mode):
         y = self.prog.resample2x(src, mode)
         self.recs.append(_PoolRec(src, y, mode))
@@ -230,8 +268,6 @@ class UNetTrainer:
     def _resblock(self, blk, h):
         U = self.U
         srcs = list(h) if isinstance(h, tuple) else [h]
-        if blk.dropout > 0:
-            raise EodError("training: dropout > 0 is not built yet")
         gn1, conv1 = blk.in_layers[0], blk.in_layers[2]
         gn2, conv2 = blk.out_layers[0], blk.out_layers[3]
         a1 = self._gn_fwd(srcs, gn1)
@@ -251,6 +287,8 @@ class UNetTrainer:
         else:
             h1 = self._conv_fwd([a1], conv1, emb=(emb_view, self.ctx.J, off, blk.emb_layers[1]))
             a2 = self._gn_fwd([h1], gn2)
+        if blk.dropout > 0 and self.unet.training:  # out_layers = [GroupNorm, SiLU, Dropout(p), conv]
+            a2 = self._dropout_fwd(a2, blk.dropout)
         if isinstance(blk.skip_connection, nn.Identity):
             if len(srcs) != 1:
                 raise EodError("identity skip over a virtual concat is not supported")
@@ -466,6 +504,8 @@ class UNetTrainer:
                 self._attn_bwd(rec)
             elif isinstance(rec, _PoolRec):
                 self._pool_bwd(rec)
+            elif isinstance(rec, _DropRec):
+                self._dropout_bwd(rec)
             else:
                 self._gn_bwd(rec)
         self._temb_bwd()
@@ -732,6 +772,8 @@ class UNetTrainer:
             self._c = cond.contiguous().float()
             self.prog.ops[self.i_in].u.small.p[1] = self._c.data_ptr()
         self.prog.ops[self.i_t].u.temb.t = self._t_slot.data_ptr()
+        for idx in self._drop_ops:
+            self.prog.ops[idx].u.small.i[2] = self.step_id & 0x7fffffff
         if y is not None:
             self._y_slot.copy_(y.to(torch.int64))
             self.prog.ops[self.i_t].u.temb.y = self._y_slot.data_ptr()
@@ -759,6 +801,8 @@ class UNetTrainer:
         for i, item in enumerate(self.bwd):
             if item[0] == "op":
                 check(L.eod_program_run(C.byref(item[1]), 1, st), "backward op")
+            elif item[0] == "dyn":
+                item[1](st)
             else:
                 check(item[1](*item[2], st), item[1].__name__)
             while pending and pending[0][0] <= i:

@@ -236,7 +236,8 @@ enum {
     EOD_OP_GN_APPLY = 5, EOD_OP_SOFTMAX = 6, EOD_OP_TEMB = 7, EOD_OP_TO_NHWC = 8, EOD_OP_TO_NCHW = 9,
     EOD_OP_POOL = 10, EOD_OP_ATTN = 11,
     EOD_OP_TRANSPOSE = 12, /* eod_transpose_gather (training forward: transposed q|k|v for the attention GEMMs) */
-    EOD_OP_ATTN_NAT = 13   /* eod_attention_fwd_nat */
+    EOD_OP_ATTN_NAT = 13,  /* eod_attention_fwd_nat */
+    EOD_OP_DROPOUT = 14    /* eod_dropout (training forward) */
 };
 typedef struct {
     const void* p[6];
@@ -313,6 +314,9 @@ int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, float* dgam
 int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype,
                      int N, int HW, int C, int Ctot, int coff, int silu, void* dx, void* stream);
 int eod_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
+/* nn.Dropout of ResBlock.out_layers (unet_openai.py:339): y = x * keep / (1 - p); keep = Philox4x32-10(seed; element/4, layer, step)
+ * -- forward and backward call it with the same key (x = activation / x = gradient), the mask is never stored */
+int eod_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, uint32_t layer, uint32_t step, void* stream);
 /* out[(i0*n1 + i1)*n2 + i2] = sum_{j<d} a[off + j] * b[off + j], off = i0*s0 + i1*s1 + i2*s2 (elements): the attention
  * backward's D[n][head][t] = sum_j dO * O over one head's channels (rowsum(dP * P) without forming dP) */
 int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, int64_t n1, int64_t n2, int64_t s0, int64_t s1, int64_t s2, int d,

@@ -54,7 +54,9 @@ def downsample(sd, pfx, x, use_conv=True):
     return F.avg_pool2d(x, 2, 2)
 
 
-def res_block(sd, pfx, x, emb, *, film=False, up=False, down=False):
+def res_block(sd, pfx, x, emb, *, film=False, up=False, down=False, drop=None):
+    """drop: optional callable pfx -> multiplicative mask (already divided by 1 - p) applied where the reference's nn.Dropout
+    sits (out_layers[2], unet_openai.py:339); None = eval mode / p = 0 (identity)"""
     h = F.silu(group_norm32(x, sd[pfx + ".in_layers.0.weight"], sd[pfx + ".in_layers.0.bias"]))
     if up:
         h = upsample(sd, "", h, use_conv=False)
@@ -73,7 +75,9 @@ def res_block(sd, pfx, x, emb, *, film=False, up=False, down=False):
     else:
         h = h + e
         h = F.silu(group_norm32(h, gw, gb))
-    h = _conv(sd, pfx + ".out_layers.3", h, padding=1)  # dropout is identity in eval
+    if drop is not None:
+        h = h * drop(pfx, h)
+    h = _conv(sd, pfx + ".out_layers.3", h, padding=1)  # (dropout is the identity in eval mode)
     if (pfx + ".skip_connection.weight") in sd:
         w = sd[pfx + ".skip_connection.weight"]
         x = F.conv2d(x, w, sd[pfx + ".skip_connection.bias"], padding=w.shape[-1] // 2)
@@ -126,11 +130,11 @@ def _heads(ch, cfg, upsample_side=False):
     return cfg.get("num_heads", 1)
 
 
-def unet_forward(sd, cfg, x, timesteps, cond=None, y=None):
+def unet_forward(sd, cfg, x, timesteps, cond=None, y=None, drop=None):
     """cfg keys mirror UNetModel.__init__ (unet_openai.py:553-575): model_channels,
     num_res_blocks, attention_resolutions, channel_mult, num_classes, num_heads,
     num_head_channels, num_heads_upsample, use_scale_shift_norm, resblock_updown,
-    use_new_attention_order, conv_resample."""
+    use_new_attention_order, conv_resample.  drop: see res_block (training-mode dropout with injected masks)."""
     mc = cfg["model_channels"]
     mult = tuple(cfg.get("channel_mult", (1, 2, 4, 8)))
     nrb = cfg["num_res_blocks"]
@@ -161,7 +165,7 @@ def unet_forward(sd, cfg, x, timesteps, cond=None, y=None):
     for level, m in enumerate(mult):
         for _ in range(nrb):
             p = f"input_blocks.{idx}"
-            h = res_block(sd, p + ".0", h, emb, film=film)
+            h = res_block(sd, p + ".0", h, emb, film=film, drop=drop)
             ch = int(m * mc)
             if ds in attn_res:
                 h = attention_block(sd, p + ".1", h, _heads(ch, cfg), new_order)
@@ -170,23 +174,23 @@ def unet_forward(sd, cfg, x, timesteps, cond=None, y=None):
         if level != len(mult) - 1:
             p = f"input_blocks.{idx}.0"
             if rud:
-                h = res_block(sd, p, h, emb, film=film, down=True)
+                h = res_block(sd, p, h, emb, film=film, down=True, drop=drop)
             else:
                 h = downsample(sd, p, h, use_conv=conv_resample)
             hs.append(h)
             idx += 1
             ds *= 2
     # ---- middle (unet_openai.py:666-690) ----
-    h = res_block(sd, "middle_block.0", h, emb, film=film)
+    h = res_block(sd, "middle_block.0", h, emb, film=film, drop=drop)
     h = attention_block(sd, "middle_block.1", h, _heads(ch, cfg), new_order)
-    h = res_block(sd, "middle_block.2", h, emb, film=film)
+    h = res_block(sd, "middle_block.2", h, emb, film=film, drop=drop)
     # ---- decoder (unet_openai.py:693-737, 772-774) ----
     idx = 0
     for level, m in list(enumerate(mult))[::-1]:
         for i in range(nrb + 1):
             p = f"output_blocks.{idx}"
             h = torch.cat([h, hs.pop()], dim=1)
-            h = res_block(sd, p + ".0", h, emb, film=film)
+            h = res_block(sd, p + ".0", h, emb, film=film, drop=drop)
             ch = int(mc * m)
             sub = 1
             if ds in attn_res:
@@ -194,7 +198,7 @@ def unet_forward(sd, cfg, x, timesteps, cond=None, y=None):
                 sub += 1
             if level and i == nrb:
                 if rud:
-                    h = res_block(sd, f"{p}.{sub}", h, emb, film=film, up=True)
+                    h = res_block(sd, f"{p}.{sub}", h, emb, film=film, up=True, drop=drop)
                 else:
                     h = upsample(sd, f"{p}.{sub}", h, use_conv=conv_resample)
                 ds //= 2

@@ -95,10 +95,10 @@ def test_training_rejects_unbuilt_variants():
     import eo_diffusion_amd.backbones.unet_openai as U
     from eo_diffusion_amd._lib import EodError
     from eo_diffusion_amd.training import UNetTrainer
-    m = U.UNetModel(16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
-                    channel_mult=(1, 2), num_heads=2, dropout=0.1).to(DEV)
+    m = U.UNetModel(24, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
+                    channel_mult=(1, 2, 2, 2), num_heads=2).to(DEV)  # 24 -> 12 -> 6 -> 3: the 3x3 -> 7x7 pad hack of Upsample
     with pytest.raises(EodError):
-        UNetTrainer(m, 2, 16, 16, DEV)
+        UNetTrainer(m, 2, 24, 24, DEV)
     m = U.UNetModel(20, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
                     channel_mult=(2, 4, 4, 4)).to(DEV)  # 20 -> 10 -> 5 -> 3: the stride-2 conv of an ODD map is not built yet
     with pytest.raises(EodError):
@@ -392,3 +392,69 @@ def test_bucketed_allreduce_overlap_single_rank(monkeypatch):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_training_with_dropout(prec):
+    """dropout > 0 (what the UNetBig / UNet / UNetSmall presets use, unet_openai.py:783-922): the Philox mask has the right keep
+    rate and scale, the backward re-derives the SAME mask, changes from step to step, and with the masks injected into the
+    oracle every parameter gradient matches torch autograd"""
+    from eo_diffusion_amd.training import UNetTrainer, _DropRec
+    from oracle import unet_ref as UR
+    extra = dict(dropout=0.25)
+    m, sd, cfg, x, noise, t = _setup(prec, 16, 32, (1, 2), 1, 2, extra=extra)
+    cfg = {k: v for k, v in cfg.items() if k != "dropout"}
+    tr = UNetTrainer(m, 2, 16, 16, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0), dropout_seed=1234)
+    pred = tr.forward(x.to(DEV), t.to(DEV))
+    recs = [r for r in tr.recs if isinstance(r, _DropRec)]
+    assert len(recs) == 8  # one per ResBlock (2 encoder + 2 middle + 4 decoder)
+    masks = [tr.dropout_mask(k, r.y.t).float().cpu() for k, r in enumerate(recs)]
+    for mk in masks:
+        keep = float((mk != 0).float().mean())
+        assert abs(keep - 0.75) < 0.03 and abs(float(mk.max()) - 1.0 / 0.75) < 2e-3
+    # the oracle applies the same masks where the reference has nn.Dropout; ResBlocks are visited in parameter (= forward) order
+    order = iter(masks)
+    drop = lambda pfx, h: next(order).permute(0, 3, 1, 2).to(h.dtype)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred_ref = UR.unet_forward(sdg, cfg, x, t, drop=drop)
+    assert rel_l2(pred.cpu(), pred_ref.detach()) < (2e-5 if prec == "fp32" else 1e-2)
+    torch.nn.functional.mse_loss(pred_ref, noise).backward()
+    tr.backward(2.0 * (pred - noise.to(DEV)) / pred.numel())
+    torch.cuda.synchronize()
+    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    worst = max(((n, rel_l2(p.grad.cpu(), sdg[n].grad)) for n, p in m.named_parameters()
+                 if sdg[n].grad is not None and float(sdg[n].grad.norm()) > 1e-5 * gmax), key=lambda kv: kv[1])
+    assert worst[1] < GTOL[prec], worst
+    m1 = tr.dropout_mask(0, recs[0].y.t).clone()
+    tr.forward(x.to(DEV), t.to(DEV))
+    assert not torch.equal(tr.dropout_mask(0, recs[0].y.t), m1)  # a new mask every step
+
+
+@pytest.mark.parametrize("factory", ["UNetSmall", "UNet"])
+def test_factory_presets_train_as_is(factory):
+    """UNetSmall / UNet exactly as the reference constructs them (dropout 0.1, FiLM, resblock_updown, new attention order,
+    num_head_channels, class conditioning, attention at three resolutions): a training step through the autograd bridge
+    gives finite, non-trivial gradients for every parameter and the loss falls under AdamW"""
+    import eo_diffusion_amd.backbones.unet_openai as U
+    torch.manual_seed(0)
+    m = getattr(U, factory)(32, in_channels=3, out_channels=3, num_classes=4).set_precision("fp16")
+    for p in m.parameters():
+        if float(p.detach().abs().sum()) == 0.0:
+            torch.nn.init.normal_(p, std=0.02)
+    m = m.to(DEV).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    x = synth_input("fp_x", (2, 3, 32, 32), 3).to(DEV)
+    noise = synth_input("fp_n", (2, 3, 32, 32), 4).to(DEV)
+    t, y = torch.tensor([10, 700], device=DEV), torch.tensor([1, 3], device=DEV)
+    losses = []
+    for _ in range(5):
+        loss = torch.nn.functional.mse_loss(m(x, t, y=y), noise)
+        loss.backward()
+        if not losses:
+            bad = [n for n, p in m.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+            assert not bad, bad[:5]
+            assert sum(float(p.grad.abs().sum()) > 0 for p in m.parameters()) > 0.9 * len(list(m.parameters()))
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
