@@ -850,7 +850,7 @@ def unet_train_forward(unet, x, timesteps, cond=None, y=None):
     N, cx, H, W = x.shape
     ccond = 0 if cond is None else cond.shape[1]
     cache = unet.__dict__.setdefault("_eod_trainers", {})
-    key = (N, cx, ccond, H, W, str(x.device), unet.precision)
+    key = (N, cx, ccond, H, W, str(x.device), unet.precision, bool(unet.training))  # (train / eval differ by the dropout ops)
     tr = cache.get(key)
     if tr is None:
         import os
