@@ -159,8 +159,11 @@ extern "C" int eod_nhwc_to_nchw(const void* src, int dtype, float* dst, int N, i
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int mode, int pad_tl) {
+    // pad_tl: mode 1 = zero row / column on top / left of the 2x image (3x3 -> 7x7 hack); mode 2 = the backward of that (the sums
+    // skip the first row / column of the input); mode 3 = the average pool dropped a last odd row / column: one zero row / column
+    // at the BOTTOM / RIGHT of the output
     const bool up = mode == 1 || mode == 3;
-    const int Ho = up ? 2 * H + pad_tl : H / 2, Wo = up ? 2 * W + pad_tl : W / 2;
+    const int Ho = up ? 2 * H + pad_tl : (H - (mode == 2 ? pad_tl : 0)) / 2, Wo = up ? 2 * W + pad_tl : (W - (mode == 2 ? pad_tl : 0)) / 2;
     const long long total = (long long)N * Ho * Wo * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -171,11 +174,12 @@ __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
         const long long n = r / Ho;
         float v;
         if (up) {
-            const int hi = ho - pad_tl, wi = wo - pad_tl;
-            v = (hi >= 0 && wi >= 0) ? (float)x[((n * H + (hi >> 1)) * W + (wi >> 1)) * C + c] : 0.0f;
+            const int hi = mode == 1 ? ho - pad_tl : ho, wi = mode == 1 ? wo - pad_tl : wo;
+            v = (hi >= 0 && wi >= 0 && hi < 2 * H && wi < 2 * W) ? (float)x[((n * H + (hi >> 1)) * W + (wi >> 1)) * C + c] : 0.0f;
             if (mode == 3) v *= 0.25f;
         } else {
-            const T* b = x + ((n * H + 2 * ho) * W + 2 * wo) * C + c;
+            const int o = mode == 2 ? pad_tl : 0;
+            const T* b = x + ((n * H + 2 * ho + o) * W + 2 * wo + o) * C + c;
             // same summation order as ATen's avg_pool2d (row-major window), then * 0.25
             v = ((float)b[0] + (float)b[C] + (float)b[(long long)W * C] + (float)b[(long long)W * C + C]) * (mode == 2 ? 1.0f : 0.25f);
         }
@@ -188,7 +192,8 @@ extern "C" int eod_resample2x(const void* x, int dtype, int N, int H, int W, int
     EOD_REQUIRE(mode >= 0 && mode <= 3, "resample2x: mode %d", mode);
     const bool up = mode == 1 || mode == 3;
     EOD_REQUIRE(up || (H >= 2 && W >= 2), "resample2x: avg-pool needs at least 2x2 (%dx%d)", H, W);  // odd dims: floor, like ATen
-    const long long total = (long long)N * (up ? 2 * H + pad_tl : H / 2) * (up ? 2 * W + pad_tl : W / 2) * C;
+    const int o2 = mode == 2 ? pad_tl : 0;
+    const long long total = (long long)N * (up ? 2 * H + pad_tl : (H - o2) / 2) * (up ? 2 * W + pad_tl : (W - o2) / 2) * C;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     if (dtype == EOD_F16)
         hipLaunchKernelGGL(resample2x_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, N, H, W, C, mode, pad_tl);

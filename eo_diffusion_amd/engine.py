@@ -285,7 +285,8 @@ class Program:
         if mode in (1, 3):
             ho, wo = 2 * x.H + int(pad_tl), 2 * x.W + int(pad_tl)
         else:
-            ho, wo = x.H // 2, x.W // 2
+            o = int(pad_tl) if mode == 2 else 0
+            ho, wo = (x.H - o) // 2, (x.W - o) // 2
         y = self.act(x.N, ho, wo, x.C)
         self._small(OP_POOL, p=(ptr(x.t), ptr(y.t)), i=(self.dt, x.N, x.H, x.W, x.C, mode, int(pad_tl)))
         return y

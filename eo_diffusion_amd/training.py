@@ -10,9 +10,9 @@ unchanged on them.
 
 Scope of this first version: ResBlock (plain), AttentionBlock (legacy qkv order), Upsample / Downsample with conv,
 first / head conv, the timestep MLP, class conditioning, and the factory variants use_scale_shift_norm (FiLM),
-resblock_updown, use_new_attention_order, dropout (Philox mask, recomputed in the backward).  Not yet: stride-2 convs of odd
-maps, Up/Downsample without conv outside resblock_updown, the 3x3 -> 7x7 pad hack -- these raise EodError (never a silent
-fallback)."""
+resblock_updown (incl. odd maps and the 3x3 -> 7x7 pad hack), use_new_attention_order, dropout (Philox mask, recomputed in the
+backward).  Not yet: stride-2 convs of odd maps, Upsample(use_conv=True) of a 3x3 map, Up/Downsample without conv outside
+resblock_updown -- these raise EodError (never a silent fallback)."""
 import ctypes as C
 import math
 import os
@@ -60,10 +60,11 @@ class _DropRec:
 
 
 class _PoolRec:
-    """2x resampling without conv (resblock_updown, unet_openai.py:320-325): mode 0 = average pool, 1 = nearest"""
+    """2x resampling without conv (resblock_updown, unet_openai.py:320-325): mode 0 = average pool (floor), 1 = nearest (with the
+    3x3 -> 7x7 zero row / column of :237-239 when pad_tl)"""
 
-    def __init__(self, src, y, mode):
-        self.src, self.y, self.mode = src, y, mode
+    def __init__(self, src, y, mode, pad_tl=False):
+        self.src, self.y, self.mode, self.pad_tl = src, y, mode, pad_tl
 
 
 class _AttnRec:
@@ -261,8 +262,9 @@ class UNetTrainer:
         return out
 
     def _pool_fwd(self, src, mode):
-        y = self.prog.resample2x(src, mode)
-        self.recs.append(_PoolRec(src, y, mode))
+        pad_tl = mode == 1 and src.H == 3 and src.W == 3  # Upsample's 3x3 -> 7x7 hack
+        y = self.prog.resample2x(src, mode, pad_tl)
+        self.recs.append(_PoolRec(src, y, mode, pad_tl))
         return y
 
     def _resblock(self, blk, h):
@@ -275,8 +277,6 @@ class UNetTrainer:
             if len(srcs) != 1 or blk.h_upd.use_conv:
                 raise EodError("training: this resblock_updown variant is not built yet")
             mode = 1 if isinstance(blk.h_upd, U.Upsample) else 0
-            if mode == 0 and (a1.H % 2 or a1.W % 2):
-                raise EodError("training: average pool of an odd map is not built yet")
             a1 = self._pool_fwd(a1, mode)
             srcs = [self._pool_fwd(srcs[0], mode)]
         off = self.ctx.offsets[id(blk)]
@@ -723,8 +723,10 @@ class UNetTrainer:
         dy = self._take_grad(rec.y)
         if dy is None:
             raise EodError("training: a resampled tensor has no gradient (graph bug)")
-        # nearest 2x -> 2x2 sum pool; 2x2 average pool -> nearest 2x times 1/4
-        g = self._bop(lambda: self.bprog.resample2x(dy, 2 if rec.mode == 1 else 3))
+        if rec.mode == 1:   # nearest 2x (+ zero row / column): sum the 2x2 blocks behind the pad
+            g = self._bop(lambda: self.bprog.resample2x(dy, 2, rec.pad_tl))
+        else:               # average pool with floor: the dropped last row / column of an odd map gets a zero gradient
+            g = self._bop(lambda: self.bprog.resample2x(dy, 3, rec.src.H % 2 == 1))
         if (g.H, g.W) != (rec.src.H, rec.src.W):
             raise EodError("training: resample backward shape mismatch")
         self._add_grad(rec.src, g)

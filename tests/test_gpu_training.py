@@ -221,15 +221,17 @@ def test_fused_optimizer_classes_follow_torch():
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-def test_training_step_factory_variants(prec):
+@pytest.mark.parametrize("size,mults,attn", [(32, (1, 2, 2), (2,)), (28, (1, 2, 2, 2), (2, 4))])
+def test_training_step_factory_variants(prec, size, mults, attn):
     """the options the UNetBig / UNet / UNetSmall presets turn on (unet_openai.py:783-922): FiLM (use_scale_shift_norm),
     resblock_updown, use_new_attention_order, class conditioning -- every parameter gradient vs torch autograd"""
     from eo_diffusion_amd.training import UNetTrainer
     extra = dict(use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=True, num_classes=5)
-    m, sd, cfg, x, noise, t = _setup(prec, 32, 32, (1, 2, 2), 1, 2, attn=(2,), heads=2, extra=extra)
+    # 28: 28 -> 14 -> 7 -> 3 (average pools of odd maps, the 3x3 -> 7x7 pad hack on the way up, attention over 196 / 49 positions)
+    m, sd, cfg, x, noise, t = _setup(prec, size, 32, mults, 1, 2, attn=attn, heads=2, extra=extra)
     y = torch.tensor([4, 1])
     pred_ref, gref = _oracle_grads(sd, cfg, x, noise, t, y=y)
-    tr = UNetTrainer(m, 2, 32, 32, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
+    tr = UNetTrainer(m, 2, size, size, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
     pred = tr.forward(x.to(DEV), t.to(DEV), y=y.to(DEV))
     assert rel_l2(pred.cpu(), pred_ref) < (2e-5 if prec == "fp32" else 1e-2)
     tr.backward(2.0 * (pred - noise.to(DEV)) / pred.numel())
@@ -430,21 +432,21 @@ def test_training_with_dropout(prec):
     assert not torch.equal(tr.dropout_mask(0, recs[0].y.t), m1)  # a new mask every step
 
 
-@pytest.mark.parametrize("factory", ["UNetSmall", "UNet"])
-def test_factory_presets_train_as_is(factory):
+@pytest.mark.parametrize("factory,size", [("UNetSmall", 32), ("UNet", 32), ("UNet", 28)])
+def test_factory_presets_train_as_is(factory, size):
     """UNetSmall / UNet exactly as the reference constructs them (dropout 0.1, FiLM, resblock_updown, new attention order,
     num_head_channels, class conditioning, attention at three resolutions): a training step through the autograd bridge
     gives finite, non-trivial gradients for every parameter and the loss falls under AdamW"""
     import eo_diffusion_amd.backbones.unet_openai as U
     torch.manual_seed(0)
-    m = getattr(U, factory)(32, in_channels=3, out_channels=3, num_classes=4).set_precision("fp16")
+    m = getattr(U, factory)(size, in_channels=3, out_channels=3, num_classes=4).set_precision("fp16")
     for p in m.parameters():
         if float(p.detach().abs().sum()) == 0.0:
             torch.nn.init.normal_(p, std=0.02)
     m = m.to(DEV).train()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
-    x = synth_input("fp_x", (2, 3, 32, 32), 3).to(DEV)
-    noise = synth_input("fp_n", (2, 3, 32, 32), 4).to(DEV)
+    x = synth_input("fp_x", (2, 3, size, size), 3).to(DEV)
+    noise = synth_input("fp_n", (2, 3, size, size), 4).to(DEV)
     t, y = torch.tensor([10, 700], device=DEV), torch.tensor([1, 3], device=DEV)
     losses = []
     for _ in range(5):
