@@ -304,6 +304,11 @@ def train_main(args, world, rank, dev, use_dist):
                                       f"loss scale {tr.loss_scale:g}", "global_batch": world * N, "image_size": S,
                           "parallelism": f"data-parallel x{world} (one flat-bucket gradient all-reduce per step)", "accumulate": "fp32"},
                "images_per_sec": world * N * args.steps / dt, "loss": float(loss), "loss_finite": bool(torch.isfinite(loss).all()),
+               # algorithmic FLOPs of one training step = 3 x the forward's (backward-data + backward-weights), per GPU
+               "roofline": {"bound": "mfma", "achieved": 3.0 * sum(o.get("flops", 0.0) for o in tr.prog.op_stats()) / (dt / args.steps) / 1e12,
+                            "peak": PEAK[args.precision] / 1e12, "unit": "TFLOP/s",
+                            "frac": 3.0 * sum(o.get("flops", 0.0) for o in tr.prog.op_stats()) / (dt / args.steps) / PEAK[args.precision],
+                            "traffic": None, "kernel": "whole training step (forward + backward-data + backward-weights)"},
                "hbm_gib": {"forward": tr.prog.nbytes / 2**30, "backward": tr.bprog.nbytes / 2**30}}
         print(json.dumps(res), flush=True)
     if use_dist:
