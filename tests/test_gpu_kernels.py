@@ -352,3 +352,29 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu(), ref) < 3e-3
     assert float((lse.cpu() - torch.logsumexp(S, -1)).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("N,H,W,Cx,Cout,ups", [(2, 16, 64, 40, 24, False), (1, 32, 32, 136, 128, False), (3, 16, 16, 8, 200, False),
+                                               (1, 8, 128, 64, 64, False), (2, 16, 32, 24, 40, True), (1, 8, 8, 16, 16, True)])
+def test_conv3x3_backward_weights_kernel(N, H, W, Cx, Cout, ups):
+    """eod_conv3x3_wgrad (pixel-major staging + transposed LDS operand reads) + eod_wgrad_reduce vs torch's conv2d weight
+    gradient: 64- / 32- / 16-wide strips, channel counts that are not tile multiples, the nearest-2x input variant, several splits"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    x = synth_input(f"wx{N}{H}{W}{Cx}", (N, Cx, H, W), 11).half()
+    dy = synth_input(f"wy{N}{H}{W}{Cout}", (N, Cout, Ho, Wo), 12, scale=0.5).half()
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = torch.nn.grad.conv2d_weight(xin, (Cout, Cx, 3, 3), dy.float(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    st = current_stream_ptr(torch.device(DEV))
+    for S in (1, 5):
+        partial = torch.full((S, 9, Cout, Cx), 7.0, dtype=torch.float32, device=DEV)
+        dw = torch.zeros((Cout, Cx, 3, 3), dtype=torch.float32, device=DEV)
+        _lib.check(L.eod_conv3x3_wgrad(dyd.data_ptr(), xd.data_ptr(), _lib.EOD_F16, N, H, W, Cx, Ho, Wo, Cout, Cout, int(ups), partial.data_ptr(), Cx, S, st),
+                   "conv3x3_wgrad")
+        _lib.check(L.eod_wgrad_reduce(partial.data_ptr(), S, 3, Cout, Cx, Cx, 0, Cx, 1.0, dw.data_ptr(), st), "wgrad_reduce")
+        torch.cuda.synchronize()
+        assert rel_l2(dw.cpu(), ref) < 2e-3, (S, rel_l2(dw.cpu(), ref))
