@@ -103,12 +103,13 @@ SYMBOLS = {
     "eod_attention_fwd": (i32, [C.POINTER(AttnDesc), vp]),
     "eod_softmax_rows": (i32, [vp, i64, vp, i64, i32, i64, i32, vp]),
     "eod_time_embed": (i32, [C.POINTER(TembDesc), vp]),
+    "eod_timestep_embedding": (i32, [vp, vp, vp, i32, i32, vp]),
     "eod_q_sample": (i32, [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
     "eod_repaint_mix": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, i32, vp]),
     "eod_ddpm_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "eod_ddim_step": (i32, [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]),
     "eod_cfg_combine": (i32, [vp, vp, f32, vp, i64, vp]),
-    "eod_ldm_p_sample": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp]),
+    "eod_ldm_p_sample": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
     "eod_randn_philox": (i32, [vp, i32, i64, C.c_uint64, i64, i32, i32, vp]),
     "eod_program_run": (i32, [C.POINTER(Op), i32, vp]),
     "eod_timer_create": (vp, [i32, i32]),

@@ -106,9 +106,17 @@ def timestep_frequencies(dim, max_period=10000):
 
 
 def timestep_embedding(timesteps, dim, max_period=10000):
-    """Sinusoidal embedding [N, dim] (unet_openai.py:81-99).  On the HIP path it is fused into
-    eod_time_embed (first Linear of time_embed), so this symbol exists for API compatibility only."""
-    raise _lib.EodError("timestep_embedding is fused into eod_time_embed on the HIP path; call UNetModel.forward")
+    """Sinusoidal embedding [N, dim] of a 1-D tensor of (possibly fractional) timesteps (unet_openai.py:81-99).  Inside
+    UNetModel.forward the sinusoid is fused into the first Linear of time_embed (eod_time_embed); this standalone form is one
+    launch of eod_timestep_embedding."""
+    require_gpu(timesteps, "timestep_embedding")
+    t = timesteps.detach().to(th.float32).contiguous()
+    assert t.dim() == 1, "timesteps must be a 1-D tensor"
+    freqs = timestep_frequencies(dim, max_period).to(t.device)
+    out = th.empty((t.shape[0], dim), dtype=th.float32, device=t.device)
+    _lib.check(_lib.lib().eod_timestep_embedding(t.data_ptr(), freqs.data_ptr() if dim >= 2 else 0, out.data_ptr(), t.shape[0], dim,
+                                                 current_stream_ptr(t.device)), "eod_timestep_embedding")
+    return out
 
 
 def checkpoint(func, inputs, params, flag):
@@ -132,7 +140,8 @@ class _Emitter(nn.Module):
     def _standalone(self, x, emit, extra_key=()):
         require_gpu(x, type(self).__name__)
         if th.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward kernels are not built yet: wrap the call in torch.no_grad()")
+            raise NotImplementedError(f"{type(self).__name__} called standalone runs inference only: wrap the call in torch.no_grad() "
+                                      "(training goes through UNetModel.forward, which has the HIP backward)")
         prec = self._precision or default_precision()
         N, Cc, H, W = x.shape
         prog = Program(x.device, prec)

@@ -338,6 +338,30 @@ __global__ __launch_bounds__(256) void temb_table_linear_kernel(const float* __r
     }
 }
 
+// standalone timestep_embedding (unet_openai.py:81-99): out[n] = [cos(t_n f) | sin(t_n f)] (+ one zero column when dim is odd)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int N,
+                                          int dim) {
+    const int half = dim / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)N * dim; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / dim), k = (int)(i - (long long)n * dim);
+        float e = 0.0f;
+        if (k < half)
+            e = cosf(t[n] * freqs[k]);
+        else if (k < 2 * half)
+            e = sinf(t[n] * freqs[k - half]);
+        out[i] = e;
+    }
+}
+
+extern "C" int eod_timestep_embedding(const float* t, const float* freqs, float* out, int N, int dim, void* stream) {
+    EOD_REQUIRE(t && out && N > 0 && dim > 0 && (freqs || dim < 2), "timestep_embedding: bad args");
+    const long long total = (long long)N * dim;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, freqs, out, N, dim);
+    EOD_CHECK_LAUNCH("timestep_embedding");
+    return EOD_OK;
+}
+
 extern "C" int eod_time_embed(const eod_temb_desc* d, void* stream) {
     EOD_REQUIRE(d && d->emb, "time_embed: null pointer");
     EOD_REQUIRE(d->N > 0 && d->E > 0 && d->J >= 0, "time_embed: bad dims");

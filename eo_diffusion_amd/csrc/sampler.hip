@@ -12,6 +12,14 @@
 //   ddim_step     diffusion/ddim.py:192-206
 #include "common.h"
 
+// Caller-supplied timesteps index the schedule tables: an index outside [0, T) would read behind them (the reference's gather
+// raises there).  Such a sample is computed with index 0 and its whole output is poisoned with NaN -- loud, but memory-safe.
+__device__ __forceinline__ long long checked_t(long long tn, int T, bool& bad) {
+    bad = tn < 0 || tn >= (long long)T;
+    return bad ? 0 : tn;
+}
+#define EOD_POISON(bad, v) ((bad) ? __builtin_nanf("") : (v))
+
 __device__ __forceinline__ long long tmin_of(const long long* t, int N) {
     long long m = t[0];
     for (int i = 1; i < N; ++i) m = t[i] < m ? t[i] : m;
@@ -20,22 +28,26 @@ __device__ __forceinline__ long long tmin_of(const long long* t, int N) {
 
 // grid (blocks, N): blockIdx.y = sample, so per-sample coefficients are computed once per thread.
 __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
-                                const float* __restrict__ sa, const float* __restrict__ sb, float* __restrict__ out, long long chw) {
+                                const float* __restrict__ sa, const float* __restrict__ sb, float* __restrict__ out, long long chw, int T) {
     const int n = blockIdx.y;
-    const float a = sa[t[n]], b = sb[t[n]];
+    bool bad;
+    const long long tn = checked_t(t[n], T, bad);
+    const float a = sa[tn], b = sb[tn];
     const long long base = (long long)n * chw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (long long)gridDim.x * blockDim.x) {
         const float p = a * x0[base + i];
         const float q = b * noise[base + i];
-        out[base + i] = p + q;
+        out[base + i] = EOD_POISON(bad, p + q);
     }
 }
 
 __global__ void repaint_mix_kernel(const float* __restrict__ x_t, const float* __restrict__ gt, const float* __restrict__ mask,
                                    const float* __restrict__ noise, const long long* __restrict__ t, const float* __restrict__ sa,
-                                   const float* __restrict__ sb, float* __restrict__ out, int C, long long hw) {
+                                   const float* __restrict__ sb, float* __restrict__ out, int C, long long hw, int T) {
     const int n = blockIdx.y;
-    const float a = sa[t[n]], b = sb[t[n]];
+    bool bad;
+    const long long tn = checked_t(t[n], T, bad);
+    const float a = sa[tn], b = sb[tn];
     const long long chw = (long long)C * hw, base = (long long)n * chw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += (long long)gridDim.x * blockDim.x) {
         const float m = mask[(long long)n * hw + (i % hw)];
@@ -45,7 +57,7 @@ __global__ void repaint_mix_kernel(const float* __restrict__ x_t, const float* _
         const float l = m * gn;              // mask*gt_noised
         const float om = 1.0f - m;           // (1-mask)
         const float r = om * x_t[base + i];  // (1-mask)*x_t
-        out[base + i] = l + r;
+        out[base + i] = EOD_POISON(bad, l + r);
     }
 }
 
@@ -53,9 +65,10 @@ template <bool CLIP>
 __global__ void ddpm_step_kernel(const float* __restrict__ x_t, const float* __restrict__ pred, const float* __restrict__ noise,
                                  const long long* __restrict__ t, const float* __restrict__ betas, const float* __restrict__ alphas,
                                  const float* __restrict__ acp, const float* __restrict__ s1m, float* __restrict__ out, int N,
-                                 long long chw) {
+                                 long long chw, int T) {
     const int n = blockIdx.y;
-    const long long tn = t[n];
+    bool bad;
+    const long long tn = checked_t(t[n], T, bad);
     const bool all_pos = tmin_of(t, N) > 0;  // the reference branches on the BATCH minimum (model.py:113,140)
     const float alpha_t = alphas[tn], acp_t = acp[tn], beta_t = betas[tn];
     float c_x0 = 0.f, c_pred = 0.f, m_x0 = 0.f, m_xt = 0.f, std = 0.0f, k_mean = 0.f, k_pred = 0.f;
@@ -100,7 +113,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x_t, const float* __r
             mean = k_mean * d;
         }
         const float sz = std * z;
-        out[base + i] = mean + sz;
+        out[base + i] = EOD_POISON(bad, mean + sz);
     }
 }
 
@@ -146,9 +159,10 @@ template <bool CLIP>
 __global__ void ldm_p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
                                     const long long* __restrict__ t, const float* __restrict__ sr, const float* __restrict__ srm1,
                                     const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ lv,
-                                    float* __restrict__ out, long long chw) {
+                                    float* __restrict__ out, long long chw, int T) {
     const int n = blockIdx.y;
-    const long long tn = t[n];
+    bool bad;
+    const long long tn = checked_t(t[n], T, bad);
     const float a = sr[tn], b = srm1[tn], k1 = c1[tn], k2 = c2[tn];
     const float nonzero = 1.0f - (tn == 0 ? 1.0f : 0.0f);
     const float sd = expf(0.5f * lv[tn]);
@@ -164,7 +178,7 @@ __global__ void ldm_p_sample_kernel(const float* __restrict__ x, const float* __
         const float q = k2 * xv;
         const float mean = p + q;
         const float z = ns * noise[base + i];
-        out[base + i] = mean + z;
+        out[base + i] = EOD_POISON(bad, mean + z);
     }
 }
 
@@ -178,7 +192,7 @@ static inline unsigned blocks_for(long long n, int cap) {
 extern "C" int eod_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp,
                             float* out, int N, int64_t chw, int T, void* stream) {
     EOD_REQUIRE(x0 && noise && t && sqrt_acp && sqrt_1m_acp && out && N > 0 && chw > 0 && T > 0, "q_sample: bad args");
-    hipLaunchKernelGGL(q_sample_kernel, dim3(blocks_for(chw, 512), N), dim3(256), 0, (hipStream_t)stream, x0, noise, (const long long*)t, sqrt_acp, sqrt_1m_acp, out, (long long)chw);
+    hipLaunchKernelGGL(q_sample_kernel, dim3(blocks_for(chw, 512), N), dim3(256), 0, (hipStream_t)stream, x0, noise, (const long long*)t, sqrt_acp, sqrt_1m_acp, out, (long long)chw, T);
     EOD_CHECK_LAUNCH("q_sample");
     return EOD_OK;
 }
@@ -186,8 +200,8 @@ extern "C" int eod_q_sample(const float* x0, const float* noise, const int64_t* 
 extern "C" int eod_repaint_mix(const float* x_t, const float* gt, const float* mask, const float* noise, const int64_t* t,
                                const float* sqrt_acp, const float* sqrt_1m_acp, float* out, int N, int C, int64_t hw, int T,
                                void* stream) {
-    EOD_REQUIRE(x_t && gt && mask && noise && t && sqrt_acp && sqrt_1m_acp && out && N > 0 && C > 0 && hw > 0, "repaint_mix: bad args");
-    hipLaunchKernelGGL(repaint_mix_kernel, dim3(blocks_for((long long)C * hw, 512), N), dim3(256), 0, (hipStream_t)stream, x_t, gt, mask, noise, (const long long*)t, sqrt_acp, sqrt_1m_acp, out, C, (long long)hw);
+    EOD_REQUIRE(x_t && gt && mask && noise && t && sqrt_acp && sqrt_1m_acp && out && N > 0 && C > 0 && hw > 0 && T > 0, "repaint_mix: bad args");
+    hipLaunchKernelGGL(repaint_mix_kernel, dim3(blocks_for((long long)C * hw, 512), N), dim3(256), 0, (hipStream_t)stream, x_t, gt, mask, noise, (const long long*)t, sqrt_acp, sqrt_1m_acp, out, C, (long long)hw, T);
     EOD_CHECK_LAUNCH("repaint_mix");
     return EOD_OK;
 }
@@ -195,12 +209,12 @@ extern "C" int eod_repaint_mix(const float* x_t, const float* gt, const float* m
 extern "C" int eod_ddpm_step(const float* x_t, const float* pred, const float* noise, const int64_t* t, const float* betas,
                              const float* alphas, const float* acp, const float* sqrt_1m_acp, float* out, int N, int64_t chw, int T,
                              int clip, void* stream) {
-    EOD_REQUIRE(x_t && pred && noise && t && betas && alphas && acp && sqrt_1m_acp && out && N > 0 && chw > 0, "ddpm_step: bad args");
+    EOD_REQUIRE(x_t && pred && noise && t && betas && alphas && acp && sqrt_1m_acp && out && N > 0 && chw > 0 && T > 0, "ddpm_step: bad args");
     dim3 grid(blocks_for(chw, 512), N);
     if (clip)
-        hipLaunchKernelGGL(ddpm_step_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x_t, pred, noise, (const long long*)t, betas, alphas, acp, sqrt_1m_acp, out, N, (long long)chw);
+        hipLaunchKernelGGL(ddpm_step_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x_t, pred, noise, (const long long*)t, betas, alphas, acp, sqrt_1m_acp, out, N, (long long)chw, T);
     else
-        hipLaunchKernelGGL(ddpm_step_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x_t, pred, noise, (const long long*)t, betas, alphas, acp, sqrt_1m_acp, out, N, (long long)chw);
+        hipLaunchKernelGGL(ddpm_step_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x_t, pred, noise, (const long long*)t, betas, alphas, acp, sqrt_1m_acp, out, N, (long long)chw, T);
     EOD_CHECK_LAUNCH("ddpm_step");
     return EOD_OK;
 }
@@ -270,14 +284,14 @@ extern "C" int eod_cfg_combine(const float* e_uncond, const float* e_cond, float
 
 extern "C" int eod_ldm_p_sample(const float* x, const float* eps, const float* noise, const int64_t* t, const float* sqrt_recip_acp,
                                 const float* sqrt_recipm1_acp, const float* post_coef1, const float* post_coef2,
-                                const float* post_logvar, float* out, int N, int64_t chw, int clip, void* stream) {
-    EOD_REQUIRE(x && eps && noise && t && sqrt_recip_acp && sqrt_recipm1_acp && post_coef1 && post_coef2 && post_logvar && out && N > 0 && chw > 0,
+                                const float* post_logvar, float* out, int N, int64_t chw, int T, int clip, void* stream) {
+    EOD_REQUIRE(x && eps && noise && t && sqrt_recip_acp && sqrt_recipm1_acp && post_coef1 && post_coef2 && post_logvar && out && N > 0 && chw > 0 && T > 0,
                 "ldm_p_sample: bad args");
     dim3 grid(blocks_for(chw, 512), N);
     if (clip)
-        hipLaunchKernelGGL(ldm_p_sample_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, eps, noise, (const long long*)t, sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2, post_logvar, out, (long long)chw);
+        hipLaunchKernelGGL(ldm_p_sample_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, eps, noise, (const long long*)t, sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2, post_logvar, out, (long long)chw, T);
     else
-        hipLaunchKernelGGL(ldm_p_sample_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, eps, noise, (const long long*)t, sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2, post_logvar, out, (long long)chw);
+        hipLaunchKernelGGL(ldm_p_sample_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, eps, noise, (const long long*)t, sqrt_recip_acp, sqrt_recipm1_acp, post_coef1, post_coef2, post_logvar, out, (long long)chw, T);
     EOD_CHECK_LAUNCH("ldm_p_sample");
     return EOD_OK;
 }

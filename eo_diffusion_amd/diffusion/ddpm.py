@@ -108,7 +108,7 @@ class DDPM(nn.Module):
             xx.data_ptr(), eps.data_ptr(), nz.data_ptr(), t.data_ptr(), self.sqrt_recip_alphas_cumprod.data_ptr(),
             self.sqrt_recipm1_alphas_cumprod.data_ptr(), self.posterior_mean_coef1.data_ptr(),
             self.posterior_mean_coef2.data_ptr(), self.posterior_log_variance_clipped.data_ptr(), out.data_ptr(), n,
-            xx.numel() // n, int(clip_denoised), current_stream_ptr(xx.device)), "eod_ldm_p_sample")
+            xx.numel() // n, self.num_timesteps, int(clip_denoised), current_stream_ptr(xx.device)), "eod_ldm_p_sample")
         return out
 
     @torch.no_grad()

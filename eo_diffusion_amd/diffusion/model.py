@@ -67,8 +67,14 @@ class EODiffusion(nn.Module):
         if self.betas.device != dev:
             raise _lib.EodError(f"EODiffusion buffers are on {self.betas.device}, data on {dev}: call .to(device) first")
 
-    @staticmethod
-    def _t64(t, dev):
+    def _t64(self, t, dev):
+        """timesteps as int64 on the device.  A host-side tensor is range-checked here for free (the reference's gather raises
+        on an index outside [0, T)); for device tensors the kernels poison that sample's output with NaN instead of reading
+        behind the schedule tables (no host synchronisation on the hot path)."""
+        if t.device.type == "cpu" and t.numel():
+            lo, hi = int(t.min()), int(t.max())
+            if lo < 0 or hi >= self.timesteps:
+                raise IndexError(f"timestep index out of range: got [{lo}, {hi}], schedule has {self.timesteps} steps")
         return t.to(device=dev, dtype=torch.int64).contiguous()
 
     # ------------------------------------------------------------------ training forward (model.py:38-44)

@@ -77,9 +77,11 @@ class AdamW(torch.optim.Optimizer):
         for group, st in zip(self.param_groups, self._flat):
             if st is None:
                 continue
+            untouched = []  # torch.optim.AdamW skips parameters without a gradient (no decay, no state update): keep their values
             for p, gv in zip(st["params"], st["gviews"]):
                 if p.grad is None:
                     gv.zero_()
+                    untouched.append((p, p.detach().clone()))
                 elif p.grad.data_ptr() != gv.data_ptr():
                     gv.copy_(p.grad)
             st["step"] += 1
@@ -87,6 +89,8 @@ class AdamW(torch.optim.Optimizer):
             check(L.eod_adamw_step(ptr(st["p"]), ptr(st["g"]), ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]), float(b1),
                                    float(b2), float(group["eps"]), float(group["weight_decay"]), st["step"], current_stream_ptr(st["p"].device)),
                   "eod_adamw_step")
+            for p, keep in untouched:  # (zero gradient -> m, v stay as they were; only the decoupled weight decay has to be undone)
+                p.detach().copy_(keep)
             for p in st["params"]:  # written through the flat buffer: advance torch's version counters (the packed-weight
                 torch.autograd.graph.increment_version(p)  # caches of the kernels key on them); no kernel is launched
         return loss
@@ -142,4 +146,9 @@ class ExponentialMovingAverage(torch.nn.Module):
                     check(L.eod_ema_update(ptr(a), ptr(b.detach().contiguous()), a.numel(), self.decay, st), "eod_ema_update")
                 else:
                     a.copy_(b.detach().to(a.device))
+            # the kernels wrote through raw pointers: advance torch's version counters so that the EMA copy's cached launch
+            # program (packed conv / qkv / proj weights, keyed on (data_ptr, _version)) is rebuilt before its next forward
+            for a, _ in pairs:
+                if a.is_cuda and a.dtype == torch.float32:
+                    torch.autograd.graph.increment_version(a)
         self.n_averaged += 1

@@ -106,9 +106,20 @@ class UNetTrainer:
         self.dropout_seed = int(torch.initial_seed() if dropout_seed is None else dropout_seed) & (2**63 - 1)
         self._drop_ops = []  # forward executor ops whose `step` field is refreshed every forward
         self._alloc_flat_grad()
+        # descriptors below bake raw device pointers of the LIVE parameters (biases, GroupNorm affine, timestep MLP): remember
+        # where every parameter lives so that a later re-pointing (optim.AdamW's flat buffer, .to(), load_state_dict(assign=True))
+        # is noticed instead of silently training on the old storage
+        self._param_ptrs = self._ptr_fingerprint()
         self._build(cond_channels)
 
     # ------------------------------------------------------------------ small helpers
+    def _ptr_fingerprint(self):
+        return tuple(p.data_ptr() for p in self.unet.parameters())
+
+    def stale(self):
+        """True when a parameter's storage moved after this trainer was built (its descriptors point at the old storage)"""
+        return self._ptr_fingerprint() != self._param_ptrs
+
     def _call(self, fn, *args):
         self.bwd.append(("call", fn, args))
 
@@ -763,6 +774,9 @@ class UNetTrainer:
     def forward(self, x, timesteps, cond=None, y=None):
         """x NCHW fp32 on the GPU, timesteps int64 [N] -> prediction NCHW fp32 (a buffer owned by the trainer)"""
         assert (y is not None) == self.with_y, "must specify y if and only if the model is class-conditional"
+        if self.stale():
+            raise EodError("UNetTrainer: the UNet's parameter storage moved after this trainer was built (optimizer flat buffer, "
+                           ".to(), load_state_dict(assign=True)); build the optimizer first or create a new UNetTrainer")
         self.step_id += 1
         for fn in self.repack:
             fn()
@@ -816,13 +830,12 @@ class UNetTrainer:
             w.wait()
         if works and world > 1:
             self.flat_grad.div_(world)
+        # parameters the forward never uses (the reference's dead `nout` / `conv_out` head, unet_openai.py:744) get NO gradient,
+        # exactly like autograd: torch.optim.AdamW then skips them (no weight decay), and so does optim.AdamW
         if not assign:
-            return [self.pgrad[p].to(p.dtype).clone() if p in self.pgrad else torch.zeros_like(p) for p in self.unet.parameters()]
+            return [self.pgrad[p].to(p.dtype).clone() if p in self.pgrad else None for p in self.unet.parameters()]
         for p, g in self.pgrad.items():
             p.grad = g
-        for p in self.unet.parameters():
-            if p.grad is None:
-                p.grad = torch.zeros_like(p, dtype=torch.float32)
         return None
 
 
@@ -854,6 +867,9 @@ def unet_train_forward(unet, x, timesteps, cond=None, y=None):
     cache = unet.__dict__.setdefault("_eod_trainers", {})
     key = (N, cx, ccond, H, W, str(x.device), unet.precision, bool(unet.training))  # (train / eval differ by the dropout ops)
     tr = cache.get(key)
+    if tr is not None and tr.stale():  # parameter storage moved (optimizer flat buffer, .to(), ...): its pointers are dead
+        del cache[key]
+        tr = None
     if tr is None:
         import os
         scale = float(os.environ.get("EOD_LOSS_SCALE", "1024" if unet.precision == "fp16" else "1"))

@@ -193,11 +193,15 @@ typedef struct {
     int32_t N, D, E, J;
 } eod_temb_desc;
 int eod_time_embed(const eod_temb_desc* d, void* stream);
+/* the sinusoid alone (timestep_embedding, unet_openai.py:81-99; the reference's standalone helper): out [N][dim] fp32 =
+ * [cos(t f) | sin(t f)] (+ a zero column when dim is odd); t fp32 [N] (may be fractional), freqs[dim/2] as above */
+int eod_timestep_embedding(const float* t, const float* freqs, float* out, int N, int dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * k11-k15: fused sampler updates.  fp32, built with -ffp-contract=off so that every rounding of
  * the reference's torch op sequence is reproduced bit-for-bit.  x/pred/noise/out are [N][CHW] fp32.
- * tables are the EODiffusion buffers (model.py:23-32), t is int64 [N].
+ * tables are the EODiffusion buffers (model.py:23-32) of length T, t is int64 [N].  A timestep outside [0, T) never reads
+ * behind the tables: that sample's output is filled with NaN (the reference's gather raises there).
  * ------------------------------------------------------------------------------------------ */
 /* model.py:94-98 (== ddpm.py:279-282) */
 int eod_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp,
@@ -217,10 +221,10 @@ int eod_ddim_step(const float* x, const float* e_t, const float* noise, float a_
 /* classifier-free guidance of p_sample_ddim (ddim.py:177-181): out = e_uncond + scale * (e_cond - e_uncond) */
 int eod_cfg_combine(const float* e_uncond, const float* e_cond, float scale, float* out, int64_t numel, void* stream);
 /* table-driven DDPM step of the LDM-derived sampler: DDPM.p_sample ddpm.py:248-255 with predict_start_from_noise :221-225,
- * q_posterior :227-234 (tables of register_schedule :122-162, fp32 [T]); noise masked per sample at t == 0. */
+ * q_posterior :227-234 (tables of register_schedule :122-162, fp32 [T]); noise masked per sample at t == 0.  t outside [0, T): NaN. */
 int eod_ldm_p_sample(const float* x, const float* eps, const float* noise, const int64_t* t, const float* sqrt_recip_acp,
                      const float* sqrt_recipm1_acp, const float* post_coef1, const float* post_coef2,
-                     const float* post_logvar, float* out, int N, int64_t chw, int clip, void* stream);
+                     const float* post_logvar, float* out, int N, int64_t chw, int T, int clip, void* stream);
 /* k15: counter-based N(0,1): Philox4x32-10 keyed by seed, counter = (element/4, sample0+n, step, stream_id)
  * -> results are invariant to how samples are sharded over ranks. */
 int eod_randn_philox(float* out, int N, int64_t chw, uint64_t seed, int64_t sample0, int32_t step,

@@ -170,3 +170,17 @@ def test_unet_non_square_and_odd_batch(prec, shape):
     with torch.no_grad():
         out = u(x.to(DEV), t.to(DEV)).cpu()
     assert rel_l2(out, UR.unet_forward(sd, cfg, x, t)) < TOL[prec]
+
+
+def test_timestep_embedding_standalone_vs_golden():
+    """timestep_embedding (unet_openai.py:81-99) as its own call, against what the reference returned for t in {0, 1, 499, 999}
+    at dims 32 / 128 / 33 (odd: one zero column).  The arguments reach 999 rad, so this also pins the range reduction."""
+    from eo_diffusion_amd.backbones.unet_openai import timestep_embedding
+    g = gt("temb")
+    for dim in (32, 128, 33):
+        e = timestep_embedding(g["t"].to(DEV), dim).cpu()
+        ref = g[f"d{dim}"]
+        assert e.shape == ref.shape and e.dtype == torch.float32
+        assert float((e - ref).abs().max()) < 2e-6, dim  # values are in [-1, 1]: absolute = relative to the scale
+    frac = timestep_embedding(torch.tensor([0.5, 10.25], device=DEV), 8).cpu()  # fractional timesteps are allowed
+    assert bool(torch.isfinite(frac).all()) and float((frac[:, :4] ** 2 + frac[:, 4:] ** 2 - 1).abs().max()) < 1e-6

@@ -135,7 +135,11 @@ def test_reference_training_loop_drop_in(use_fp16):
         assert pred.requires_grad
         loss = loss_fn(pred, noise)
         loss.backward()
-        assert all(p.grad is not None for p in model.parameters() if p.requires_grad)
+        # every parameter the forward uses has a gradient; the reference's dead duplicate head (nout / conv_out,
+        # unet_openai.py:744) gets None, as under torch autograd (torch.optim.AdamW then leaves it alone)
+        dead = ("nout.", "conv_out.")
+        assert all((p.grad is None) == any(d in n for d in dead) for n, p in model.named_parameters()), \
+            [n for n, p in model.named_parameters() if p.grad is None]
         opt.step()
         opt.zero_grad()
         ema.update_parameters(model)
@@ -152,11 +156,15 @@ def test_autograd_accumulates_like_torch():
     xg, ng, tg = x.to(DEV), noise.to(DEV), t.to(DEV)
     loss = torch.nn.functional.mse_loss(m(xg, tg), ng)
     loss.backward()
-    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    assert len(g1) >= len(list(m.parameters())) - 4  # all but the dead duplicate head (nout / conv_out)
     loss = torch.nn.functional.mse_loss(m(xg, tg), ng)
     loss.backward()
     for n, p in m.named_parameters():
-        assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-6, atol=1e-12), n
+        if n in g1:
+            assert torch.allclose(p.grad, 2 * g1[n], rtol=1e-6, atol=1e-12), n
+        else:
+            assert p.grad is None, n
 
 
 def test_fused_adamw_ema_mse_bit_exact_vs_oracle():
@@ -453,9 +461,10 @@ def test_factory_presets_train_as_is(factory, size):
         loss = torch.nn.functional.mse_loss(m(x, t, y=y), noise)
         loss.backward()
         if not losses:
-            bad = [n for n, p in m.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+            live = [(n, p) for n, p in m.named_parameters() if not (n.startswith("nout.") or n.startswith("conv_out."))]
+            bad = [n for n, p in live if p.grad is None or not bool(torch.isfinite(p.grad).all())]
             assert not bad, bad[:5]
-            assert sum(float(p.grad.abs().sum()) > 0 for p in m.parameters()) > 0.9 * len(list(m.parameters()))
+            assert sum(float(p.grad.abs().sum()) > 0 for _, p in live) > 0.9 * len(live)
         opt.step()
         opt.zero_grad()
         losses.append(float(loss.detach()))
