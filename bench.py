@@ -8,11 +8,20 @@ EODiffusion.sampling (model.py:54-69).  Workload at N=1 is the shape BASELINE.js
 With --gpus N each rank runs the same per-GPU batch (config 4: 8 x 16 = 128 images; weak scaling), no
 per-step communication; the final images are all-gathered once over RCCL.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp16|fp32] [--arch A0|A1] [--size 256] [--batch 16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|fp16] [--arch A0|A1] [--size 256] [--batch 16]
+
+The headline (`value`, `dtype`) is measured in the REFERENCE's precision: fp32 storage and arithmetic (the reference runs this path
+in fp32 everywhere, SURVEY.md section 8 legend), rel-L2 <= 1e-5 vs the fp32 CPU oracle.  The fp16-storage / fp16-MFMA mode
+(tolerance 5e-3) is timed in the same run and reported as the labelled secondary object `fp16`.
+
+`--gpus N` with N > 1 and no torchrun environment: this process starts the N ranks itself (torch.distributed.run, one rank per
+GPU, RCCL) BEFORE touching the GPU and relays their output; under the driver's own `python -m torch.distributed.run ... bench.py
+--gpus N` launch the ranks read RANK / LOCAL_RANK / WORLD_SIZE from the environment.  A world size that differs from --gpus is
+an error, never a silent single-rank run.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (MFMA implicit-GEMM conv kernel, per-launch
 HIP-event timing on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on the
-host cores on a bounded sample of the same workload).
+host cores on a bounded sample of the same workload, plus BASELINE config 1 -- MNIST, T = 200 -- end to end).
 """
 import argparse
 import json
@@ -31,7 +40,11 @@ ARCHS = {
 }
 # algorithmic GFLOP per denoising step, whole batch (conv 2*N*Cout*Ho*Wo*Cin*k*k, linear 2*N*in*out,
 # attention 4*N*T^2*C): A0@256/16 = 10303.7
-PEAK = {"fp16": 2.5e15, "fp32": 157.3e12}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK = {"fp32": 157.3e12, "fp16": 2.5e15}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_NOTE = {}
+DTYPE_NAME = {"fp32": "f32", "fp16": "f16"}
+TOLERANCE = {"fp32": "rel-L2 <= 1e-5 per UNet forward vs the fp32 CPU oracle (fp32 storage, exact fp32 MFMA)",
+             "fp16": "rel-L2 <= 5e-3 per UNet forward vs the fp32 CPU oracle (fp16 storage, fp16 MFMA, fp32 accumulate)"}
 HBM_PEAK = 8.0e12
 
 
@@ -76,6 +89,38 @@ def host_cores():
     return min(n, int(os.environ.get("EOD_CPU_THREADS", "16")))
 
 
+def cpu_config1_mnist(seconds_cap=40.0):
+    """BASELINE config 1 end to end on the host cores: MNIST-shaped unconditional DDPM (28x28x1, base 32, mults [2,4],
+    scripts/train_mnist.py:46-48), T = 200, a complete `sampling()` call of the CPU oracle (x_T draw + 200 x (randn + UNet +
+    clipped update)), batch 4 -- the case the reference itself can run without a GPU."""
+    from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
+    from oracle import sampler_ref, schedule, unet_ref
+    from tests.synth import synth_state_dict
+    cfg = dict(image_size=28, in_channels=1, out_channels=1, model_channels=32, channel_mult=[2, 4], attention_resolutions=[],
+               num_res_blocks=1, num_heads=1)
+    sd = synth_state_dict(unet_param_shapes(**cfg), 7)
+    T, bs = 200, 4
+    tb = schedule.eo_cosine_tables(T)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((bs, 1, 28, 28), generator=g)
+    done = 0
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for i in range(T - 1, -1, -1):
+            t = torch.full((bs,), i, dtype=torch.int64)
+            noise = torch.randn(x.shape, generator=g)
+            x = sampler_ref.ddpm_step_clip(tb, x, t, noise, unet_ref.unet_forward(sd, cfg, x, t))
+            done += 1
+            if time.perf_counter() - t0 > seconds_cap:
+                break
+        dt = time.perf_counter() - t0
+    full = dt * T / done
+    return {"images_per_s": bs / full, "steps_per_s": done / dt, "seconds_per_call": full, "timesteps": T, "batch": bs,
+            "steps_timed": done, "finite": bool(torch.isfinite(x).all()),
+            "what": "config 1: 28x28x1 unconditional DDPM, T=200, complete sampling call of the CPU oracle"
+                    + ("" if done == T else f" (capped after {done} steps, extrapolated)")}
+
+
 def cpu_baseline(arch, size, batch, seconds_budget=25.0):
     """Oracle (CPU restatement of the reference, oracle/) timed on the host cores: bounded sample."""
     from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
@@ -105,72 +150,77 @@ def cpu_baseline(arch, size, batch, seconds_budget=25.0):
             x = step(x)
         dt = (time.perf_counter() - t0) / n
     steps_per_s_bs = 1.0 / dt
-    return {"value": steps_per_s_bs * bs / batch, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} timed step(s) of the CPU oracle (UNet fwd + randn + DDPM update) at batch {bs} "
-                      f"({size}x{size}, arch {arch}, {dt:.2f} s/step), scaled by {bs}/{batch} to batch {batch}; torch CPU fp32, "
-                      f"{cores} threads"}
+    out = {"value": steps_per_s_bs * bs / batch, "unit": "steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n} timed step(s) of the CPU oracle (UNet fwd + randn + DDPM update) at batch {bs} "
+                     f"({size}x{size}, arch {arch}, {dt:.2f} s/step), scaled by {bs}/{batch} to batch {batch}; torch CPU fp32, "
+                     f"{cores} threads"}
+    try:
+        out["config1_mnist_T200"] = cpu_config1_mnist()
+    except Exception as e:  # the headline baseline above stands on its own
+        out["config1_mnist_T200"] = {"error": repr(e)}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
-    ap.add_argument("--arch", default="A0", choices=list(ARCHS))
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--graph", action="store_true", help="replay the UNet program as one hipGraph launch")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-op-timing", action="store_true")
-    ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (JSON) here")
-    ap.add_argument("--train", action="store_true", help="time the TRAINING step (forward + MSE + backward + fused AdamW [+ gradient "
-                    "all-reduce for N > 1]) instead of the sampling step; SURVEY section 8f rank 1 / BASELINE config 5")
-    ap.add_argument("--in-ch", type=int, default=3)
-    args = ap.parse_args()
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or os.environ.get("EOD_BENCH_FORCE_DIST") == "1"  # (FORCE: rehearse the RCCL path on one GPU)
-    if use_dist:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")  # RCCL on ROCm
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
 
-    if args.train:
-        return train_main(args, world, rank, dev, use_dist)
-    m = build_model(args.arch, args.size, args.precision, dev)
-    if args.graph:
-        m.model.enable_graph(True)
-        args.no_op_timing = True  # the event-bracketing executor cannot be captured
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks as CHILD processes (one per GPU, RCCL) and relay
+    their output.  Runs before this process has made any GPU call (a process that has initialised the GPU must never exec)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), EOD_BENCH_CHILD="1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def time_sampling(args, m, dev, rank, world, use_dist, dist, timing=True):
+    """warm-up, then EXACTLY args.steps denoising steps between two barrier + synchronize; returns (seconds [max over ranks],
+    final x_t, roofline dict or None)"""
     N, S = args.batch, args.size
     shape = (N, 3, S, S)
     seed, sample0 = 3, rank * N
-    x_t = m._philox(shape, dev, 2, sample0, m.timesteps, 0)
+    stub = m is None
+    if stub:  # CPU rehearsal of the launch / barrier / reduction plumbing (tests/test_dist_cpu.py): no GPU, no kernels
+        x_t = torch.zeros(shape)
 
-    def one_step(x_t, i):
-        noise = m._philox(shape, dev, seed, sample0, i, 1)
-        t = torch.full((N,), i, dtype=torch.int64, device=dev)
-        pred = m.model(x_t, t)
-        return m._ddpm_update(x_t, pred, noise, t, clip=True)
+        def one_step(x_t, i):
+            return x_t + 1.0
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
+        def sync():
+            pass
+    else:
+        x_t = m._philox(shape, dev, 2, sample0, m.timesteps, 0)
+
+        def one_step(x_t, i):
+            noise = m._philox(shape, dev, seed, sample0, i, 1)
+            t = torch.full((N,), i, dtype=torch.int64, device=dev)
+            pred = m.model(x_t, t)
+            return m._ddpm_update(x_t, pred, noise, t, clip=True)
+
+        def sync():
             torch.cuda.synchronize(dev)
 
+    def barrier():
+        sync()
+        if use_dist:
+            dist.barrier()
+            sync()
+
+    T = 1000 if stub else m.timesteps
+    prog = None
     with torch.no_grad():
-        i = m.timesteps - 1
+        i = T - 1
         for _ in range(args.warmup):
             x_t = one_step(x_t, i)
             i -= 1
-        prog = m.model.program_for(N, 3, 0, S, S, dev, False)
-        timing = not args.no_op_timing
+        timing = timing and not stub and not args.no_op_timing
         if timing:
+            prog = m.model.program_for(N, 3, 0, S, S, dev, False)
             # HIP events only around the dominant kernel's launches (an event pair idles the stream for ~8 us; bracketing
             # all ~130 ops of a step would cost ~1.3 ms/step).  --dump-ops times every op instead.
             stats0 = prog.op_stats()
@@ -180,20 +230,19 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             x_t = one_step(x_t, i)
-            i = i - 1 if i > 0 else m.timesteps - 1
+            i = i - 1 if i > 0 else T - 1
         if use_dist:  # the one collective of the path: gather the final images
-            out = torch.empty((world * N, 3, S, S), dtype=torch.float32, device=dev)
+            out = torch.empty((world * N, 3, S, S), dtype=torch.float32, device=x_t.device)
             dist.all_gather_into_tensor(out, x_t.contiguous())
         barrier()
         dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=x_t.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    finite = bool(torch.isfinite(x_t).all())
-
     roof = None
     if timing:
+        prec = m.model.precision
         runs, ms = prog.read_timing()
         stats = prog.op_stats()
         prog.disable_timing()
@@ -204,31 +253,102 @@ def main():
         nl = len(conv)
         afl = sum(s["flops"] for s, _ in allconv)
         asec = sum(t for _, t in allconv) / runs * 1e-3
+        peak = PEAK[prec]
         roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel (3x3 stride-1 convs of one UNet forward, incl. virtual-2x-upsample ones)",
-                "achieved": fl / tsec / 1e12, "peak": PEAK[args.precision] / 1e12, "unit": "TFLOP/s",
-                "frac": fl / tsec / PEAK[args.precision], "traffic": None,
+                "achieved": fl / tsec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": fl / tsec / peak, "traffic": None,
                 "launches_per_step": nl, "avg_launch_ms": tsec * 1e3 / nl, "algorithmic_gflop_per_launch_avg": fl / nl / 1e9,
                 "kernel_ms_per_step": tsec * 1e3,
                 "kernel_share_of_step": tsec / (dt / args.steps)}
+        if prec in PEAK_NOTE:
+            roof["peak_note"] = PEAK_NOTE[prec]
         if args.dump_ops:
             roof["all_conv_launches"] = {"launches_per_step": len(allconv), "ms_per_step": asec * 1e3,
-                                         "achieved_tflops": afl / asec / 1e12, "frac": afl / asec / PEAK[args.precision]}
+                                         "achieved_tflops": afl / asec / 1e12, "frac": afl / asec / peak}
             roof["all_ops_ms_per_step"] = sum(ms) / runs
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 prof = json.load(open(tf))
-                roof["traffic"] = prof.get(f"{args.arch}_{args.size}_{args.batch}_{args.precision}")
-                if args.precision == "fp16" and "_pmc_mfma" in prof:
-                    # PMC evidence from the committed rocprofv3 pass (not measured in this run): the MFMA pipes are busy
-                    # this fraction of the GPU cycles; the clock the chip sustains under this load is far below 2.4 GHz
-                    roof["pmc_mfma"] = prof["_pmc_mfma"]
+                key = f"{args.arch}_{args.size}_{args.batch}_{prec}"
+                if key in prof:
+                    # NOT measured in this run: HBM bytes per launch from a committed rocprofv3 --pmc pass over the same command
+                    # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); file and commit of origin are named in it
+                    roof["traffic_from_profile"] = prof[key]
             except Exception:
                 pass
         if args.dump_ops and rank == 0:
             rows = [dict(s, ms=t / runs) for s, t in zip(stats, ms)]
-            with open(args.dump_ops, "w") as f:
+            with open(args.dump_ops if prec == args.precision else args.dump_ops + "." + prec, "w") as f:
                 json.dump(rows, f, indent=1)
+    return dt, x_t, roof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="fp32", choices=list(PEAK),
+                    help="headline precision mode (default: the reference's, fp32); the fp16 mode is timed as a secondary object")
+    ap.add_argument("--arch", default="A0", choices=list(ARCHS))
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--graph", action="store_true", help="replay the UNet program as one hipGraph launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (fp16) measurement")
+    ap.add_argument("--no-op-timing", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (JSON) here")
+    ap.add_argument("--train", action="store_true", help="time the TRAINING step (forward + MSE + backward + fused AdamW [+ gradient "
+                    "all-reduce for N > 1]) instead of the sampling step; SURVEY section 8f rank 1 / BASELINE config 5")
+    ap.add_argument("--in-ch", type=int, default=3)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    stub = os.environ.get("EOD_BENCH_STUB") == "1"  # CPU / gloo rehearsal of the multi-rank plumbing (no GPU work)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # nothing above has touched the GPU
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    use_dist = world > 1 or os.environ.get("EOD_BENCH_FORCE_DIST") == "1"  # (FORCE: rehearse the RCCL path on one GPU)
+    dist = None
+    if use_dist:
+        import torch.distributed as dist
+        dist.init_process_group("gloo" if stub else "nccl")  # "nccl" = RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+
+    if args.train:
+        return train_main(args, world, rank, dev, use_dist)
+    N, S = args.batch, args.size
+    m = None if stub else build_model(args.arch, S, args.precision, dev)
+    if args.graph and m is not None:
+        m.model.enable_graph(True)
+        args.no_op_timing = True  # the event-bracketing executor cannot be captured
+    dt, x_t, roof = time_sampling(args, m, dev, rank, world, use_dist, dist)
+    finite = bool(torch.isfinite(x_t).all())
+
+    secondary = None
+    if not stub and not args.no_secondary and args.precision != "fp16":
+        # the reduced-precision mode, same workload, same run: a labelled extra, never the headline
+        del m, x_t
+        torch.cuda.empty_cache()
+        m2 = build_model(args.arch, S, "fp16", dev)
+        dt2, x2, roof2 = time_sampling(args, m2, dev, rank, world, use_dist, dist)
+        secondary = {"value": world * args.steps / dt2, "unit": "steps/s", "ms_per_step": dt2 / args.steps * 1e3, "dtype": "f16",
+                     "tolerance": "rel-L2 <= 5e-3 per UNet forward vs the fp32 CPU oracle (fp16 storage, fp16 MFMA, fp32 accumulate)",
+                     "outputs_finite": bool(torch.isfinite(x2).all()), "roofline": roof2}
+        del m2, x2
 
     if rank == 0:
         steps_per_s = world * args.steps / dt
@@ -236,18 +356,22 @@ def main():
             "metric": "denoising steps/sec (UNet fwd + DDPM update) at 256x256 bs=16",
             "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+            "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
             "config": {"workload": f"DDPM sampling step, {S}x{S}x3, batch {N} per GPU, UNet arch {args.arch} "
                                    f"(base 128, mults [1,2,3,4], {ARCHS[args.arch]['num_res_blocks']} res-block(s), "
                                    f"attn_res {ARCHS[args.arch]['attention_resolutions']}), Philox noise, x0-clipped update",
                        "global_batch": world * N, "image_size": S, "parallelism": f"batch-sharded x{world}",
-                       "accumulate": "fp32"},
+                       "accumulate": "fp32", "precision_mode": args.precision, "tolerance": TOLERANCE[args.precision]},
             "images_per_sec_1000step_ddpm": world * N / (1000.0 * dt / args.steps),
             "outputs_finite": finite,
         }
+        if stub:
+            res["stub"] = True
         if roof:
             res["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1:
+        if secondary:
+            res["fp16"] = secondary
+        if not args.no_cpu_baseline and world == 1 and not stub:
             res["cpu_baseline"] = cpu_baseline(args.arch, S, N)
         print(json.dumps(res), flush=True)
     if use_dist:
@@ -262,8 +386,8 @@ def train_main(args, world, rank, dev, use_dist):
     m = build_model(args.arch, args.size, args.precision, dev, in_ch=args.in_ch)
     unet = m.model.train()
     N, S, C = args.batch, args.size, args.in_ch
+    opt = AdamW(unet.parameters(), lr=1e-4)  # first: it moves the parameters into its flat buffer (the trainer bakes their pointers)
     tr = UNetTrainer(unet, N, S, S, dev, loss_scale=(1024.0 if args.precision == "fp16" else 1.0))
-    opt = AdamW(unet.parameters(), lr=1e-4)
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     x = torch.rand((N, C, S, S), device=dev, generator=g)
     noise = torch.randn((N, C, S, S), device=dev, generator=g)
@@ -299,7 +423,7 @@ def train_main(args, world, rank, dev, use_dist):
         res = {"metric": f"training steps/sec (UNet fwd + MSE + bwd + AdamW) at {S}x{S} bs={N}", "value": world * args.steps / dt,
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+               "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
                "config": {"workload": f"training step, {S}x{S}x{C}, batch {N} per GPU, UNet arch {args.arch}, MSE(eps) loss, fused AdamW, "
                                       f"loss scale {tr.loss_scale:g}", "global_batch": world * N, "image_size": S,
                           "parallelism": f"data-parallel x{world} (one flat-bucket gradient all-reduce per step)", "accumulate": "fp32"},

@@ -89,3 +89,36 @@ def test_allreduce_mean_is_a_noop_without_a_process_group():
     from eo_diffusion_amd.training import allreduce_mean_
     t = torch.ones(8)
     assert allreduce_mean_(t) is t and bool((t == 1).all())
+
+
+def _run_bench(args, extra_env=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EOD_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must itself start 2 ranks (here: the stub step over gloo, no GPU):
+    rank 0 prints ONE line with n_gpus = 2 and the aggregate of both ranks' steps"""
+    r, out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1, r.stdout
+    res = out[0]
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and res["stub"] is True
+    assert res["config"]["global_batch"] == 2 * 16 and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * 3 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]  # whole-job rate = ranks x steps / max time
+
+
+def test_bench_rejects_world_size_mismatch():
+    """a launcher that started fewer ranks than --gpus says is an error, not a silent single-rank measurement"""
+    r, out = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], extra_env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not out
+    assert "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -1,0 +1,253 @@
+"""GPU parity AT THE SIZES BASELINE.json NAMES (not just finite outputs): every config's workload against the CPU oracle.
+
+  config 2  A0 @ 64x64, batch 16          one denoising step (small maps: split-K convs)
+  metric    A0 @ 256x256 (batch 2 here)   UNet forward + 3 recursive DDPM steps  (256^2 halo tiling, 896/1024-channel concat convs,
+  config 4                                the 2 GiB window arithmetic, XCD remap at thousands of tiles -- per-image work is identical
+                                          to batch 16, the batch only multiplies the tile count)
+  config 3  A1 @ 256x256, batch 1         forward + 2 masked (RePaint) DDIM steps through DDIMSampler: attention at T = 4096 / 1024
+  config 5  A1, 13 channels, 128x128      training step: forward + backward vs torch autograd through the oracle (+ the 13-channel
+                                          reference-generated gradient fixture in test_gpu_training.py)
+
+The oracle costs 1-3 s per 256x256 image on the host cores, so its outputs are computed once per configuration and shared by
+the precision modes."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import DEV, TOL
+from tests.helpers import rel_l2
+from tests.synth import rect_mask, synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+A0 = dict(model_channels=128, channel_mult=[1, 2, 3, 4], attention_resolutions=[], num_res_blocks=1, num_heads=1)
+A1 = dict(model_channels=128, channel_mult=[1, 2, 3, 4], attention_resolutions=[4, 8], num_res_blocks=2, num_heads=8)
+PRECS = ["fp32", "fp16"]
+TRAJ = {"fp32": 2e-5, "fp16": 1e-2}
+
+
+def _cfg(arch, size, ch=3):
+    return dict(image_size=size, in_channels=ch, out_channels=ch, **arch)
+
+
+@functools.lru_cache(maxsize=None)
+def _weights(arch_name, size, ch=3):
+    from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
+    cfg = _cfg({"A0": A0, "A1": A1}[arch_name], size, ch)
+    return cfg, synth_state_dict(unet_param_shapes(**cfg), 7)
+
+
+def _unet(arch_name, size, prec, ch=3):
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel
+    cfg, sd = _weights(arch_name, size, ch)
+    u = UNetModel(**cfg).set_precision(prec)
+    u.load_state_dict(sd)
+    return u
+
+
+def _eps_fn(arch_name, size):
+    from oracle import unet_ref as UR
+    cfg, sd = _weights(arch_name, size)
+    return lambda x, t: UR.unet_forward(sd, cfg, x, t)
+
+
+# ------------------------------------------------------------------------------------------------ metric shape: A0 @ 256x256
+@functools.lru_cache(maxsize=None)
+def _a0_256_oracle():
+    from oracle import sampler_ref as SR
+    from oracle import schedule as SCH
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    x = synth_input("b256_x", (2, 3, 256, 256), 1)
+    t = torch.tensor([999, 3])
+    with torch.no_grad():
+        fwd = _eps_fn("A0", 256)(x, t)
+        xT = synth_input("b256_xT", (2, 3, 256, 256), 2)
+        noises = [synth_input(f"b256_n{k}", (2, 3, 256, 256), 3) for k in range(3)]
+        traj = SR.ddpm_sampling(SCH.eo_cosine_tables(3), _eps_fn("A0", 256), xT, noises, 3, clip=True)
+    return x, t, fwd, xT, noises, traj
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_a0_256_forward_vs_oracle(prec):
+    x, t, ref, *_ = _a0_256_oracle()
+    u = _unet("A0", 256, prec).to(DEV).eval()
+    with torch.no_grad():
+        out = u(x.to(DEV), t.to(DEV)).cpu()
+    err = rel_l2(out, ref)
+    print(f"A0@256 forward [{prec}] rel-L2 = {err:.3e}")
+    assert err < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_a0_256_three_ddpm_steps_vs_oracle(prec):
+    """EODiffusion.sampling with a 3-step cosine schedule, injected x_T / noises: the recursion (UNet -> clipped update -> UNet ...)
+    at the metric's image size"""
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    _, _, _, xT, noises, ref = _a0_256_oracle()
+    m = EODiffusion(_unet("A0", 256, prec), timesteps=3, image_size=256, in_channels=3, device=DEV).to(DEV).eval()
+    out = m.sampling(2, device=DEV, x_T=xT, noises=noises, progress=False).cpu()
+    err = rel_l2(out, ref)
+    print(f"A0@256 3 DDPM steps [{prec}] rel-L2 = {err:.3e}")
+    assert err < TRAJ[prec]
+
+
+# ------------------------------------------------------------------------------------------------ config 2: A0 @ 64x64, batch 16
+@functools.lru_cache(maxsize=None)
+def _a0_64_oracle():
+    from oracle import sampler_ref as SR
+    from oracle import schedule as SCH
+    x = synth_input("b64_x", (16, 3, 64, 64), 1)
+    z = synth_input("b64_z", (16, 3, 64, 64), 2)
+    t = torch.full((16,), 700, dtype=torch.int64)
+    with torch.no_grad():
+        eps = _eps_fn("A0", 64)(x, t)
+        step = SR.ddpm_step_clip(SCH.eo_cosine_tables(1000), x, t, z, eps)
+    return x, z, t, eps, step
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_a0_64_batch16_step_vs_oracle(prec):
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    x, z, t, eps_ref, step_ref = _a0_64_oracle()
+    m = EODiffusion(_unet("A0", 64, prec), timesteps=1000, image_size=64, in_channels=3, device=DEV).to(DEV).eval()
+    with torch.no_grad():
+        eps = m.model(x.to(DEV), t.to(DEV)).cpu()
+        out = m._reverse_diffusion_with_clip(x.to(DEV), t.to(DEV), z.to(DEV)).cpu()
+    print(f"A0@64 bs16 [{prec}] eps rel-L2 = {rel_l2(eps, eps_ref):.3e}, step rel-L2 = {rel_l2(out, step_ref):.3e}")
+    assert rel_l2(eps, eps_ref) < TOL[prec] and rel_l2(out, step_ref) < TOL[prec]
+
+
+# ------------------------------------------------------------------------------------------------ config 3: A1 @ 256x256, RePaint DDIM
+@functools.lru_cache(maxsize=None)
+def _a1_256_oracle():
+    from oracle import sampler_ref as SR
+    from oracle import schedule as SCH
+    x = synth_input("c3_x", (1, 3, 256, 256), 1)
+    t = torch.tensor([500])
+    tb = SCH.eo_cosine_tables(1000)
+    steps = SCH.ddim_timesteps("uniform", 250, 1000)
+    dd_full = SCH.ddim_tables(tb["alphas_cumprod"], steps, 0.0)
+    sub = steps[:2]  # what ddim_sampling(timesteps=3) walks: [1, 5] -> t = 5, then t = 1 (ddim.py:126-131)
+    dd = {k: v[:2] for k, v in dd_full.items()}
+    xT = synth_input("c3_xT", (1, 3, 256, 256), 2)
+    x0 = synth_input("c3_x0", (1, 3, 256, 256), 3, uniform=True)
+    mask = rect_mask(1, 256, 256, 4)
+    sn = [synth_input(f"c3_s{k}", (1, 3, 256, 256), 5) for k in range(2)]
+    mn = [synth_input(f"c3_m{k}", (1, 3, 256, 256), 6) for k in range(2)]
+    with torch.no_grad():
+        fwd = _eps_fn("A1", 256)(x, t)
+        img, p0 = SR.ddim_sampling(tb, dd, sub, _eps_fn("A1", 256), xT, sn, x0=x0, mask=mask, mix_noises=mn)
+    return x, t, fwd, xT, x0, mask, sn, mn, img, p0
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_a1_256_forward_and_masked_ddim_vs_oracle(prec):
+    """attention UNet at 256x256 (attention over T = 4096 and 1024 positions, 8 heads of 48 / 64 channels) + the RePaint mix
+    through DDIMSampler.ddim_sampling -- config 3's code path, two steps of its 250"""
+    from eo_diffusion_amd.diffusion.ddim import DDIMSampler
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    x, t, fwd, xT, x0, mask, sn, mn, img_ref, p0_ref = _a1_256_oracle()
+    m = EODiffusion(_unet("A1", 256, prec), timesteps=1000, image_size=256, in_channels=3, cond_type="sum", device=DEV).to(DEV).eval()
+    with torch.no_grad():
+        out = m.model(x.to(DEV), t.to(DEV)).cpu()
+    err = rel_l2(out, fwd)
+    print(f"A1@256 forward [{prec}] rel-L2 = {err:.3e}")
+    assert err < TOL[prec]
+    s = DDIMSampler(m)
+    s.make_schedule(ddim_num_steps=250, ddim_eta=0.0, verbose=False)
+    assert np.array_equal(np.asarray(s.ddim_timesteps[:3], np.int64), np.array([1, 5, 9]))
+    img, inter = s.ddim_sampling(None, (1, 3, 256, 256), x_T=xT, mask=mask, x0=x0, timesteps=3, step_noises=sn, mix_noises=mn,
+                                 progress=False)
+    e_img, e_p0 = rel_l2(img.cpu(), img_ref), rel_l2(inter["pred_x0"][-1].cpu(), p0_ref)
+    print(f"A1@256 2 masked DDIM steps [{prec}] rel-L2 = {e_img:.3e} (pred_x0 {e_p0:.3e})")
+    assert e_img < TRAJ[prec] and e_p0 < TRAJ[prec]
+
+
+# ------------------------------------------------------------------------------------------------ config 5: 13-channel A1 training step
+@functools.lru_cache(maxsize=None)
+def _a1_13ch_oracle():
+    from oracle import unet_ref as UR
+    cfg, sd = _weights("A1", 128, 13)
+    x = synth_input("c5_x", (1, 13, 128, 128), 1)
+    noise = synth_input("c5_n", (1, 13, 128, 128), 2)
+    t = torch.tensor([321])
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred = UR.unet_forward(sdg, cfg, x, t)
+    torch.nn.functional.mse_loss(pred, noise).backward()
+    return x, noise, t, pred.detach(), {k: v.grad for k, v in sdg.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_a1_13ch_training_step_vs_oracle_autograd(prec):
+    """Sentinel-2-like 13-channel attention UNet (in = out = 13, attention at 32x32 / 16x16, 8 heads), 128x128: forward + backward
+    on the HIP path vs torch autograd through the oracle -- the 13 -> 128 first conv's and the 128 -> 13 head conv's backward
+    included"""
+    from eo_diffusion_amd.training import UNetTrainer
+    x, noise, t, pred_ref, gref = _a1_13ch_oracle()
+    m = _unet("A1", 128, prec, 13).to(DEV).train()
+    tr = UNetTrainer(m, 1, 128, 128, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
+    pred = tr.forward(x.to(DEV), t.to(DEV))
+    assert rel_l2(pred.cpu(), pred_ref) < (2e-5 if prec == "fp32" else 1e-2)
+    tr.backward(2.0 * (pred - noise.to(DEV)) / pred.numel())
+    torch.cuda.synchronize()
+    gmax = max(float(v.norm()) for v in gref.values())
+    worst, n_checked = ("", 0.0), 0
+    for name, p in m.named_parameters():
+        if name not in gref or float(gref[name].norm()) < 1e-5 * gmax:
+            continue
+        e = rel_l2(p.grad.cpu(), gref[name])
+        n_checked += 1
+        if e > worst[1]:
+            worst = (name, e)
+    print(f"A1 13ch @128 training step [{prec}]: {n_checked} gradients, worst rel-L2 = {worst}")
+    assert n_checked > 150
+    assert worst[1] < (2e-4 if prec == "fp32" else 4e-2), worst
+    for k in ("input_blocks.0.0.weight", "out.2.weight", "out.2.bias"):
+        assert rel_l2(dict(m.named_parameters())[k].grad.cpu(), gref[k]) < (2e-4 if prec == "fp32" else 4e-2), k
+
+
+# ------------------------------------------------------------------------------------------------ ddpm.py rows (a21, a23-a25)
+def _ldm_with_model_py_tables(unet, T):
+    """DDPM whose coefficient buffers are overwritten (as a checkpoint would, via load_state_dict) with the tables model.py's own
+    fp32 expressions give: p_sample / p_sample_loop must then reproduce what the REFERENCE's model.py produced"""
+    from eo_diffusion_amd.diffusion.ddpm import DDPM
+    from oracle import schedule as SCH
+    from tests.helpers import eo_tables_as_ldm
+    tb = SCH.eo_cosine_tables(T)
+    m = DDPM(unet, timesteps=T, given_betas=tb["betas"].double().numpy(), image_size=16, channels=3)
+    missing = m.load_state_dict(eo_tables_as_ldm(tb), strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("model.") for k in missing.missing_keys)
+    return m.to(DEV).eval()
+
+
+def test_ldm_p_sample_kernel_vs_reference_generated_steps():
+    """a23 / a24 pinned to reference OUTPUTS: eod_ldm_p_sample fed the cosine tables of model.py reproduces the reference-generated
+    `sampler_steps_T1000` (model.py:126-150 run by the reference itself) to fp32 rounding"""
+    from tests.helpers import gt
+
+    class Fixed(torch.nn.Module):
+        def forward(self, x, t, cond=None, y=None):
+            return self.pred
+
+    g = gt("sampler_steps_T1000")
+    m = _ldm_with_model_py_tables(Fixed(), 1000)
+    for tag in ("t999", "t500", "t1", "t0"):
+        m.model.pred = g[tag + "_pred"].to(DEV)
+        out = m.p_sample(g[tag + "_x"].to(DEV), g[tag + "_t"].to(DEV), clip_denoised=True, noise=g[tag + "_noise"].to(DEV)).cpu()
+        assert rel_l2(out, g[tag + "_clip"]) < 1e-6, tag
+
+
+def test_ldm_p_sample_loop_vs_reference_trajectory():
+    """a25 pinned to a reference OUTPUT: DDPM.p_sample_loop (reversed(range(T)), ts = full((b,), i)) on the same UNet, tables
+    and injected noise reproduces the 20-step trajectory the reference's sampling() produced"""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from tests.helpers import gt, unet_cfgs
+    g = gt("traj_ddpm_uncond_clip_T20")
+    cfg = unet_cfgs()["u_a0_tiny"]
+    u = UNetModel(**cfg).set_precision("fp32")
+    u.load_state_dict(synth_state_dict(unet_param_shapes(**cfg), 7))
+    m = _ldm_with_model_py_tables(u, 20)
+    out = m.p_sample_loop((2, 3, 16, 16), x_T=g["x_T"], noises=list(g["noises"])).cpu()
+    assert rel_l2(out, g["out"]) < 2e-5

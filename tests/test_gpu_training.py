@@ -328,7 +328,7 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-@pytest.mark.parametrize("name", ["u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls", "u_mnist"])
+@pytest.mark.parametrize("name", ["u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls", "u_mnist", "u_s2_13ch"])
 def test_training_gradients_vs_reference_golden(prec, name):
     """HIP forward + backward vs gradients computed by the REFERENCE itself (tests/golden/train_grads_*.npz, generated by
     importing /root/reference: per-parameter L2 norm and projection on a fixed synthetic direction, loss, prediction)"""

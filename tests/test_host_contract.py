@@ -147,3 +147,17 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
     ema2.load_state_dict(ck["model_ema"])
     for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("sch,T", [("linear", 1000), ("cosine", 1000), ("linear", 20), ("sqrt_linear", 50)])
+def test_ldm_register_schedule_buffers_vs_fixture(sch, T):
+    """a21 (ddpm.py:122-162): the product's register_schedule buffers equal the harness-derived float64 tables bit for bit (the 11
+    tables + betas; fixture = reference make_beta_schedule + the table formulas evaluated by tests/golden/make_golden.py)"""
+    import torch
+    from eo_diffusion_amd.diffusion.ddpm import DDPM
+    from tests.helpers import bits_equal, gt
+    g = gt(f"ldm_tables_{sch}_T{T}")
+    m = DDPM(torch.nn.Identity(), timesteps=T, beta_schedule=sch)
+    assert m.num_timesteps == T
+    for k, v in g.items():
+        assert bits_equal(getattr(m, k), v), (sch, T, k)

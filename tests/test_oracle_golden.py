@@ -205,6 +205,32 @@ def test_ddim_single_steps_vs_golden(eta):
         assert close_ulp(xp, g[k + "x_prev"]) and close_ulp(p0, g[k + "pred_x0"])
 
 
+@pytest.mark.parametrize("sch,T", [("linear", 1000), ("cosine", 1000), ("linear", 20), ("sqrt_linear", 50)])
+def test_ldm_register_schedule_vs_harness_derived_tables(sch, T):
+    """a21: the 11 register_schedule tables (ddpm.py:122-162).  The fixture is HARNESS-DERIVED (ddpm.py is not importable): betas
+    from the reference's importable util.make_beta_schedule, the table formulas of ddpm.py:129-162 evaluated by
+    tests/golden/make_golden.py in float64.  The oracle restatement reproduces it bit for bit."""
+    g = gt(f"ldm_tables_{sch}_T{T}")
+    lt = SCH.ldm_register_schedule(SCH.ldm_beta_schedule(sch, T))
+    assert len(g) == 12 and set(g) == set(lt)
+    for k, v in g.items():
+        assert bits_equal(lt[k], v), (sch, T, k)
+
+
+def test_ldm_p_sample_reproduces_reference_steps_given_model_py_tables():
+    """a23/a24: ddpm.py's p_sample (predict_start_from_noise, clamp, q_posterior, masked noise) is model.py's clipped step
+    written on coefficient TABLES.  Fed the tables that model.py's own fp32 expressions give (tests/helpers.eo_tables_as_ldm),
+    the restatement reproduces the outputs the REFERENCE produced (sampler_steps_T1000, generated from model.py) to fp32
+    rounding -- this pins the step algebra of the un-importable file to reference outputs."""
+    from tests.helpers import eo_tables_as_ldm
+    g = gt("sampler_steps_T1000")
+    lt = eo_tables_as_ldm(gt("schedule_T1000"))
+    for tag in ("t999", "t500", "t1", "t0"):
+        t, x, pred, noise = g[tag + "_t"], g[tag + "_x"], g[tag + "_pred"], g[tag + "_noise"]
+        out = SR.ldm_p_sample(lt, x, t, pred, noise, clip_denoised=True)
+        assert rel_l2(out, g[tag + "_clip"]) < 1e-6, tag
+
+
 def test_ldm_p_sample_matches_eo_step_given_same_tables():
     # ddpm.py's p_sample is algebraically the clipped EO step (SURVEY.md a13); pinned only through
     # util.make_beta_schedule (ddpm.py itself is not importable: un-vendored ldm.* / lightning).
@@ -262,7 +288,7 @@ def test_train_ref_mse_and_ema_vs_torch():
     assert np.allclose(avg, (0.99 * a + (1 - 0.99) * b).numpy(), rtol=1e-6, atol=1e-8)
 
 
-@pytest.mark.parametrize("name", ["u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls", "u_mnist"])
+@pytest.mark.parametrize("name", ["u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls", "u_mnist", "u_s2_13ch"])
 def test_oracle_training_gradients_vs_reference(name):
     """torch autograd through the oracle UNet + MSE loss (train.py:116-118) vs the gradients of the REFERENCE itself
     (tests/golden/train_grads_*.npz: per-parameter L2 norm and projection on a fixed direction): pins the training oracle"""
