@@ -8,9 +8,11 @@ parameter containers + *emitters* that append descriptors to an `engine.Program`
 in libeodiff.so (implicit-GEMM MFMA convolutions, fused GroupNorm+SiLU, attention GEMMs, ...).
 
 Precision modes (storage dtype of activations / packed weights; accumulation is always fp32):
-  "fp32": exact-fp32 MFMA, parity mode (rel-L2 <= 1e-5 vs the fp32 CPU oracle)
-  "fp16": fp16 storage + v_mfma_f32_32x32x16_f16 (the reference's `use_fp16=True` intent, :568,592)
-Select with UNetModel(..., use_fp16=True), `model.set_precision("fp16")` or EOD_PRECISION=fp16.
+  "fp32":   exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), rel-L2 <= 1e-5 vs the fp32 CPU oracle
+  "fp32x3": fp32 storage; the 3x3 convs compute each product as three fp16 MFMAs on operands split into hi + lo halves
+            (~2^-22 relative per product, same 1e-5 gate as "fp32", ~2.5x faster); everything else as "fp32"
+  "fp16":   fp16 storage + v_mfma_f32_32x32x16_f16 (the reference's `use_fp16=True` intent, :568,592), <= 5e-3
+Select with UNetModel(..., use_fp16=True), `model.set_precision(...)` or EOD_PRECISION=...
 """
 import math
 import os
@@ -584,7 +586,7 @@ class UNetModel(_Emitter):
         return self
 
     def set_precision(self, precision):
-        if precision not in ("fp32", "fp16"):
+        if precision not in ("fp32", "fp16", "fp32x3"):
             raise ValueError(precision)
         self._precision = precision
         self.__dict__.pop("_eod_cache", None)

@@ -69,6 +69,7 @@ struct IgemmP {
     int splitk;    // conv: K-steps are split over gridDim.y workgroups; raw fp32 partial tiles go to `y` (= workspace)
     int force_cfg; // 0 auto, 1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage (EOD_IGEMM_CFG, tuning only)
     float alpha;
+    const float* w_scale;  // split-fp16 mode: device {s, 1/(s*A_SCALE)} of the packed weights (eod_pack_conv_weight_split)
 };
 
 template <typename T> struct Mma;
@@ -84,6 +85,49 @@ template <> struct Mma<float> {
         for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], c, 0, 0, 0);
     }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fp32 THROUGH THE fp16 MATRIX PIPE ("fp32x3" precision mode).  v_mfma_f32_32x32x2_f32 runs at 1/16 of the fp16 MFMA rate, so
+// the exact-fp32 convolution is pinned at 157 TFLOP/s.  Here every fp32 operand is split into two fp16 values,
+//     x = hi + lo,   hi = fp16(x),  lo = fp16(x - hi)          (x - hi is exact in fp32; hi + lo carries ~22 significant bits)
+// and a product is three fp16 MFMAs into ONE fp32 accumulator:  a*b ~ a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  (the dropped lo*lo term is
+// 2^-22 relative).  Measured on gfx950: fp16 SUBNORMAL inputs are honoured by the MFMA and produced by v_cvt_f16_f32
+// (tools/probe/mfma_denorm.hip), so `lo` keeps an absolute resolution of 2^-25 / scale even where it underflows the normal range.
+// Scaling (exact powers of two, undone by alpha in the epilogue):
+//   * weights: per tensor, s = 2^k with max|w|*s in (2^12, 2^13] (pack time, device side) -> lo_w is a normal fp16 for every weight
+//     within 2^-17 of the largest one;
+//   * activations: A_SCALE = 16 -> lo_a is exact to 2^-29 absolute; |x| must stay below 65504/16 = 4094 (GroupNorm'd inputs always
+//     do; beyond that the result is inf/NaN -- loud --, and the exact "fp32" mode remains available).
+// LDS image: operands stay 4 bytes per element.  Each pair of 16-byte chunks (8 consecutive k) is rewritten IN PLACE as
+// [8 x hi | 8 x lo]: weights are packed that way in HBM, activation patches are converted once per staged element by the wave
+// that DMA'd them (lanes l and l^1 hold the two chunks of a pair and swap halves through DPP).  A K-step of 128 bytes = 32 k =
+// 2 MFMA sub-steps; lane half h of sub-step s reads pair 2s+h: hi at chunk 2(2s+h), lo at chunk 2(2s+h)+1 -- the same
+// ds_read_b128 / XOR-swizzle machinery as the other modes, 16 reads and 24 MFMAs per K-step and wave.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define EOD_SPLIT_ASCALE 16.0f
+__device__ __forceinline__ void mma_f16(const i32x4& a, const i32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+// four fp32 values (one 16-byte chunk, already multiplied by the activation scale) -> packed {hi[4]} , {lo[4]} (2 dwords each)
+__device__ __forceinline__ void split4(const f32x4& f, int (&hi)[2], int (&lo)[2]) {
+    half4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (half_t)f[e];
+        l[e] = (half_t)(f[e] - (float)h[e]);
+    }
+    const auto hb = __builtin_bit_cast(__attribute__((ext_vector_type(2))) int, h);
+    const auto lb = __builtin_bit_cast(__attribute__((ext_vector_type(2))) int, l);
+    hi[0] = hb[0]; hi[1] = hb[1]; lo[0] = lb[0]; lo[1] = lb[1];
+}
+// the lane holding the EVEN chunk of a pair keeps [hi_even | hi_odd], the lane holding the ODD chunk keeps [lo_even | lo_odd]
+__device__ __forceinline__ i32x4 split_pair_exchange(const f32x4& f, bool odd_chunk) {
+    int hi[2], lo[2];
+    split4(f, hi, lo);
+    const int s0 = odd_chunk ? hi[0] : lo[0], s1 = odd_chunk ? hi[1] : lo[1];
+    const int r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    return odd_chunk ? i32x4{r0, r1, lo[0], lo[1]} : i32x4{hi[0], hi[1], r0, r1};
+}
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -691,8 +735,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // UPS = true: the conv input is the nearest-2x upsampling of x (Upsample.conv, unet_openai.py:236-241).  The 8x16
 // output tile then reads only a (8/2+2) x (16/2+2) = 6 x 10 patch of the STORED half-resolution tensor: output pixel
 // (u, v) + tap reads patch row ((u+1)>>1, (v+1)>>1) -- the 2x image is never materialised and A traffic drops ~28x.
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel(const IgemmP p) {
+    static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 product is a mode of fp32 storage");
+    constexpr bool XF = GN || SPLIT;  // the staged patch pieces are rewritten in place by the wave that DMA'd them
     constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
     constexpr int BM = 32 * NW, TH = BM / 16, TW = 16;
     constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2, PR = PH * PW;  // 180 (60) patch rows
@@ -788,43 +834,54 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     auto transform_piece = [&](int i, const Chunk& c, char* abuf, const char* ssbuf) {
         const bool ok = ((pvalid >> i) & 1u) && (!c.ktail || (c.kin + pchunk[i] * EPC < c.cw));
         char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
-        const float* sp = reinterpret_cast<const float*>(ssbuf) + pchunk[i] * EPC * 2;
         const i32x4 raw = *reinterpret_cast<const i32x4*>(ptr);
-        i32x4 outv;
-        if constexpr (ES == 2) {
-            const half8 h = __builtin_bit_cast(half8, raw);
-            half8 o;
-            f32x4 q[4];
+        i32x4 outv = raw;
+        if constexpr (GN) {
+            const float* sp = reinterpret_cast<const float*>(ssbuf) + pchunk[i] * EPC * 2;
+            if constexpr (ES == 2) {
+                const half8 h = __builtin_bit_cast(half8, raw);
+                half8 o;
+                f32x4 q[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
+                for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = (float)h[e] * q[e >> 1][(e & 1) * 2] + q[e >> 1][(e & 1) * 2 + 1];
-                if (p.gn_silu) v = silu_f<true>(v);
-                o[e] = (half_t)v;
+                for (int e = 0; e < 8; ++e) {
+                    float v = (float)h[e] * q[e >> 1][(e & 1) * 2] + q[e >> 1][(e & 1) * 2 + 1];
+                    if (p.gn_silu) v = silu_f<true>(v);
+                    o[e] = (half_t)v;
+                }
+                outv = __builtin_bit_cast(i32x4, o);
+            } else {
+                const f32x4 f = __builtin_bit_cast(f32x4, raw);
+                f32x4 o;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const float sc[4] = {q0[0], q0[2], q1[0], q1[2]}, sh[4] = {q0[1], q0[3], q1[1], q1[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = f[e] * sc[e] + sh[e];
+                    if (p.gn_silu) v = silu_f<false>(v);
+                    o[e] = v;
+                }
+                outv = __builtin_bit_cast(i32x4, o);
             }
-            outv = __builtin_bit_cast(i32x4, o);
-        } else {
-            const f32x4 f = __builtin_bit_cast(f32x4, raw);
-            f32x4 o;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
-            const float sc[4] = {q0[0], q0[2], q1[0], q1[2]}, sh[4] = {q0[1], q0[3], q1[1], q1[3]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = f[e] * sc[e] + sh[e];
-                if (p.gn_silu) v = silu_f<false>(v);
-                o[e] = v;
-            }
-            outv = __builtin_bit_cast(i32x4, o);
+            if (!ok) outv = raw;  // conv zero padding / masked channel tail: stays zero
         }
-        if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
+        if constexpr (SPLIT) {
+            // fp32 chunk -> its half of the pair's [8 x hi | 8 x lo] image (zeros stay zeros); both lanes of a pair take part
+            f32x4 f = __builtin_bit_cast(f32x4, outv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+            *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk[i] & 1) != 0);
+        } else {
+            if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
+        }
     };
     auto issue_weights = [&](int tap, const Chunk& c, char* bst) {
         const unsigned soff = (unsigned)(tap * tapstride) + c.bk;
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             unsigned v = b_v[i];
-            if (c.ktail) v = (c.kin + b_chunk[i] * EPC < c.cw) ? v : EOD_OOB;
+            if (c.ktail) v = (c.kin + (SPLIT ? (b_chunk[i] >> 1) * 8 : b_chunk[i] * EPC) < c.cw) ? v : EOD_OOB;
             blds16(rsB, v, soff, bst + (wave + NW * i) * 1024);
         }
     };
@@ -872,10 +929,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
         for (int st = 0; st < BSTAGES - 1; ++st)
             if (st < NSTEP) issue_weights_for_step(st);
-        if constexpr (GN) {
-            // chunk 0: everything has to land before the first tap anyway; normalise the own pieces now
+        if constexpr (XF) {
+            // chunk 0: everything has to land before the first tap anyway; normalise / split the own pieces now
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // wave 0's scale/shift table is visible
+            if constexpr (GN) __builtin_amdgcn_s_barrier();  // wave 0's scale/shift table is visible
 #pragma unroll
             for (int i = 0; i < LAH; ++i)
                 if ((wave + NW * i) < PG) transform_piece(i, c0, sA, sS);
@@ -885,7 +942,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     // DMA issued AFTER the weights of the step we are about to wait for may stay in flight (vmcnt retires in order):
     //   pp1 / pp2 : a patch piece was issued one / two steps ago;  ww1 : weights were issued one step ago (3-stage ring)
     int pp1 = 0, pp2 = 0;
-    bool ww1 = BSTAGES == 3 && NSTEP > 1 && !GN;  // (GN: the prologue already drained everything)
+    bool ww1 = BSTAGES == 3 && NSTEP > 1 && !XF;  // (XF: the prologue already drained everything)
     int step = 0;
     for (int cc = 0; cc < KC; ++cc) {
         const Chunk cur = chunk_of(cc);
@@ -907,7 +964,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                     default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
                 }
             }
-            if constexpr (GN) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): in-place normalisation writes are done
+            if constexpr (XF) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): in-place normalisation / split writes are done
             __builtin_amdgcn_s_barrier();
             // DMA for step + BSTAGES - 1: weights first, then (taps 0..LAH-1) one piece of the next chunk's patch
             pp2 = pp1;
@@ -937,6 +994,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                 arow[i] = prow * BKB;
                 asw[i] = (prow >> 1) & 7;
             }
+            if constexpr (SPLIT) {
+                // 2 sub-steps of 16 k; lane half lh of sub-step s owns chunk pair 2s+lh: [8 x hi] at chunk 2(2s+lh), [8 x lo] right
+                // behind it.  Three fp16 MFMAs per 32x32 tile into the one fp32 accumulator, smallest terms first.
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int ch = 2 * (2 * s + lh);
+                    i32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        ah[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + ((ch ^ asw[i]) << 4));
+                        al[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((ch + 1) ^ asw[i]) << 4));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        bh[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + ((ch ^ bsw) << 4));
+                        bl[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + (((ch + 1) ^ bsw) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mma_f16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mma_f16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mma_f16(ah[i], bh[j], acc[i][j]);
+                }
+            } else {
             // fragments are read ONE sub-step ahead of the MFMAs that consume them (two register sets), and the order
             // {4 ds_read of s+1, 4 MFMA of s} is pinned: left to itself hipcc reads each fragment right before its MFMA
             // and waits lgkmcnt(0) ~6 times per K-step, exposing the LDS latency every time.
@@ -965,7 +1053,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                     for (int j = 0; j < TN; ++j) Mma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
             }
-            if constexpr (GN) {
+            }
+            if constexpr (XF) {
                 // piece (t-2) of the NEXT chunk was issued two steps ago and is covered by this step's vmcnt wait;
                 // the scale/shift table (wave 0, tap 0) became visible with this step's barrier (t >= 2).
                 // (spreading these ~110 VALU ops into the MFMA gaps with sched_group_barrier was measured: 3 % SLOWER)
@@ -976,7 +1065,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
-    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4>(p, g, acc, smem, wave, lane, n0);
+    if constexpr (SPLIT) {
+        IgemmP pe = p;
+        pe.alpha = p.alpha * p.w_scale[1];  // undo the weight and activation scales (exact powers of two)
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true>(pe, g, acc, smem, wave, lane, n0);
+    } else {
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4>(p, g, acc, smem, wave, lane, n0);
+    }
 }
 
 // split-K second pass: y[m][c] = alpha * sum_z ws[z][m][c] + bias[c] + cbias[n(m)][c] + res[m][c]   (fixed z order)
@@ -1064,7 +1159,7 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int NW = WAVES_M * WAVES_N, BM = 32 * NW, TH = BM / 16;
@@ -1073,7 +1168,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128 + (GN ? 2048 : 0);
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1127,6 +1222,19 @@ static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
     return force == 2 ? 4 : 2;
 }
 static int conv_bm(const eod_conv_desc* d, bool halo, int force) { return (!halo && d->Cout > 64 && force == 2) ? 256 : 128; }
+
+// 1 if this conv can run as the split-fp16 product (fp32 storage, weights packed by eod_pack_conv_weight_split): the halo-patch
+// kernel with whole chunk pairs (8 channels) per source
+static bool conv_split_ok(const eod_conv_desc* d, int Ho, int Wo, int force) {
+    return d->dtype == EOD_F32 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && conv_uses_halo(d, Ho, Wo, force);
+}
+extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
+    if (!d) return 0;
+    const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
+    const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    return conv_split_ok(d, Ho, Wo, igemm_forced_cfg()) ? 1 : 0;
+}
 
 // 1 if eod_conv2d_igemm can apply GroupNorm(+SiLU) to the conv INPUT on the fly (gn_scale_shift) for this geometry.
 // The fused form re-normalises the halo patch once per N-tile (Cout / 128 times), so it only pays while the conv has
@@ -1252,6 +1360,21 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.stats = d->stats;
         p.stats_P = slots;
         p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
+    }
+    EOD_REQUIRE(!d->w_split || (halo_ok && conv_split_ok(d, Ho, Wo, p.force_cfg) && d->w_scale),
+                "conv: w_split needs a geometry for which eod_conv_split_ok(d) == 1 and the w_scale of eod_pack_conv_weight_split");
+    if (halo_ok && d->w_split) {
+        // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)
+        p.w_scale = d->w_scale;
+        if (d->gn_scale_shift) {
+            EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
+            p.gn_ss = d->gn_scale_shift;
+            p.gn_silu = d->gn_silu;
+            return d->Cout <= 32 ? launch_halo<float, 32, 4, 1, false, 2, true, true>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true, true>(p, st);
+        }
+        if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false, true>(p, st);
+        if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false, true>(p, st);
+        return launch_halo<float, 128, 2, 2, false, 2, false, true>(p, st);
     }
     if (halo_ok) {
         if (d->Cout <= 32) {  // head conv (out_nchw_f32): HBM-bound, the patch removes the 9x re-gather of the input

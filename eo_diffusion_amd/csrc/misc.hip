@@ -34,6 +34,68 @@ extern "C" int eod_pack_conv_weight(const float* w, void* dst, int dtype, int Co
     return EOD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// split-fp16 weights of the "fp32x3" mode (csrc/igemm.hip): OIHW fp32 -> [tap][Cout][cin_pad] at 4 bytes per element, every group
+// of 8 input channels stored as [8 x hi | 8 x lo] fp16 with hi = fp16(s*w), lo = fp16(s*w - hi); s = 2^k per tensor such that
+// max|w|*s lies in (2^12, 2^13].  scale[0] = s, scale[1] = 1 / (s * 16) (what the conv epilogue multiplies by: weight scale and the
+// activation scale of 16).  Two launches, no host round trip: the scale is read from device memory by the pack kernel and by the conv.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restrict__ w, long long n, float* __restrict__ scale) {
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
+        float s = 1.0f;
+        if (m > 0.0f && m < 3.0e38f) {
+            int e;
+            frexpf(m, &e);           // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(13 - e) in [2^12, 2^13)
+            s = ldexpf(1.0f, 13 - e);
+        }
+        scale[0] = s;
+        scale[1] = 1.0f / (s * 16.0f);
+    }
+}
+
+__global__ void pack_conv_w_split_kernel(const float* __restrict__ w, half_t* __restrict__ dst, const float* __restrict__ scale, int Cout,
+                                         int Cin, int taps, int cin_pad) {
+    const float s = scale[0];
+    const long long groups = (long long)taps * Cout * (cin_pad / 8);
+    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(gi % (cin_pad / 8));
+        const long long r = gi / (cin_pad / 8);
+        const int co = (int)(r % Cout), tap = (int)(r / Cout);
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = cg * 8 + j;
+            const float v = ci < Cin ? w[((long long)co * Cin + ci) * taps + tap] * s : 0.0f;
+            hi[j] = (half_t)v;
+            lo[j] = (half_t)(v - (float)hi[j]);
+        }
+        half8* o = reinterpret_cast<half8*>(dst + gi * 16);
+        o[0] = hi;
+        o[1] = lo;
+    }
+}
+
+extern "C" int eod_pack_conv_weight_split(const float* w, void* dst, float* scale, int Cout, int Cin, int ksize, int cin_pad, void* stream) {
+    EOD_REQUIRE(w && dst && scale && Cout > 0 && Cin > 0 && cin_pad >= Cin && cin_pad % 8 == 0 && (ksize == 1 || ksize == 3),
+                "pack_conv_weight_split: bad args (cin_pad must be a multiple of 8)");
+    EOD_REQUIRE(eod_aligned16(dst), "pack_conv_weight_split: dst must be 16-byte aligned");
+    const int taps = ksize * ksize;
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cout * Cin * taps, scale);
+    const long long groups = (long long)taps * Cout * (cin_pad / 8);
+    const unsigned blocks = (unsigned)((groups + 255) / 256 > 4096 ? 4096 : (groups + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_w_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, scale, Cout, Cin, taps, cin_pad);
+    EOD_CHECK_LAUNCH("pack_conv_weight_split");
+    return EOD_OK;
+}
+
 // OIHW fp32 -> [Cout][ldk], k = tap*cin_pad + c (thin-input first conv, eod_conv_desc.w_tapmajor)
 template <typename T>
 __global__ void pack_conv_w_tapmajor_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int cin_pad, int ldk) {
@@ -232,9 +294,9 @@ __global__ void temb_linear_kernel(const float* __restrict__ in, const long long
             for (int k = lane; k < K; k += 64) {
                 float e = 0.0f;
                 if (k < half)
-                    e = cosf(tf * freqs[k]);
+                    e = cosf(__fmul_rn(tf, freqs[k]));
                 else if (k < 2 * half)
-                    e = sinf(tf * freqs[k - half]);
+                    e = sinf(__fmul_rn(tf, freqs[k - half]));
                 acc += e * wr[k];
             }
         } else {
@@ -284,9 +346,9 @@ __global__ __launch_bounds__(256) void temb_table_linear_kernel(const float* __r
                 if (STAGE == 1) {
                     const float tf = (float)t[n0 + n];
                     if (k < half)
-                        e = cosf(tf * freqs[k]);
+                        e = cosf(__fmul_rn(tf, freqs[k]));
                     else if (k < 2 * half)
-                        e = sinf(tf * freqs[k - half]);
+                        e = sinf(__fmul_rn(tf, freqs[k - half]));
                 } else {
                     e = in[(long long)(n0 + n) * K + k];
                     if (STAGE == 3) e = silu_f<false>(e);
@@ -346,9 +408,9 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, const flo
         const int n = (int)(i / dim), k = (int)(i - (long long)n * dim);
         float e = 0.0f;
         if (k < half)
-            e = cosf(t[n] * freqs[k]);
+            e = cosf(__fmul_rn(t[n], freqs[k]));  // the product is rounded to fp32 BEFORE the range reduction, as torch does
         else if (k < 2 * half)
-            e = sinf(t[n] * freqs[k - half]);
+            e = sinf(__fmul_rn(t[n], freqs[k - half]));
         out[i] = e;
     }
 }

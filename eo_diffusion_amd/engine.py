@@ -17,7 +17,9 @@ from . import _lib
 from ._lib import (OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
                    OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
 
-PRECISIONS = {"fp32": torch.float32, "fp16": torch.float16}
+# precision mode -> storage dtype of activations.  "fp32x3": fp32 storage, the 3x3 halo convs compute every product as three fp16
+# MFMAs on split operands (csrc/igemm.hip, eod_conv_desc.w_split); everything else runs exactly as in "fp32".
+PRECISIONS = {"fp32": torch.float32, "fp16": torch.float16, "fp32x3": torch.float32}
 
 
 def current_stream_ptr(device):
@@ -44,6 +46,33 @@ class Act:
         return self.H * self.W
 
 
+class _LazyConvW:
+    """Conv weight of an fp32x3 program: its packed format (plain fp32 or split fp16 pairs + device scale) is decided by the conv
+    that consumes it (Program.conv asks eod_conv_split_ok for its geometry); each format is packed at most once."""
+
+    def __init__(self, prog, weight, cin_pad):
+        self.prog, self.weight, self.cin_pad = prog, weight, cin_pad
+        self._plain = self._split = None
+
+    def plain(self):
+        if self._plain is None:
+            self._plain = self.prog._pack_conv_plain(self.weight, self.cin_pad)
+        return self._plain
+
+    def split(self):
+        if self._split is None:
+            prog = self.prog
+            w = prog.f32(self.weight)
+            cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+            cin_pad = self.cin_pad or cin
+            dst = prog.empty((k * k, cout, cin_pad), torch.float32)  # 4 bytes per element: [8 x fp16 hi | 8 x fp16 lo] per 8 channels
+            scale = prog.empty((2,), torch.float32)
+            check(prog.L.eod_pack_conv_weight_split(ptr(w), ptr(dst), ptr(scale), cout, cin, k, cin_pad,
+                                                    current_stream_ptr(prog.device)), "pack_conv_weight_split")
+            self._split = (dst, scale)
+        return self._split
+
+
 class Program:
     def __init__(self, device, precision):
         if precision not in PRECISIONS:
@@ -51,6 +80,7 @@ class Program:
         self.device = torch.device(device)
         self.precision = precision
         self.tdtype = PRECISIONS[precision]
+        self.split = precision == "fp32x3"
         self.dt = _lib.dtype_id(self.tdtype)
         self.epc = 16 // self.tdtype.itemsize  # elements per 16-byte chunk
         self.ops = []
@@ -85,7 +115,13 @@ class Program:
 
     # ------------------------------------------------------------------ weight packing (one-off, at build time)
     def pack_conv(self, weight, cin_pad=None):
-        """Conv2d/Conv1d weight (OIHW / OIK fp32) -> [tap][Cout][cin_pad] in the storage dtype."""
+        """Conv2d/Conv1d weight (OIHW / OIK fp32) -> [tap][Cout][cin_pad] in the storage dtype (fp32x3 programs: a handle whose
+        format the consuming conv chooses)."""
+        if self.split and weight.dim() == 4:
+            return _LazyConvW(self, weight, cin_pad)
+        return self._pack_conv_plain(weight, cin_pad)
+
+    def _pack_conv_plain(self, weight, cin_pad=None):
         w = self.f32(weight)
         cout, cin = w.shape[0], w.shape[1]
         k = w.shape[2] if w.dim() >= 3 else 1
@@ -150,7 +186,7 @@ class Program:
         wo = (weff + 2 * pad - ksize) // stride + 1
         op, idx = self._push(OP_CONV)
         d = op.u.conv
-        d.x, d.x2, d.w = ptr(x.t), ptr(x2.t) if x2 is not None else 0, ptr(w_packed)
+        d.x, d.x2 = ptr(x.t), ptr(x2.t) if x2 is not None else 0
         d.bias, d.cbias, d.cbias_stride = ptr(bias), ptr(cbias), cbias_stride
         d.res = ptr(res.t) if res is not None else 0
         d.dtype, d.N, d.H, d.W = self.dt, x.N, x.H, x.W
@@ -158,6 +194,14 @@ class Program:
         d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
         d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
         d.w_tapmajor = int(w_tapmajor)
+        if isinstance(w_packed, _LazyConvW):  # fp32x3: split-fp16 product where the library has it for this geometry
+            if self.L.eod_conv_split_ok(C.byref(d)):
+                wt, wscale = w_packed.split()
+                d.w, d.w_split, d.w_scale = ptr(wt), 1, ptr(wscale)
+            else:
+                d.w = ptr(w_packed.plain())
+        else:
+            d.w = ptr(w_packed)
         if gn is not None:
             d.gn_scale_shift, d.gn_silu = ptr(gn[0]), int(gn[1])
         wsz = self.L.eod_conv_workspace_size(C.byref(d))

@@ -91,8 +91,10 @@ class UNetTrainer:
         self.N, self.H, self.W = N, H, W
         self.loss_scale = float(loss_scale)
         self.inv_scale = 1.0 / self.loss_scale
-        self.prog = Program(self.device, unet.precision)   # forward ops (native executor)
-        self.bprog = Program(self.device, unet.precision)  # backward ops that reuse executor op kinds
+        # (the split-fp16 inference mode "fp32x3" trains as exact "fp32": the backward kernels keep plain fp32 operands)
+        prec = "fp32" if unet.precision == "fp32x3" else unet.precision
+        self.prog = Program(self.device, prec)   # forward ops (native executor)
+        self.bprog = Program(self.device, prec)  # backward ops that reuse executor op kinds
         self.L = self.prog.L
         self.dt = self.prog.dt
         self.es = self.prog.tdtype.itemsize

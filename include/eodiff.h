@@ -81,13 +81,17 @@ typedef struct {
                             w is [Cout][ldk] with k = tap*C0 + c (eod_pack_conv_weight_tapmajor, ldk =
                             eod_conv_tapmajor_ldk) and the K loop runs over the flattened [tap][C0] axis -- ceil(9*C0/BK)
                             K-steps instead of 9 mostly-zero ones.  Needs C1 == 0, no upsample, C0 in {1,2,4} 16-byte chunks */
-    int32_t reserved0;
+    int32_t w_split;     /* 1: "fp32x3" product -- fp32 storage, every product as three fp16 MFMAs on split operands (hi + lo):
+                            w is the output of eod_pack_conv_weight_split, w_scale its scale pair.  Only where
+                            eod_conv_split_ok(d) == 1 (halo-patch 3x3 convs with C0, C1 multiples of 8); rel. error ~2^-22 per product */
+    const float* w_scale; /* device pointer to {s, 1/(16 s)} written by eod_pack_conv_weight_split (w_split only) */
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
  * images, NCHW output): the caller sizes `stats` with it. */
 int eod_conv_stats_slots(const eod_conv_desc* d);
 int eod_conv_gn_fusable(const eod_conv_desc* d);
+int eod_conv_split_ok(const eod_conv_desc* d);
 int64_t eod_conv_workspace_size(const eod_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
@@ -118,6 +122,10 @@ int eod_gemm_nt(const eod_gemm_desc* d, void* stream);
 /* weights: OIHW fp32 (Conv2d.weight, unet_openai.py:21-25) -> [tap][Cout][cin_pad] storage dtype */
 int eod_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int ksize,
                          int cin_pad, void* stream);
+/* split-fp16 weights of the fp32x3 product (eod_conv_desc.w_split): [tap][Cout][cin_pad] at 4 bytes per element, every 8 input
+ * channels as [8 x fp16 hi | 8 x fp16 lo] of s*w, s = 2^k per tensor chosen on the device; scale (device, 2 floats) receives
+ * {s, 1/(16 s)}.  cin_pad % 8 == 0.  No host synchronisation. */
+int eod_pack_conv_weight_split(const float* w_oihw, void* dst, float* scale, int Cout, int Cin, int ksize, int cin_pad, void* stream);
 /* thin-input variant: OIHW fp32 -> [Cout][ldk], k = tap*cin_pad + c, zero padded (see eod_conv_desc.w_tapmajor) */
 int eod_pack_conv_weight_tapmajor(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int cin_pad, void* stream);
 int eod_conv_tapmajor_ldk(int C0, int dtype);

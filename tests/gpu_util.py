@@ -6,7 +6,8 @@ from eo_diffusion_amd.engine import Program, round_up
 
 DEV = "cuda:0"
 # stated tolerances (rel-L2 vs the fp32 CPU oracle): SURVEY.md section 8c noise-floor measurements
-TOL = {"fp32": 1e-5, "fp16": 5e-3}
+# ("fp32x3": fp32 storage, 3x3 convs through three fp16 MFMAs on split operands -- held to the SAME gate as exact fp32)
+TOL = {"fp32": 1e-5, "fp16": 5e-3, "fp32x3": 1e-5}
 
 
 def run_program(prec, x_nchw, emit):

@@ -24,8 +24,8 @@ pytestmark = pytest.mark.gpu
 
 A0 = dict(model_channels=128, channel_mult=[1, 2, 3, 4], attention_resolutions=[], num_res_blocks=1, num_heads=1)
 A1 = dict(model_channels=128, channel_mult=[1, 2, 3, 4], attention_resolutions=[4, 8], num_res_blocks=2, num_heads=8)
-PRECS = ["fp32", "fp16"]
-TRAJ = {"fp32": 2e-5, "fp16": 1e-2}
+PRECS = ["fp32", "fp16", "fp32x3"]
+TRAJ = {"fp32": 2e-5, "fp16": 1e-2, "fp32x3": 2e-5}
 
 
 def _cfg(arch, size, ch=3):
@@ -179,7 +179,7 @@ def _a1_13ch_oracle():
     return x, noise, t, pred.detach(), {k: v.grad for k, v in sdg.items() if v.grad is not None}
 
 
-@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
 def test_a1_13ch_training_step_vs_oracle_autograd(prec):
     """Sentinel-2-like 13-channel attention UNet (in = out = 13, attention at 32x32 / 16x16, 8 heads), 128x128: forward + backward
     on the HIP path vs torch autograd through the oracle -- the 13 -> 128 first conv's and the 128 -> 13 head conv's backward

@@ -35,7 +35,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_vs_torch(prec, case):
     N, Cin, H, W, Cout, k, stride, pad, ups = case
@@ -59,7 +59,7 @@ def test_conv_vs_torch(prec, case):
     assert rel_l2(got, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("dims", [(2, 64, 32, 8, 8, 64), (2, 64, 32, 16, 16, 128), (1, 128, 96, 32, 16, 256)])
 def test_conv_fused_epilogue_concat_residual_temb(prec, dims):
     """two A sources (virtual concat), per-sample bias (timestep embedding) and residual in one launch
@@ -172,7 +172,7 @@ def test_bad_arguments_fail_loudly():
         prog.run()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("dims", [(2, 64, 32, 16, 16, 128), (1, 128, 0, 32, 16, 256), (2, 96, 0, 8, 16, 192), (2, 32, 0, 8, 8, 32)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_conv_with_fused_input_groupnorm(prec, dims, silu):
@@ -202,6 +202,36 @@ def test_conv_with_fused_input_groupnorm(prec, dims, silu):
     assert rel_l2(got, ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-2, 1e2, 1e-4])
+@pytest.mark.parametrize("wmag", [1.0, 1e-3, 30.0])
+def test_fp32x3_product_is_fp32_grade_at_any_magnitude(mag, wmag):
+    """the split-fp16 product (three fp16 MFMAs per product, per-tensor power-of-two weight scale, activation scale 16, fp16
+    subnormals for the low halves) against a float64 convolution: as accurate as the exact-fp32 MFMA path for activations from
+    1e-2 to 1e2 and weights from 1e-3 to 30 -- not just inside the 1e-5 gate.  The low half of an activation has an ABSOLUTE
+    resolution of 2^-29 (fp16 subnormal quantum / activation scale 16), so a conv input whose values are all ~1e-4 (never the case
+    behind a GroupNorm) degrades gracefully to ~1e-5 relative: that floor is pinned here too."""
+    N, Cin, H, W, Cout = 1, 256, 32, 32, 128
+    x = synth_input("x3x", (N, Cin, H, W), 51, scale=mag)
+    w = synth_input("x3w", (Cout, Cin, 3, 3), 51, scale=wmag / math.sqrt(Cin * 9))
+    b = synth_input("x3b", (Cout,), 51, scale=0.1 * mag * wmag)
+
+    def emit(prog, a):
+        y, idx = prog.conv(a, prog.pack_conv(w.to(DEV)), prog.f32(b.to(DEV)), Cout)
+        emit.split = prog.ops[idx].u.conv.w_split
+        return y
+
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    err = {}
+    for prec in ("fp32", "fp32x3"):
+        err[prec] = rel_l2(run_program(prec, x, emit), ref)
+        assert emit.split == (1 if prec == "fp32x3" else 0)  # the split kernel really ran
+    print(f"activations ~{mag:g}, weights ~{wmag:g}: exact fp32 {err['fp32']:.2e}, fp32x3 {err['fp32x3']:.2e}")
+    if mag >= 1e-2:
+        assert err["fp32x3"] < 1e-6 and err["fp32x3"] < 4 * err["fp32"] + 2e-7
+    else:
+        assert err["fp32x3"] < 2.0 ** -29 / (0.5 * mag)  # the documented absolute floor
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 @pytest.mark.parametrize("dims", [(2, 3, 16, 16, 128), (1, 7, 32, 16, 128), (2, 13, 8, 24, 64), (1, 4, 7, 9, 32), (1, 3, 64, 64, 128)])
 def test_first_conv_tapmajor(prec, dims):
@@ -223,7 +253,7 @@ def test_first_conv_tapmajor(prec, dims):
     assert rel_l2(got, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("dims", [(2, 128, 16, 16, 3), (1, 64, 8, 32, 13), (2, 96, 16, 16, 3)])
 @pytest.mark.parametrize("fused_gn", [True, False])
 def test_head_conv_nchw_f32(prec, dims, fused_gn):

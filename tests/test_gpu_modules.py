@@ -11,7 +11,7 @@ from tests.test_oracle_golden import ATT, RES, attn_shapes, res_shapes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("name", list(RES))
 def test_resblock_vs_golden(prec, name, monkeypatch):
     from eo_diffusion_amd.backbones.unet_openai import ResBlock
@@ -61,7 +61,7 @@ def test_resample_vs_golden(prec, monkeypatch):
         assert rel_l2(y, g["y"]) < TOL[prec], name
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("name", list(unet_cfgs()))
 def test_unet_vs_golden(prec, name):
     from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
@@ -125,7 +125,7 @@ def test_flash_attention_longer_sequences(C, heads, hw, monkeypatch):
         assert rel_l2(y, ref) < TOL["fp16"]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("factory,size", [("UNetSmall", 32), ("UNet", 28)])
 def test_factory_presets_vs_oracle(prec, factory, size):
     """UNetBig/UNet/UNetSmall presets (unet_openai.py:783-922): FiLM, resblock_updown, new attention order,
