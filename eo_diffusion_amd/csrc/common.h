@@ -46,6 +46,16 @@ template <> struct dt<half_t> {
     static constexpr int epc = 8;
 };
 
+// a * b rounded to fp32 as its own operation.  hipcc contracts a multi-use fmul into EVERY consuming add (aggressive FMA fusion), and
+// HIP's __fmul_rn is a plain `*`: where a product has to exist as a rounded fp32 value before it is used (the sinusoid argument
+// t*f in front of sin/cos range reduction: an unrounded product moves a 999 rad argument by up to half an ulp = 3e-5 in the
+// result), it is pinned in a register behind an opaque asm.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 // SiLU (nn.SiLU, unet_openai.py:314,330,338): precise form for the fp32 parity mode, fast form
 // (v_exp_f32 + v_rcp_f32) for the fp16 mode where the result is rounded to 11 bits anyway.
 template <bool FAST> __device__ __forceinline__ float silu_f(float v) {

@@ -426,8 +426,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     }
 }
 
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmP p) {
+    static_assert(!SPLIT || (sizeof(T) == 4 && CONV && STAGES == 2), "split-fp16 product: fp32 conv, 2-stage ring");
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
     constexpr int BKB = 128;       // bytes of K per row per K-step
@@ -457,6 +458,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     IgemmP pe = p;  // epilogue view of the parameters
     if constexpr (CONV) {
         if (p.splitk > 1) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;
+    }
+    if constexpr (SPLIT) {
+        if (p.splitk <= 1) pe.alpha = p.alpha * p.w_scale[1];  // (split-K: raw partial tiles, the reduce pass rescales)
     }
     const long long offA = g.offA, offB = g.offB;
 
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     };
     auto issue_b = [&](int i, char* sbase) {
         unsigned v = b_v[i];
-        if (ss.ktail) v = (ss.kin + b_chunk[i] * EPC < ss.cw) ? v : EOD_OOB;
+        if (ss.ktail) v = (ss.kin + (SPLIT ? (b_chunk[i] >> 1) * 8 : b_chunk[i] * EPC) < ss.cw) ? v : EOD_OOB;
         blds16(rsB, v, ss.soffB, sbase + STAGE_A + (wave + NW * i) * 1024);
     };
     auto issue_loads = [&](int stage) {  // all DMA instructions of one K-step
@@ -673,10 +677,55 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if constexpr (SPLIT) {
+            // this wave's A pieces of step kt have landed: rewrite each fp32 chunk pair in place as [8 x hi | 8 x lo] (x 16), see
+            // the fp32x3 note at the top; masked lanes were zero-filled by the DMA and stay zero.  Weights arrive pre-split.
+            char* sa = smem + (kt % STAGES) * STAGE;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                char* ptr = sa + (wave + NW * i) * 1024 + lane * 16;
+                f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+                *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (a_chunk[i] & 1) != 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the rewritten pieces are in LDS before the barrier publishes them
+        }
         __builtin_amdgcn_s_barrier();
         // (issuing the DMA instructions one by one between the MFMA sub-steps was measured: no gain, -5..10 %)
         if (kt + STAGES - 1 < KT) issue_loads((kt + STAGES - 1) % STAGES);
         const char* sb = smem + (kt % STAGES) * STAGE;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ch = 2 * (2 * s + lh);
+                const int ohi = (ch ^ sw) * 16, olo = ((ch + 1) ^ sw) * 16;
+                i32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + ohi);
+                    al[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + olo);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + ohi);
+                    bl[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + olo);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_f16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_f16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_f16(ah[i], bh[j], acc[i][j]);
+            }
+            continue;
+        }
         // fragments are read one sub-step ahead of their MFMAs and the {ds_read group, MFMA group} order is pinned
         // (see conv3x3_halo_kernel): +5 % over hipcc's own read-then-wait schedule
         i32x4 fa[2][TM], fb[2][TN];
@@ -1078,7 +1127,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 template <typename T>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long M, int Cout, int HoWo, float alpha,
                                      const float* __restrict__ bias, const float* __restrict__ cbias, long long cbias_stride,
-                                     const T* __restrict__ res, T* __restrict__ y) {
+                                     const T* __restrict__ res, T* __restrict__ y, const float* __restrict__ w_scale) {
+    if (w_scale) alpha *= w_scale[1];  // split-fp16 product: undo the operand scales
     const long long total4 = M * Cout / 4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long e = i * 4, m = e / Cout;
@@ -1108,14 +1158,14 @@ static int igemm_forced_cfg() {
     return v;
 }
 
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false>
 static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, NW = WAVES_M * WAVES_N;
     const size_t ring = STAGES * (size_t)(BM + BN) * 128;
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES>;
+    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES, SPLIT>;
     static bool attr_done = false;  // >64 KiB dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1202,6 +1252,13 @@ template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipSt
     return launch_cfg<T, CONV, 128, 128, 2, 2, 2>(p, batch, st);
 }
 
+// fp32 conv as the split-fp16 product on the generic kernel (1x1, stride 2, ragged maps)
+static int launch_conv_split(IgemmP& p, int batch, hipStream_t st) {
+    if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true>(p, batch, st);
+    if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true>(p, batch, st);
+    return launch_cfg<float, true, 128, 128, 2, 2, 2, true>(p, batch, st);
+}
+
 // row length (elements) of tap-major packed weights: 9*C0 rounded up to whole 128-byte K-steps
 extern "C" int eod_conv_tapmajor_ldk(int C0, int dtype) {
     const int bk = 128 / (dtype == EOD_F16 ? 2 : 4);
@@ -1223,10 +1280,10 @@ static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
 }
 static int conv_bm(const eod_conv_desc* d, bool halo, int force) { return (!halo && d->Cout > 64 && force == 2) ? 256 : 128; }
 
-// 1 if this conv can run as the split-fp16 product (fp32 storage, weights packed by eod_pack_conv_weight_split): the halo-patch
-// kernel with whole chunk pairs (8 channels) per source
+// 1 if this conv can run as the split-fp16 product (fp32 storage, weights packed by eod_pack_conv_weight_split): whole chunk
+// pairs (8 channels) per source; every kernel variant has it except the thin-input (tap-major) first conv
 static bool conv_split_ok(const eod_conv_desc* d, int Ho, int Wo, int force) {
-    return d->dtype == EOD_F32 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && conv_uses_halo(d, Ho, Wo, force);
+    return d->dtype == EOD_F32 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && !d->w_tapmajor && d->upsample != 2 && force != 7;
 }
 extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
     if (!d) return 0;
@@ -1361,8 +1418,9 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.stats_P = slots;
         p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
     }
-    EOD_REQUIRE(!d->w_split || (halo_ok && conv_split_ok(d, Ho, Wo, p.force_cfg) && d->w_scale),
+    EOD_REQUIRE(!d->w_split || (conv_split_ok(d, Ho, Wo, p.force_cfg) && d->w_scale),
                 "conv: w_split needs a geometry for which eod_conv_split_ok(d) == 1 and the w_scale of eod_pack_conv_weight_split");
+    p.w_scale = d->w_split ? d->w_scale : nullptr;
     if (halo_ok && d->w_split) {
         // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)
         p.w_scale = d->w_scale;
@@ -1408,17 +1466,19 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         q.splitk = splitk;
         q.y = (char*)d->workspace;
         q.bias = nullptr; q.bias_mode = 0; q.cbias = nullptr; q.res = nullptr; q.alpha = 1.0f;
-        const int rc = d->dtype == EOD_F16 ? launch_T<half_t, true>(q, splitk, st) : launch_T<float, true>(q, splitk, st);
+        const int rc = d->w_split ? launch_conv_split(q, splitk, st)
+                                  : d->dtype == EOD_F16 ? launch_T<half_t, true>(q, splitk, st) : launch_T<float, true>(q, splitk, st);
         if (rc != EOD_OK) return rc;
         const long long total4 = p.M * p.Cout / 4;
         const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
         if (d->dtype == EOD_F16)
-            hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y);
+            hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y, (const float*)nullptr);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y);
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, d->w_split ? d->w_scale : (const float*)nullptr);
         EOD_CHECK_LAUNCH("splitk_reduce");
         return EOD_OK;
     }
+    if (d->w_split) return launch_conv_split(p, 1, st);
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }
 

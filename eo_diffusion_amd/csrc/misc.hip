@@ -294,9 +294,9 @@ __global__ void temb_linear_kernel(const float* __restrict__ in, const long long
             for (int k = lane; k < K; k += 64) {
                 float e = 0.0f;
                 if (k < half)
-                    e = cosf(__fmul_rn(tf, freqs[k]));
+                    e = cosf(mul_rn(tf, freqs[k]));
                 else if (k < 2 * half)
-                    e = sinf(__fmul_rn(tf, freqs[k - half]));
+                    e = sinf(mul_rn(tf, freqs[k - half]));
                 acc += e * wr[k];
             }
         } else {
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(256) void temb_table_linear_kernel(const float* __r
                 if (STAGE == 1) {
                     const float tf = (float)t[n0 + n];
                     if (k < half)
-                        e = cosf(__fmul_rn(tf, freqs[k]));
+                        e = cosf(mul_rn(tf, freqs[k]));
                     else if (k < 2 * half)
-                        e = sinf(__fmul_rn(tf, freqs[k - half]));
+                        e = sinf(mul_rn(tf, freqs[k - half]));
                 } else {
                     e = in[(long long)(n0 + n) * K + k];
                     if (STAGE == 3) e = silu_f<false>(e);
@@ -408,9 +408,9 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, const flo
         const int n = (int)(i / dim), k = (int)(i - (long long)n * dim);
         float e = 0.0f;
         if (k < half)
-            e = cosf(__fmul_rn(t[n], freqs[k]));  // the product is rounded to fp32 BEFORE the range reduction, as torch does
+            e = cosf(mul_rn(t[n], freqs[k]));  // (rounded product: see mul_rn)
         else if (k < 2 * half)
-            e = sinf(__fmul_rn(t[n], freqs[k - half]));
+            e = sinf(mul_rn(t[n], freqs[k - half]));
         out[i] = e;
     }
 }

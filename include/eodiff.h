@@ -83,7 +83,7 @@ typedef struct {
                             K-steps instead of 9 mostly-zero ones.  Needs C1 == 0, no upsample, C0 in {1,2,4} 16-byte chunks */
     int32_t w_split;     /* 1: "fp32x3" product -- fp32 storage, every product as three fp16 MFMAs on split operands (hi + lo):
                             w is the output of eod_pack_conv_weight_split, w_scale its scale pair.  Only where
-                            eod_conv_split_ok(d) == 1 (halo-patch 3x3 convs with C0, C1 multiples of 8); rel. error ~2^-22 per product */
+                            eod_conv_split_ok(d) == 1 (fp32, C0 and C1 multiples of 8, not w_tapmajor); rel. error ~2^-22 per product */
     const float* w_scale; /* device pointer to {s, 1/(16 s)} written by eod_pack_conv_weight_split (w_split only) */
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
