@@ -418,12 +418,21 @@ class AttentionBlock(_Emitter):
         assert x.C == Cc
         N, T = x.N, x.HW
         d_nat = Cc // nh
-        if (prog.precision == "fp16" and d_nat % 8 == 0 and d_nat <= 64 and os.environ.get("EOD_ATTN", "nat") == "nat"):
+        if (prog.precision in ("fp16", "fp32x3") and d_nat % 8 == 0 and d_nat <= 64 and os.environ.get("EOD_ATTN", "nat") == "nat"):
             # fused attention straight on the qkv projection's natural channel layout (legacy [h][q|k|v][d], new [q|k|v][h][d]):
-            # one projection GEMM, no packed q|k / transposed v operands (eod_attention_fwd_nat)
+            # one projection GEMM, no packed q|k / transposed v operands, T x T never materialised (eod_attention_fwd_nat;
+            # fp32x3: fp32 in / out with split-fp16 products, the projections run as 1x1 convs of the same product type)
             qo, ko, vo, hs = (0, Cc, 2 * Cc, d_nat) if self.attention.new_order else (0, d_nat, 2 * d_nat, 3 * d_nat)
-            wqkv = prog.pack_rows(self.qkv.weight.view(3 * Cc, Cc))
             xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps)
+            if prog.split:
+                qkv, _ = prog.conv(xn, prog.pack_conv(self.qkv.weight.view(3 * Cc, Cc, 1, 1)), prog.f32(self.qkv.bias), 3 * Cc,
+                                   ksize=1, stride=1, pad=0)
+                a = prog.act(N, x.H, x.W, Cc)
+                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs)
+                out, _ = prog.conv(a, prog.pack_conv(self.proj_out.weight.view(Cc, Cc, 1, 1)), prog.f32(self.proj_out.bias), Cc,
+                                   ksize=1, stride=1, pad=0, res=x, stats=True)
+                return out
+            wqkv = prog.pack_rows(self.qkv.weight.view(3 * Cc, Cc))
             qkv = prog.empty((N * T, 3 * Cc))
             prog.gemm(xn.t, wqkv, qkv, N * T, 3 * Cc, Cc, Cc, Cc, 3 * Cc, bias=prog.f32(self.qkv.bias), bias_mode=1)
             a = prog.empty((N * T, Cc))

@@ -336,8 +336,11 @@ int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, int64_t n1, 
 /* softmax backward on rows (QKVAttention, unet_openai.py:479): dS[r][j] = P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]),
  * P / dS storage dtype with row stride ldp, dP fp32 with row stride lds; columns n..ldp-1 of dS are written as zeros */
 /* fused attention forward on the NATURAL qkv layout [N][T][3C] (channel = q_off / k_off / v_off + head*head_stride + j; legacy
- * order: 0, d, 2d, 3d; new order: 0, C, 2C, d), fp16, head dim a multiple of 8 and <= 64, any T; out [N][T][C]; lse optional
- * [N][heads][T].  K / V tiles staged row-major by LDS-DMA, V^T through transposed LDS reads (csrc/attn_bwd.hip) */
+ * order: 0, d, 2d, 3d; new order: 0, C, 2C, d), head dim a multiple of 8 and <= 64, any T; out [N][T][C]; lse optional
+ * [N][heads][T].  The T x T weights of unet_openai.py:476-480 / 508-514 never exist in HBM.
+ *   EOD_F16: K / V tiles staged row-major by LDS-DMA, V^T through transposed LDS reads (csrc/attn_bwd.hip)
+ *   EOD_F32: fp32 in / out, fp32 online softmax, both contractions as three fp16 MFMAs per product on operands split into
+ *            hi + lo halves (fp32-grade, ~2^-22 per product; csrc/attn_x3.hip) */
 int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off, int k_off,
                           int v_off, int head_stride, void* stream);
 /* flash-style attention backward (fp16, head dim a multiple of 8 and <= 64, any T): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /

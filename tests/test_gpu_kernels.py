@@ -384,6 +384,36 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
     assert float((lse.cpu() - torch.logsumexp(S, -1)).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
+                                                 (64, 4, 8, False), (4096, 2, 64, False)])
+@pytest.mark.parametrize("mag", [0.8, 4.0])
+def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag):
+    """the fp32-storage instance of eod_attention_fwd_nat (fp32 online softmax, both contractions as three fp16 MFMAs per product
+    on split operands; the T x T weights never exist) vs a float64 softmax(q k^T / sqrt(d)) v: fp32-grade, also for peaked
+    softmax rows (mag 4: logits of +-50)"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    N, C = 2, heads * d
+    qkv = synth_input(f"fn32{T}{d}", (N, T, 3 * C), 9, scale=mag)
+    qo, ko, vo, hs = (0, C, 2 * C, d) if new_order else (0, d, 2 * d, 3 * d)
+    pick = lambda off: torch.stack([qkv.double()[:, :, off + h * hs: off + h * hs + d] for h in range(heads)], 1)
+    q, k, v = pick(qo), pick(ko), pick(vo)
+    S = q @ k.transpose(-1, -2) / math.sqrt(d)
+    ref = (torch.softmax(S, -1) @ v).permute(0, 2, 1, 3).reshape(N, T, C)
+    qd = qkv.to(DEV)
+    out = torch.full((N, T, C), 9.0, dtype=torch.float32, device=DEV)
+    lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F32, N, T, C, heads, d, qo, ko, vo, hs,
+                                       current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
+    torch.cuda.synchronize()
+    err = rel_l2(out.cpu(), ref)
+    f32 = rel_l2((torch.softmax(S.float(), -1) @ v.float()).permute(0, 2, 1, 3).reshape(N, T, C), ref)  # what plain fp32 torch gives
+    print(f"T={T} d={d} mag={mag}: fused fp32x3 attention {err:.2e}, torch fp32 {f32:.2e}")
+    assert err < 2e-6
+    assert float((lse.cpu().double() - torch.logsumexp(S, -1)).abs().max()) < 2e-5 * max(1.0, float(S.abs().max()))
+
+
 @pytest.mark.parametrize("N,H,W,Cx,Cout,ups", [(2, 16, 64, 40, 24, False), (1, 32, 32, 136, 128, False), (3, 16, 16, 8, 200, False),
                                                (1, 8, 128, 64, 64, False), (2, 16, 32, 24, 40, True), (1, 8, 8, 16, 16, True)])
 def test_conv3x3_backward_weights_kernel(N, H, W, Cx, Cout, ups):

@@ -27,7 +27,7 @@ def test_resblock_vs_golden(prec, name, monkeypatch):
     assert rel_l2(y, g["y"]) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("name", list(ATT))
 def test_attention_vs_golden(prec, name, monkeypatch):
     from eo_diffusion_amd.backbones.unet_openai import AttentionBlock
