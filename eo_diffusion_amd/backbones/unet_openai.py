@@ -353,6 +353,35 @@ class ResBlock(TimestepBlock):
         return self._standalone(x, emit)
 
 
+def _qkv_attention_standalone(mod, qkv):
+    """QKVAttention(Legacy).forward(qkv) (unet_openai.py:465-481 / 497-515) as its own call: qkv [N, 3*H*d, T] -> [N, H*d, T].
+    One layout pass to the kernels' [N][T][3C] form, the fused attention kernel (eod_attention_fwd_nat; the T x T weights never exist),
+    one pass back.  fp16 mode: fp16 storage; fp32 / fp32x3: fp32 in and out with split-fp16 products and fp32 softmax."""
+    require_gpu(qkv, type(mod).__name__)
+    bs, width, length = qkv.shape
+    nh = mod.n_heads
+    assert width % (3 * nh) == 0
+    d = width // (3 * nh)
+    Cc = nh * d
+    if d % 8 or d > 64:
+        raise _lib.EodError(f"{type(mod).__name__} standalone: head dim {d} must be a multiple of 8 and <= 64 (inside AttentionBlock the "
+                            "other head sizes run through the GEMM path)")
+    prec = default_precision()
+    prog = Program(qkv.device, "fp16" if prec == "fp16" else "fp32x3")
+    a0, i_in = prog.to_nhwc(bs, width, 0, 1, length, width)
+    xin = qkv.detach().contiguous().float()
+    prog.ops[i_in].u.small.p[0] = xin.data_ptr()
+    qo, ko, vo, hs = (0, Cc, 2 * Cc, d) if mod.new_order else (0, d, 2 * d, 3 * d)
+    a = prog.act(bs, 1, length, Cc)
+    prog.attention_nat(a0.t, a.t, bs, length, Cc, nh, d, qo, ko, vo, hs)
+    out = th.empty((bs, Cc, 1, length), dtype=th.float32, device=qkv.device)
+    i_out = prog.to_nchw(a)
+    prog.ops[i_out].u.small.p[1] = out.data_ptr()
+    prog.run()
+    th.cuda.current_stream(qkv.device).synchronize()  # program-owned buffers die with `prog`
+    return out.view(bs, Cc, length).type(qkv.dtype)
+
+
 class QKVAttentionLegacy(nn.Module):
     """Head-interleaved qkv layout [h][q|k|v][d] (unet_openai.py:456-481)."""
     new_order = False
@@ -361,7 +390,8 @@ class QKVAttentionLegacy(nn.Module):
         super().__init__()
         self.n_heads = n_heads
 
-    forward = _not_on_path
+    def forward(self, qkv):
+        return _qkv_attention_standalone(self, qkv)
 
 
 class QKVAttention(nn.Module):
@@ -372,7 +402,8 @@ class QKVAttention(nn.Module):
         super().__init__()
         self.n_heads = n_heads
 
-    forward = _not_on_path
+    def forward(self, qkv):
+        return _qkv_attention_standalone(self, qkv)
 
 
 class AttentionBlock(_Emitter):

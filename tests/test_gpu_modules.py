@@ -188,3 +188,23 @@ def test_timestep_embedding_standalone_vs_golden():
         assert bool(((e - ref).abs() <= tol).all()), (dim, float((e - ref).abs().max()))
     frac = timestep_embedding(torch.tensor([0.5, 10.25], device=DEV), 8).cpu()  # fractional timesteps are allowed
     assert bool(torch.isfinite(frac).all()) and float((frac[:, :4] ** 2 + frac[:, 4:] ** 2 - 1).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
+@pytest.mark.parametrize("cls,heads,d,T", [("QKVAttentionLegacy", 4, 16, 49), ("QKVAttention", 8, 48, 256), ("QKVAttentionLegacy", 1, 64, 1024),
+                                           ("QKVAttention", 2, 32, 200)])
+def test_qkv_attention_standalone_vs_oracle(prec, cls, heads, d, T, monkeypatch):
+    """QKVAttentionLegacy / QKVAttention .forward(qkv) (unet_openai.py:465-481, 497-515) called on their own, both channel orders,
+    ragged lengths, vs the oracle restatement of the same two functions"""
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from oracle import unet_ref as UR
+    from tests.synth import synth_input
+    monkeypatch.setenv("EOD_PRECISION", prec)
+    qkv = synth_input(f"sa{cls}{T}", (2, 3 * heads * d, T), 6)
+    ref = (UR.qkv_attention_legacy if cls == "QKVAttentionLegacy" else UR.qkv_attention_new)(qkv, heads)
+    with torch.no_grad():
+        out = getattr(U, cls)(heads)(qkv.to(DEV)).cpu()
+    assert out.shape == ref.shape == (2, heads * d, T)
+    assert rel_l2(out, ref) < (2e-3 if prec == "fp16" else 5e-6)
+    with pytest.raises(U._lib.EodError):
+        getattr(U, cls)(1)(torch.zeros(1, 3 * 20, 8, device=DEV))  # head dim 20: refused, not approximated
