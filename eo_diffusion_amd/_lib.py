@@ -112,6 +112,9 @@ SYMBOLS = {
     "eod_ddim_step": (i32, [vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp]),
     "eod_cfg_combine": (i32, [vp, vp, f32, vp, i64, vp]),
     "eod_ldm_p_sample": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp]),
+    "eod_repaint_cond": (i32, [vp, vp, vp, i32, i32, i64, i32, vp]),
+    "eod_postprocess": (i32, [vp, vp, i64, i32, vp]),
+    "eod_masked_preview": (i32, [vp, vp, vp, i32, i32, i64, f32, vp]),
     "eod_randn_philox": (i32, [vp, i32, i64, C.c_uint64, i64, i32, i32, vp]),
     "eod_program_run": (i32, [C.POINTER(Op), i32, vp]),
     "eod_timer_create": (vp, [i32, i32]),

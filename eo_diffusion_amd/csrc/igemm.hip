@@ -908,7 +908,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = f[e] * sc[e] + sh[e];
-                    if (p.gn_silu) v = silu_f<false>(v);
+                    // (fp32x3: v_exp_f32 / v_rcp_f32 form, ~2 ulp -- far inside the 2^-22 of the split product that consumes it;
+                    //  the exact-fp32 mode keeps the IEEE expf / divide form)
+                    if (p.gn_silu) v = silu_f<SPLIT>(v);
                     o[e] = v;
                 }
                 outv = __builtin_bit_cast(i32x4, o);

@@ -295,3 +295,73 @@ extern "C" int eod_ldm_p_sample(const float* x, const float* eps, const float* n
     EOD_CHECK_LAUNCH("ldm_p_sample");
     return EOD_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Harness-side elementwise ops of inference.py, same bit-exact convention as above:
+//   repaint_cond   inference.py:100-109   cond = cat(image, 1 - mask)   (cond_type == "sum": mask 1 = keep after the inversion)
+//   postprocess    inference.py:128       samples.clip(0, 1)  |  (samples + 1) / 2
+//   masked_preview inference.py:134       image * (mask + 0.7).clip(0, 1)
+// ---------------------------------------------------------------------------------------------
+__global__ void repaint_cond_kernel(const float* __restrict__ image, const float* __restrict__ mask, float* __restrict__ cond, int C,
+                                    long long hw, int invert) {
+    const int n = blockIdx.y;
+    const long long per_in = (long long)C * hw, per_out = (long long)(C + 1) * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per_out; i += (long long)gridDim.x * blockDim.x) {
+        float v;
+        if (i < per_in) {
+            v = image[(long long)n * per_in + i];
+        } else {
+            const float m = mask[(long long)n * hw + (i - per_in)];
+            v = invert ? 1.0f - m : m;
+        }
+        cond[(long long)n * per_out + i] = v;
+    }
+}
+
+__global__ void postprocess_kernel(const float* __restrict__ x, float* __restrict__ y, long long numel, int mode) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float o;
+        if (mode == 0) {
+            o = fminf(fmaxf(v, 0.0f), 1.0f);
+            if (v != v) o = v;  // torch.clip propagates NaN
+        } else {
+            const float a = v + 1.0f;
+            o = a / 2.0f;
+        }
+        y[i] = o;
+    }
+}
+
+__global__ void masked_preview_kernel(const float* __restrict__ image, const float* __restrict__ mask, float* __restrict__ out, int C,
+                                      long long hw, float lift) {
+    const int n = blockIdx.y;
+    const long long per = (long long)C * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long long)gridDim.x * blockDim.x) {
+        const float a = mask[(long long)n * hw + (i % hw)] + lift;
+        const float g = fminf(fmaxf(a, 0.0f), 1.0f);
+        out[(long long)n * per + i] = image[(long long)n * per + i] * g;
+    }
+}
+
+extern "C" int eod_repaint_cond(const float* image, const float* mask, float* cond, int N, int C, int64_t hw, int invert, void* stream) {
+    EOD_REQUIRE(image && mask && cond && N > 0 && C > 0 && hw > 0, "repaint_cond: bad args");
+    hipLaunchKernelGGL(repaint_cond_kernel, dim3(blocks_for((long long)(C + 1) * hw, 512), N), dim3(256), 0, (hipStream_t)stream, image, mask, cond, C, (long long)hw, invert);
+    EOD_CHECK_LAUNCH("repaint_cond");
+    return EOD_OK;
+}
+
+extern "C" int eod_postprocess(const float* x, float* y, int64_t numel, int mode, void* stream) {
+    EOD_REQUIRE(x && y && numel > 0 && (mode == 0 || mode == 1), "postprocess: bad args");
+    hipLaunchKernelGGL(postprocess_kernel, dim3(blocks_for(numel, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)numel, mode);
+    EOD_CHECK_LAUNCH("postprocess");
+    return EOD_OK;
+}
+
+extern "C" int eod_masked_preview(const float* image, const float* mask, float* out, int N, int C, int64_t hw, float lift, void* stream) {
+    EOD_REQUIRE(image && mask && out && N > 0 && C > 0 && hw > 0, "masked_preview: bad args");
+    hipLaunchKernelGGL(masked_preview_kernel, dim3(blocks_for((long long)C * hw, 512), N), dim3(256), 0, (hipStream_t)stream, image, mask, out, C, (long long)hw, lift);
+    EOD_CHECK_LAUNCH("masked_preview");
+    return EOD_OK;
+}

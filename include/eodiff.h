@@ -238,6 +238,14 @@ int eod_ldm_p_sample(const float* x, const float* eps, const float* noise, const
 int eod_randn_philox(float* out, int N, int64_t chw, uint64_t seed, int64_t sample0, int32_t step,
                      int32_t stream_id, void* stream);
 
+/* harness-side elementwise ops of inference.py, fp32, bit-exact vs the torch expressions:
+ *   eod_repaint_cond   :100-109  cond [N][C+1][hw] = cat(image [N][C][hw], invert ? 1 - mask : mask), mask [N][1][hw]
+ *   eod_postprocess    :128      mode 0: y = clip(x, 0, 1) (data in [0,1]);  mode 1: y = (x + 1) / 2 (data in [-1,1])
+ *   eod_masked_preview :134      out = image * clip(mask + lift, 0, 1)   (lift = 0.7 in the reference) */
+int eod_repaint_cond(const float* image, const float* mask, float* cond, int N, int C, int64_t hw, int invert, void* stream);
+int eod_postprocess(const float* x, float* y, int64_t numel, int mode, void* stream);
+int eod_masked_preview(const float* image, const float* mask, float* out, int N, int C, int64_t hw, float lift, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Native executor: run a pre-built program (array of tagged descriptors) on one stream without
  * returning to the host language between launches (replaces the ~100-180 Python-dispatched

@@ -161,3 +161,18 @@ def test_ldm_register_schedule_buffers_vs_fixture(sch, T):
     assert m.num_timesteps == T
     for k, v in g.items():
         assert bits_equal(getattr(m, k), v), (sch, T, k)
+
+
+def test_make_label_matches_reference_semantics():
+    """script_utils/utils.py:17-37: one rectangle of ones, side lengths between 10 % and 40 % of the image, fully inside it, and
+    the same draw order from the same RandomState as the reference's four np.random.randint calls"""
+    import numpy as np
+    from eo_diffusion_amd.harness import make_label
+    for seed in range(20):
+        lab = make_label((64, 48), 10, 10, 40, 40, np.random.RandomState(seed))
+        r = np.random.RandomState(seed)
+        ws, hs = r.randint(6, 25, 1)[0], r.randint(4, 19, 1)[0]
+        x, y = r.randint(ws, 64 - ws, 1)[0], r.randint(hs, 48 - hs, 1)[0]
+        ref = np.zeros((64, 48))
+        ref[x:x + ws, y:y + hs] = 1
+        assert np.array_equal(lab, ref) and lab.sum() == ws * hs

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-shape conv micro-benchmark (kernel iteration / rocprofv3 target).
-   python tools/conv_bench.py [--prec fp16] [--shapes name,...] [--iters 20]"""
+   python tools/conv_bench.py [--prec fp16|fp32|fp32x3] [--shapes name,...] [--iters 20] [--gn]   (--gn: GroupNorm+SiLU of the input fused)"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--prec", default="fp16")
     ap.add_argument("--shapes", default="l0_128,l0_384,l1_256,l1_640,l2_384,l3_512,up_256,sk_384")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--gn", action="store_true")
     a = ap.parse_args()
     dev = "cuda:0"
     for name in a.shapes.split(","):
@@ -29,9 +30,12 @@ def main():
         prog = Program(dev, a.prec)
         x = prog.act(N, H, W, Cin)
         x.t.normal_()
-        w = prog.empty((k * k, Cout, Cin)); w.normal_(std=0.02)
+        w = prog.pack_conv(torch.randn((Cout, Cin, k, k), device=dev) * 0.02)
         b = prog.empty((Cout,), torch.float32); b.normal_()
-        y, _ = prog.conv(x, w, b, Cout, ksize=k, stride=stride, pad=k // 2, upsample=ups)
+        gn = None
+        if a.gn and not ups and k == 3:
+            gn = (prog.gn_stats([x], prog.f32(torch.ones(Cin, device=dev)), prog.f32(torch.zeros(Cin, device=dev))), True)
+        y, _ = prog.conv(x, w, b, Cout, ksize=k, stride=stride, pad=k // 2, upsample=ups, gn=gn)
         prog.finalize()
         for _ in range(3): prog.run()
         torch.cuda.synchronize()
@@ -40,7 +44,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.iters
         fl = 2.0 * N * y.H * y.W * Cout * Cin * k * k
-        print(f"{name:8s} {a.prec} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
+        print(f"{name:8s} {a.prec}{' gn' if gn else ''} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
 
 if __name__ == "__main__":
     main()
