@@ -157,6 +157,7 @@ class _Emitter(nn.Module):
         out = th.empty((y.N, y.C, y.H, y.W), dtype=th.float32, device=x.device)
         i2 = prog.to_nchw(y)
         prog.ops[i2].u.small.p[1] = out.data_ptr()
+        prog.next_dropout_step()
         prog.run()
         th.cuda.current_stream(x.device).synchronize()  # program-owned buffers die with `prog`
         return out
@@ -296,8 +297,6 @@ class ResBlock(TimestepBlock):
         cin = sum(s.C for s in srcs)
         assert cin == self.channels, (cin, self.channels)
         cout = self.out_channels
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("dropout > 0 in train mode is not built yet; call .eval()")
         gn1, conv1 = self.in_layers[0], self.in_layers[2]
         gn2, conv2 = self.out_layers[0], self.out_layers[3]
         # GroupNorm+SiLU of the block input: statistics here, the normalisation itself is applied inside the conv
@@ -329,6 +328,14 @@ class ResBlock(TimestepBlock):
             k = sc.kernel_size[0]
             skip, _ = prog.conv(srcs[0], prog.pack_conv(sc.weight), prog.f32(sc.bias), cout,
                                 x2=srcs[1] if len(srcs) > 1 else None, ksize=k, stride=1, pad=k // 2)
+        if self.training and self.dropout > 0:
+            # train-mode forward without autograd (the reference samples previews from modules left in train mode): nn.Dropout of
+            # out_layers[2] (unet_openai.py:339) is live.  GroupNorm+SiLU is materialised, then y = x * keep / (1 - p) with the
+            # Philox mask of eod_dropout keyed by (seed, layer, forward counter) -- a fresh mask every forward
+            hn = prog.gn_apply([h1], ss2, silu=True)
+            hd = prog.dropout(hn, self.dropout)
+            out, _ = prog.conv(hd, prog.pack_conv(conv2.weight), prog.f32(conv2.bias), cout, res=skip, stats=True)
+            return out
         # every block output feeds a GroupNorm next (in_layers / attention norm / out head): emit its partial sums here
         out, _ = prog.conv(h1, prog.pack_conv(conv2.weight), prog.f32(conv2.bias), cout, res=skip, stats=True, gn=(ss2, True))
         return out
@@ -730,7 +737,8 @@ class UNetModel(_Emitter):
         if y is not None:
             assert y.shape == (N,), (y.shape, x.shape)
         prog = self.program_for(N, cx, ccond, H, W, x.device, y is not None)
-        if getattr(self, "_use_graph", None) if getattr(self, "_use_graph", None) is not None else os.environ.get("EOD_GRAPH", "0") == "1":
+        use_graph = self._use_graph if getattr(self, "_use_graph", None) is not None else os.environ.get("EOD_GRAPH", "0") == "1"
+        if use_graph and not prog.drop_ops:  # (a captured graph would replay ONE dropout mask: train-mode dropout runs un-captured)
             return self._forward_graph(prog, x, timesteps, cond, y)
         xin = x if (x.dtype == th.float32 and x.is_contiguous()) else x.float().contiguous()
         t64 = timesteps.to(device=x.device, dtype=th.int64).contiguous()
@@ -745,6 +753,7 @@ class UNetModel(_Emitter):
             prog.set_binding("y", y64.data_ptr())
         prog.set_binding("t", t64.data_ptr())
         prog.set_binding("out", out.data_ptr())
+        prog.next_dropout_step()
         prog.run()
         # xin/t64/cin/y64 may be temporaries: the caching allocator is stream-ordered on this stream,
         # so reuse after this frame is ordered behind the kernels that read them.

@@ -224,8 +224,14 @@ __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
     // pad_tl: mode 1 = zero row / column on top / left of the 2x image (3x3 -> 7x7 hack); mode 2 = the backward of that (the sums
     // skip the first row / column of the input); mode 3 = the average pool dropped a last odd row / column: one zero row / column
     // at the BOTTOM / RIGHT of the output
+    // mode 4 = crop: drops the last row (pad_tl & 1) and / or column (pad_tl & 2) -- the backward-data conv of a stride-2 conv on
+    // an odd map is computed on the even (H+1) x (W+1) grid
     const bool up = mode == 1 || mode == 3;
-    const int Ho = up ? 2 * H + pad_tl : (H - (mode == 2 ? pad_tl : 0)) / 2, Wo = up ? 2 * W + pad_tl : (W - (mode == 2 ? pad_tl : 0)) / 2;
+    int Ho = up ? 2 * H + pad_tl : (H - (mode == 2 ? pad_tl : 0)) / 2, Wo = up ? 2 * W + pad_tl : (W - (mode == 2 ? pad_tl : 0)) / 2;
+    if (mode == 4) {
+        Ho = H - (pad_tl & 1);
+        Wo = W - ((pad_tl >> 1) & 1);
+    }
     const long long total = (long long)N * Ho * Wo * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -235,7 +241,9 @@ __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
         const int ho = (int)(r % Ho);
         const long long n = r / Ho;
         float v;
-        if (up) {
+        if (mode == 4) {
+            v = (float)x[((n * H + ho) * W + wo) * C + c];
+        } else if (up) {
             const int hi = mode == 1 ? ho - pad_tl : ho, wi = mode == 1 ? wo - pad_tl : wo;
             v = (hi >= 0 && wi >= 0 && hi < 2 * H && wi < 2 * W) ? (float)x[((n * H + (hi >> 1)) * W + (wi >> 1)) * C + c] : 0.0f;
             if (mode == 3) v *= 0.25f;
@@ -251,11 +259,12 @@ __global__ void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
 
 extern "C" int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y, void* stream) {
     EOD_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, "resample2x: bad args");
-    EOD_REQUIRE(mode >= 0 && mode <= 3, "resample2x: mode %d", mode);
+    EOD_REQUIRE(mode >= 0 && mode <= 4, "resample2x: mode %d", mode);
     const bool up = mode == 1 || mode == 3;
     EOD_REQUIRE(up || (H >= 2 && W >= 2), "resample2x: avg-pool needs at least 2x2 (%dx%d)", H, W);  // odd dims: floor, like ATen
     const int o2 = mode == 2 ? pad_tl : 0;
-    const long long total = (long long)N * (up ? 2 * H + pad_tl : (H - o2) / 2) * (up ? 2 * W + pad_tl : (W - o2) / 2) * C;
+    long long total = (long long)N * (up ? 2 * H + pad_tl : (H - o2) / 2) * (up ? 2 * W + pad_tl : (W - o2) / 2) * C;
+    if (mode == 4) total = (long long)N * (H - (pad_tl & 1)) * (W - ((pad_tl >> 1) & 1)) * C;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     if (dtype == EOD_F16)
         hipLaunchKernelGGL(resample2x_kernel<half_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, N, H, W, C, mode, pad_tl);

@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
+from ._lib import (OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_DROPOUT, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
                    OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
 
 # precision mode -> storage dtype of activations.  "fp32x3": fp32 storage, the 3x3 halo convs compute every product as three fp16
@@ -90,6 +90,9 @@ class Program:
         self._timer = None
         self.L = _lib.lib()
         self.nbytes = 0
+        self.drop_ops = []       # indices of OP_DROPOUT descriptors (their `step` field advances every run)
+        self.drop_seed = int(torch.initial_seed()) & (2**63 - 1)
+        self.drop_step = 0
 
     # ------------------------------------------------------------------ memory
     def empty(self, shape, dtype=None, zero=False):
@@ -326,6 +329,10 @@ class Program:
         return idx
 
     def resample2x(self, x, mode, pad_tl=False):
+        if mode == 4:  # crop: pad_tl = bit 0 drop the last row, bit 1 drop the last column
+            y = self.act(x.N, x.H - (int(pad_tl) & 1), x.W - ((int(pad_tl) >> 1) & 1), x.C)
+            self._small(OP_POOL, p=(ptr(x.t), ptr(y.t)), i=(self.dt, x.N, x.H, x.W, x.C, 4, int(pad_tl)))
+            return y
         if mode in (1, 3):
             ho, wo = 2 * x.H + int(pad_tl), 2 * x.W + int(pad_tl)
         else:
@@ -334,6 +341,23 @@ class Program:
         y = self.act(x.N, ho, wo, x.C)
         self._small(OP_POOL, p=(ptr(x.t), ptr(y.t)), i=(self.dt, x.N, x.H, x.W, x.C, mode, int(pad_tl)))
         return y
+
+    def dropout(self, x, p):
+        """nn.Dropout in train mode: y = x * keep / (1 - p), keep = Philox4x32-10(seed; element / 4, layer, step) (eod_dropout)"""
+        y = self.act(x.N, x.H, x.W, x.C)
+        layer = len(self.drop_ops)
+        idx = self._small(OP_DROPOUT, p=(ptr(x.t), ptr(y.t)), l=(x.t.numel(), self.drop_seed), i=(self.dt, layer, 0), f=(float(p),))
+        self.drop_ops.append(idx)
+        return y
+
+    def next_dropout_step(self):
+        if not self.drop_ops:
+            return
+        self.drop_step += 1
+        if self._arr is None:
+            self.finalize()
+        for idx in self.drop_ops:
+            self._arr[idx].u.small.i[2] = self.drop_step & 0x7fffffff
 
     def temb(self, desc_fields):
         op, idx = self._push(OP_TEMB)

@@ -11,8 +11,7 @@ unchanged on them.
 Scope of this first version: ResBlock (plain), AttentionBlock (legacy qkv order), Upsample / Downsample with conv,
 first / head conv, the timestep MLP, class conditioning, and the factory variants use_scale_shift_norm (FiLM),
 resblock_updown (incl. odd maps and the 3x3 -> 7x7 pad hack), use_new_attention_order, dropout (Philox mask, recomputed in the
-backward).  Not yet: stride-2 convs of odd maps, Upsample(use_conv=True) of a 3x3 map, Up/Downsample without conv outside
-resblock_updown -- these raise EodError (never a silent fallback)."""
+backward), stride-2 convs of odd maps, Upsample(use_conv=True) of a 3x3 map, Up/Downsample without conv (conv_resample=False)."""
 import ctypes as C
 import math
 import os
@@ -316,13 +315,17 @@ class UNetTrainer:
         if isinstance(layer, U.ResBlock):
             return self._resblock(layer, h)
         if isinstance(layer, U.Upsample):
-            if not layer.use_conv or isinstance(h, tuple) or (h.H == 3 and h.W == 3):
-                raise EodError("training: this Upsample variant is not built yet")
+            if isinstance(h, tuple):
+                raise EodError("training: Upsample over a virtual concat is not supported")
+            if not layer.use_conv:           # conv_resample=False: plain nearest 2x (unet_openai.py:229-241 without :241)
+                return self._pool_fwd(h, 1)
+            if h.H == 3 and h.W == 3:        # the 3x3 -> 7x7 zero row / column hack (:237-239): materialise it, then a plain conv
+                return self._conv_fwd([self._pool_fwd(h, 1)], layer.conv)
             return self._conv_fwd([h], layer.conv, upsample=True)
         if isinstance(layer, U.Downsample):
-            if not layer.use_conv or h.H % 2 or h.W % 2:
-                raise EodError("training: this Downsample variant is not built yet (needs conv, even sizes)")
-            return self._conv_fwd([h], layer.op, stride=2)
+            if not layer.use_conv:           # conv_resample=False: 2x2 average pool (:266-267)
+                return self._pool_fwd(h, 0)
+            return self._conv_fwd([h], layer.op, stride=2)  # odd maps: the backward-data runs on the even grid and is cropped
         if isinstance(layer, U.AttentionBlock):
             return self._attention(layer, h)
         raise EodError(f"training: unsupported layer {type(layer).__name__}")
@@ -677,11 +680,14 @@ class UNetTrainer:
                 "pack_conv_weight_dgrad"))
             pack()
             self.repack.append(pack)
-            prev = None if rec.upsample else self._pop_single(xs)
+            odd = stride == 2 and ((xs.H % 2) or (xs.W % 2))  # stride-2 conv of an odd map (unet_openai.py:262-264, e.g. 7 -> 4)
+            prev = None if (rec.upsample or odd) else self._pop_single(xs)
             g, _ = self._bop(lambda: bp.conv(dy, wd, None, cs, ksize=ks, stride=1, pad=ks // 2, upsample=(2 if stride == 2 else False),
                                              res=prev))
             if rec.upsample:
                 g = self._bop(lambda: bp.resample2x(g, 2))
+            if odd:  # dX lives on the (2 Ho) x (2 Wo) grid of the zero-inserted gradient: the input's last row / column does not exist
+                g = self._bop(lambda: bp.resample2x(g, 4, (xs.H % 2) | ((xs.W % 2) << 1)))
             if (g.H, g.W) != (xs.H, xs.W):
                 raise EodError(f"training: backward-data shape {g.H}x{g.W} != input {xs.H}x{xs.W}")
             self._add_grad(xs, g)

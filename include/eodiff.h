@@ -287,7 +287,8 @@ int eod_timer_read(void* timer, float* ms);
 int eod_timer_set_mask(void* timer, const unsigned char* mask, int n_ops);
 int eod_program_run_timed(const eod_op* ops, int n_ops, void* stream, void* timer);
 /* resblock_updown helpers (unet_openai.py:320-325): mode 0 = 2x2 average pool, 1 = nearest 2x,
- * 2 = 2x2 sum pool (backward of nearest 2x), 3 = nearest 2x times 0.25 (backward of the average pool) -- training path */
+ * 2 = 2x2 sum pool (backward of nearest 2x), 3 = nearest 2x times 0.25 (backward of the average pool), 4 = crop the last row
+ * (pad_tl & 1) / column (pad_tl & 2) -- training path */
 int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mode, int pad_tl, void* y,
                    void* stream);
 

@@ -208,3 +208,45 @@ def test_qkv_attention_standalone_vs_oracle(prec, cls, heads, d, T, monkeypatch)
     assert rel_l2(out, ref) < (2e-3 if prec == "fp16" else 5e-6)
     with pytest.raises(U._lib.EodError):
         getattr(U, cls)(1)(torch.zeros(1, 3 * 20, 8, device=DEV))  # head dim 20: refused, not approximated
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
+def test_train_mode_forward_without_grad_applies_dropout(prec):
+    """train.py:149 samples previews from modules that may still be in train mode: under no_grad the inference program runs with
+    nn.Dropout live (unet_openai.py:339).  The masks are Philox draws keyed by (seed, layer, forward counter): rebuilt here through
+    the same entry point and injected into the oracle; a second forward draws new masks; eval mode has none."""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from eo_diffusion_amd.engine import current_stream_ptr
+    from oracle import unet_ref as UR
+    from tests.synth import synth_input
+    cfg = dict(unet_cfgs()["u_a1_tiny"], dropout=0.3)
+    sd = synth_state_dict(unet_param_shapes(**cfg), 7)
+    u = UNetModel(**cfg).set_precision(prec)
+    u.load_state_dict(sd)
+    u = u.to(DEV).train()
+    S = cfg["image_size"]
+    x, t = synth_input("do_x", (2, 3, S, S), 1), torch.tensor([4, 15])
+    with torch.no_grad():
+        out1 = u(x.to(DEV), t.to(DEV)).cpu()
+        prog = u.program_for(2, 3, 0, S, S, torch.device(DEV), False)
+        assert len(prog.drop_ops) == sum(1 for m in u.modules() if type(m).__name__ == "ResBlock") and prog.drop_step == 1
+        masks = []
+        for layer, idx in enumerate(prog.drop_ops):
+            sm = prog._arr[idx].u.small
+            ones = torch.ones((sm.l[0],), dtype=prog.tdtype, device=DEV)
+            mk = torch.empty_like(ones)
+            _lib.check(_lib.lib().eod_dropout(ones.data_ptr(), mk.data_ptr(), prog.dt, sm.l[0], 0.3, prog.drop_seed, layer, prog.drop_step,
+                                              current_stream_ptr(torch.device(DEV))), "eod_dropout")
+            masks.append(mk.float().cpu())
+        out2 = u(x.to(DEV), t.to(DEV)).cpu()
+        u.eval()
+        out_eval = u(x.to(DEV), t.to(DEV)).cpu()
+    keep = torch.cat([m.flatten() for m in masks])
+    assert abs(float((keep > 0).float().mean()) - 0.7) < 0.02 and abs(float(keep.max()) - 1 / 0.7) < 1e-3
+    order = iter(masks)
+    drop = lambda pfx, h: next(order).reshape(h.shape[0], h.shape[2], h.shape[3], h.shape[1]).permute(0, 3, 1, 2).to(h.dtype)
+    ref = UR.unet_forward(sd, {k: v for k, v in cfg.items() if k != "dropout"}, x, t, drop=drop)
+    assert rel_l2(out1, ref) < TOL[prec]
+    assert rel_l2(out2, out1) > 1e-2          # a new mask every forward
+    assert rel_l2(out_eval, UR.unet_forward(sd, {k: v for k, v in cfg.items() if k != "dropout"}, x, t)) < TOL[prec]

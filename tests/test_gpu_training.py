@@ -91,18 +91,43 @@ def test_training_step_with_torch_adamw_reduces_loss():
     assert losses[-1] < 0.7 * losses[0], losses
 
 
-def test_training_rejects_unbuilt_variants():
-    import eo_diffusion_amd.backbones.unet_openai as U
-    from eo_diffusion_amd._lib import EodError
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("size,in_ch,mults,extra", [
+    (16, 3, (1, 2, 2), {"conv_resample": False}),       # Up / Downsample WITHOUT conv (average pool / plain nearest 2x)
+    (28, 1, (1, 2, 2, 2), {"conv_resample": False}),    # 28 -> 14 -> 7 -> 3 (floor pool) -> 7 (3x3 -> 7x7 pad hack without conv) -> 14 -> 28
+])
+def test_training_resample_variants_vs_oracle(prec, size, in_ch, mults, extra):
+    """conv_resample=False (unet_openai.py:229-242, 266-271 without their convs), which used to raise in the training path: gradients
+    of every parameter vs torch autograd through the oracle.  (A stride-2 CONV of an odd map, or Upsample(use_conv=True) of a 3x3
+    map, cannot occur inside a UNetModel -- 5 -> 3 -> 7 or 7 -> 4 -> 8 do not meet their skip connections, the reference fails
+    at th.cat -- so those two forms, built in training.py for completeness, have no end-to-end case.)"""
     from eo_diffusion_amd.training import UNetTrainer
-    m = U.UNetModel(24, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[],
-                    channel_mult=(1, 2, 2, 2), num_heads=2).to(DEV)  # 24 -> 12 -> 6 -> 3: the 3x3 -> 7x7 pad hack of Upsample
-    with pytest.raises(EodError):
-        UNetTrainer(m, 2, 24, 24, DEV)
-    m = U.UNetModel(20, in_channels=1, model_channels=32, out_channels=1, num_res_blocks=1, attention_resolutions=[],
-                    channel_mult=(2, 4, 4, 4)).to(DEV)  # 20 -> 10 -> 5 -> 3: the stride-2 conv of an ODD map is not built yet
-    with pytest.raises(EodError):
-        UNetTrainer(m, 2, 20, 20, DEV)
+    import eo_diffusion_amd.backbones.unet_openai as U
+    m = U.UNetModel(size, in_channels=in_ch, model_channels=32, out_channels=in_ch, num_res_blocks=1, attention_resolutions=[],
+                    channel_mult=mults, num_heads=2, **extra)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 11)
+    m.load_state_dict(sd)
+    m = m.set_precision(prec).to(DEV).train()
+    cfg = dict(model_channels=32, num_res_blocks=1, channel_mult=mults, attention_resolutions=(), num_heads=2, **extra)
+    x, noise = synth_input("rvx", (2, in_ch, size, size), 3), synth_input("rvn", (2, in_ch, size, size), 4)
+    t = torch.tensor([7, 650])
+    pred_ref, gref = _oracle_grads(sd, cfg, x, noise, t)
+    tr = UNetTrainer(m, 2, size, size, DEV, loss_scale=(256.0 if prec == "fp16" else 1.0))
+    pred = tr.forward(x.to(DEV), t.to(DEV))
+    assert rel_l2(pred.cpu(), pred_ref) < (2e-5 if prec == "fp32" else 1e-2)
+    tr.backward(2.0 * (pred - noise.to(DEV)) / pred.numel())
+    torch.cuda.synchronize()
+    gmax = max(float(v.norm()) for v in gref.values())
+    worst, n_checked = ("", 0.0), 0
+    for name, p in m.named_parameters():
+        if name not in gref or float(gref[name].norm()) < 1e-5 * gmax:
+            continue
+        e = rel_l2(p.grad.cpu(), gref[name])
+        n_checked += 1
+        if e > worst[1]:
+            worst = (name, e)
+    assert n_checked > 20
+    assert worst[1] < GTOL[prec], f"worst gradient: {worst}"
 
 
 @pytest.mark.parametrize("use_fp16", [False, True])
