@@ -103,6 +103,8 @@ template <> struct Mma<float> {
 // that DMA'd them (lanes l and l^1 hold the two chunks of a pair and swap halves through DPP).  A K-step of 128 bytes = 32 k =
 // 2 MFMA sub-steps; lane half h of sub-step s reads pair 2s+h: hi at chunk 2(2s+h), lo at chunk 2(2s+h)+1 -- the same
 // ds_read_b128 / XOR-swizzle machinery as the other modes, 16 reads and 24 MFMAs per K-step and wave.
+// Measured and rejected here (A/B on MI355X, tools/conv_bench.py): reading both sub-steps' fragments ahead of the MFMAs (two register
+// sets, pinned order; 246-256 VGPRs): -1..-3 %; rewriting the patch piece before instead of after a step's MFMAs: +-0.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define EOD_SPLIT_ASCALE 16.0f
 __device__ __forceinline__ void mma_f16(const i32x4& a, const i32x4& b, f32x16& c) {
