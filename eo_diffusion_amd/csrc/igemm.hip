@@ -210,15 +210,25 @@ __device__ __forceinline__ void map_tile(const IgemmP& p, int& tile_m, int& tile
 // (fp32, wave-private slab), 16-byte stores along the channel axis with the residual added on the way.
 // Precondition: every wave has passed a barrier after its last LDS read of the operand ring.
 // =============================================================================================
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, bool OUTF32>
-__device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& g, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
-                                               char* smem, int wave, int lane, int n0) {
+// accumulator layout of the two MFMA shapes (C/D maps of cdna_hip_programming.md section 3): MS = 32: 32x32 tiles, 16 registers,
+// col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5);  MS = 16: 16x16 tiles, 4 registers, col = lane & 15, row = 4 (lane >> 4) + r
+template <int MS> struct AccLayout {
+    static constexpr int R = MS == 32 ? 16 : 4;
+    typedef typename std::conditional<MS == 32, f32x16, f32x4>::type vec;
+    static __device__ __forceinline__ int row(int r, int lane) { return MS == 32 ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r; }
+    static __device__ __forceinline__ int col(int lane) { return MS == 32 ? (lane & 31) : (lane & 15); }
+};
+
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, bool OUTF32, int MS = 32>
+__device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& g,
+                                               typename AccLayout<MS>::vec (&acc)[BM / WAVES_M / MS][BN / WAVES_N / MS], char* smem, int wave,
+                                               int lane, int n0) {
     constexpr int ES = sizeof(T);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TM = WM / MS, TN = WN / MS, R = AccLayout<MS>::R;
     constexpr int EP_LD = WN + 4;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int lr = lane & 31, lh = lane >> 5;
+    const int lr = AccLayout<MS>::col(lane);
     // =========================== epilogue ===========================
     // 1) C layout (lane = column): alpha, per-column bias; conv: per-sample bias needs the row's image.
     int col[TN];
@@ -226,7 +236,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     float bcol[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        col[j] = n0 + wn * WN + j * 32 + lr;
+        col[j] = n0 + wn * WN + j * MS + lr;
         cok[j] = col[j] < p.Ncols;
         bcol[j] = (cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f;
     }
@@ -252,8 +262,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int r = 0; r < R; ++r) {
+                const int row = wm * WM + i * MS + AccLayout<MS>::row(r, lane);
                 int nrel, ho, wo;
                 if (!decode_row<BM>(p, g, row, nrel, ho, wo)) continue;
                 const int n = g.n_first + nrel;
@@ -321,8 +331,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rw = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // row inside the wave's slab
+        for (int r = 0; r < R; ++r) {
+            const int rw = i * MS + AccLayout<MS>::row(r, lane);  // row inside the wave's slab
             float cb[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) cb[j] = 0.0f;
@@ -345,7 +355,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                 }
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * 32 + lr] = acc[i][j][r] * p.alpha + bcol[j] + cb[j];
+            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * MS + lr] = acc[i][j][r] * p.alpha + bcol[j] + cb[j];
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
     __builtin_amdgcn_wave_barrier();
@@ -786,9 +796,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // UPS = true: the conv input is the nearest-2x upsampling of x (Upsample.conv, unet_openai.py:236-241).  The 8x16
 // output tile then reads only a (8/2+2) x (16/2+2) = 6 x 10 patch of the STORED half-resolution tensor: output pixel
 // (u, v) + tap reads patch row ((u+1)>>1, (v+1)>>1) -- the 2x image is never materialised and A traffic drops ~28x.
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false>
+// MS = MFMA shape of the fp16 products: 32 = v_mfma_f32_32x32x16_f16 (2x2 tiles per wave), 16 = v_mfma_f32_16x16x32_f16 (4x4 tiles).
+// Same flops, same LDS bytes and reads per K-step; under the chip's power limit the 16x16x32 form sustains ~1.14x the issued
+// FLOP/s (tools/probe/mfma_shape.hip: 1.76 vs 1.54 PFLOP/s for this wave tile with every operand re-read from LDS).
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel(const IgemmP p) {
     static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 product is a mode of fp32 storage");
+    static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only");
     constexpr bool XF = GN || SPLIT;  // the staged patch pieces are rewritten in place by the wave that DMA'd them
     constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
     constexpr int BM = 32 * NW, TH = BM / 16, TW = 16;
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     constexpr int PG = (PR + 7) / 8;                                             // 23 (8) DMA groups of 8 rows
     constexpr int LAH = (PG + NW - 1) / NW;                                      // patch pieces per wave
     constexpr int ES = sizeof(T), EPC = 16 / ES, BKB = 128, BK = BKB / ES;
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / MS, TN = WN / MS;
     constexpr int GB = BN / 8, LB = GB / NW;
     constexpr int ABUF = PG * 1024, BSTAGE = BN * BKB;
     static_assert(GB % NW == 0 && LAH <= 6 && (BSTAGES == 2 || BSTAGES == 3), "layout");
@@ -939,20 +953,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         }
     };
 
-    f32x16 acc[TM][TN];
+    typename AccLayout<MS>::vec acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < AccLayout<MS>::R; ++r) acc[i][j][r] = 0.0f;
 
-    // ---- fragment addressing ----
-    const int lr = lane & 31, lh = lane >> 5;
+    // ---- fragment addressing: lane (lr = row inside an MS-row block, lh = which 8-k slice of the MFMA's K it supplies) ----
+    const int lr = lane & (MS - 1), lh = MS == 32 ? lane >> 5 : lane >> 4;
     int prow0[TM], pyo[TM], pxo[TM];  // patch row of this lane's output pixel for tap (0,0) / its tile coordinates
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int r = wm * WM + i * 32 + lr;
+        const int r = wm * WM + i * MS + lr;
         pyo[i] = r >> 4;
         pxo[i] = r & 15;
         prow0[i] = pyo[i] * PW + pxo[i];
@@ -1047,7 +1061,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                 arow[i] = prow * BKB;
                 asw[i] = (prow >> 1) & 7;
             }
-            if constexpr (SPLIT) {
+            if constexpr (MS == 16 && SPLIT) {
+                // the K-step's 32 k are ONE 16x16x32 sub-step: lane quarter lh supplies chunk pair pi(lh) = {0, 3, 1, 2}[lh] (the
+                // permutation keeps every ds_read_b128 lane group on 16 distinct 16-byte slots; A and B use the same one, so the
+                // contraction is unchanged).  [8 x hi] at chunk 2 pi, [8 x lo] behind it; 3 x 16 MFMAs, smallest terms first.
+                const int ch = 2 * ((0x2130 >> (4 * lh)) & 3);
+                i32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((ch + 1) ^ asw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * MS * BKB + ((ch ^ bsw) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + ((ch ^ asw[i]) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * MS * BKB + (((ch + 1) ^ bsw) << 4));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+            } else if constexpr (MS == 16) {
+                // fp16 storage: the K-step's 64 k are two 16x16x32 sub-steps; lane quarter lh of sub-step s reads chunk 4 s + lh
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int ch = 4 * s + lh;
+                    i32x4 fa16[TM], fb16[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa16[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + ((ch ^ asw[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb16[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * MS * BKB + ((ch ^ bsw) << 4));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa16[i]), __builtin_bit_cast(half8, fb16[j]), acc[i][j], 0, 0, 0);
+                }
+            } else if constexpr (SPLIT) {
                 // 2 sub-steps of 16 k; lane half lh of sub-step s owns chunk pair 2s+lh: [8 x hi] at chunk 2(2s+lh), [8 x lo] right
                 // behind it.  Three fp16 MFMAs per 32x32 tile into the one fp32 accumulator, smallest terms first.
 #pragma unroll
@@ -1121,9 +1180,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     if constexpr (SPLIT) {
         IgemmP pe = p;
         pe.alpha = p.alpha * p.w_scale[1];  // undo the weight and activation scales (exact powers of two)
-        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true>(pe, g, acc, smem, wave, lane, n0);
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0);
     } else {
-        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4>(p, g, acc, smem, wave, lane, n0);
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0);
     }
 }
 
@@ -1153,6 +1212,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long l
 
 // ------------------------------------------------------------------------------------------ host side
 #include <stdlib.h>
+// MFMA shape of the fp16 products in the halo kernel: 16 (default, v_mfma_f32_16x16x32_f16) or 32 (EOD_MFMA_SHAPE=32, A/B switch)
+static int halo_mfma_shape() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("EOD_MFMA_SHAPE");
+        v = (e && atoi(e) == 32) ? 32 : 16;
+    }
+    return v;
+}
 static int igemm_forced_cfg() {
     static int v = -1;
     if (v < 0) {
@@ -1213,7 +1281,7 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int NW = WAVES_M * WAVES_N, BM = 32 * NW, TH = BM / 16;
@@ -1222,7 +1290,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128 + (GN ? 2048 : 0);
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1425,18 +1493,31 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     EOD_REQUIRE(!d->w_split || (conv_split_ok(d, Ho, Wo, p.force_cfg) && d->w_scale),
                 "conv: w_split needs a geometry for which eod_conv_split_ok(d) == 1 and the w_scale of eod_pack_conv_weight_split");
     p.w_scale = d->w_split ? d->w_scale : nullptr;
+    const bool m16 = halo_mfma_shape() == 16;
     if (halo_ok && d->w_split) {
         // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)
-        p.w_scale = d->w_scale;
         if (d->gn_scale_shift) {
             EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
-            return d->Cout <= 32 ? launch_halo<float, 32, 4, 1, false, 2, true, true>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true, true>(p, st);
+            if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, true, true>(p, st);
+            return m16 ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true, true>(p, st);
         }
-        if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false, true>(p, st);
-        if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false, true>(p, st);
-        return launch_halo<float, 128, 2, 2, false, 2, false, true>(p, st);
+        if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, false, true>(p, st);
+        if (d->upsample) return m16 ? launch_halo<float, 128, 2, 2, true, 2, false, true, 16>(p, st) : launch_halo<float, 128, 2, 2, true, 2, false, true>(p, st);
+        return m16 ? launch_halo<float, 128, 2, 2, false, 2, false, true, 16>(p, st) : launch_halo<float, 128, 2, 2, false, 2, false, true>(p, st);
+    }
+    if (halo_ok && d->dtype == EOD_F16 && m16 && !halo_big(d, Ho, p.force_cfg)) {
+        if (d->gn_scale_shift) {
+            EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
+            p.gn_ss = d->gn_scale_shift;
+            p.gn_silu = d->gn_silu;
+            if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, true, false, 16>(p, st);
+            return launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16>(p, st);
+        }
+        if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, false, false, 16>(p, st);
+        if (d->upsample) return launch_halo<half_t, 128, 2, 2, true, 2, false, false, 16>(p, st);
+        return launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16>(p, st);
     }
     if (halo_ok) {
         if (d->Cout <= 32) {  // head conv (out_nchw_f32): HBM-bound, the patch removes the 9x re-gather of the input
