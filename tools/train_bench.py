@@ -19,20 +19,21 @@ a = ap.parse_args()
 dev = torch.device("cuda", 0)
 m = build_model(a.arch, a.size, a.precision, dev, in_ch=a.in_ch)
 unet = m.model.train()
-t0 = time.perf_counter()
-tr = UNetTrainer(unet, a.batch, a.size, a.size, dev, loss_scale=(1024.0 if a.precision == "fp16" else 1.0))
-torch.cuda.synchronize()
-print(f"build {time.perf_counter() - t0:.1f} s; forward buffers {tr.prog.nbytes / 2**30:.2f} GiB, backward buffers {tr.bprog.nbytes / 2**30:.2f} GiB, "
-      f"{len(tr.bwd)} backward launches", flush=True)
 x = torch.randn(a.batch, a.in_ch, a.size, a.size, device=dev)
 noise = torch.randn_like(x)
 t = torch.randint(0, 1000, (a.batch,), device=dev)
-opt = None
+opt = None  # (the optimizer first: the fused AdamW moves the parameters into its flat buffer, the trainer bakes their pointers)
 if a.optimizer == "torch":
     opt = torch.optim.AdamW(unet.parameters(), lr=1e-4)
 elif a.optimizer == "fused":
     from eo_diffusion_amd.optim import AdamW
     opt = AdamW(unet.parameters(), lr=1e-4)
+
+t0 = time.perf_counter()
+tr = UNetTrainer(unet, a.batch, a.size, a.size, dev, loss_scale=(1024.0 if a.precision == "fp16" else 1.0))
+torch.cuda.synchronize()
+print(f"build {time.perf_counter() - t0:.1f} s; forward buffers {tr.prog.nbytes / 2**30:.2f} GiB, backward buffers {tr.bprog.nbytes / 2**30:.2f} GiB, "
+      f"{len(tr.bwd)} backward launches", flush=True)
 
 def step():
     xt = m._forward_diffusion(x, t, noise)
