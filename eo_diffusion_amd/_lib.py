@@ -90,6 +90,7 @@ SYMBOLS = {
     "eod_embedding_bwd": (i32, [vp, vp, i32, i32, i32, f32, vp, vp]),
     "eod_mse_loss": (i32, [vp, vp, i64, vp, vp, vp, i32, vp]),
     "eod_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp]),
+    "eod_adamw_step_guarded": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i32, vp, vp, i32, vp]),
     "eod_ema_update": (i32, [vp, vp, i64, f64, vp]),
     "eod_pack_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
     "eod_nchw_to_nhwc": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),

@@ -815,6 +815,69 @@ extern "C" int eod_adamw_step(float* p, const float* g, float* m, float* v, int6
     return EOD_OK;
 }
 
+// ---- overflow guard of fp16 training (static loss scale): a gradient that is not finite must not reach the weights.  Two launches,
+// no atomics, no host round trip: per-block flags, then one block folds them into state = {found now, skipped steps so far}; the
+// guarded AdamW reads state[0] and leaves p / m / v untouched when it is set.
+__global__ void nonfinite_blocks_kernel(const float* __restrict__ g, long long n, int* __restrict__ block_flags) {
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        bad |= !(fabsf(v) <= 3.402823466e38f);  // inf or NaN
+    }
+    bad = __any(bad);
+    __shared__ int sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) block_flags[blockIdx.x] = sh[0] | sh[1] | sh[2] | sh[3];
+}
+__global__ void nonfinite_fold_kernel(const int* __restrict__ block_flags, int nblocks, int* __restrict__ state) {
+    int bad = 0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) bad |= block_flags[i];
+    bad = __any(bad);
+    __shared__ int sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int f = sh[0] | sh[1] | sh[2] | sh[3];
+        state[0] = f;
+        state[1] += f;
+    }
+}
+__global__ void adamw_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                                     float decay_mul, float beta1, float one_m_beta1, float beta2, float one_m_beta2, float bc2_sqrt, float eps,
+                                     float neg_step_size, const int* __restrict__ state) {
+    if (state[0]) return;  // this step's gradients are not finite: skipped (uniform over the grid)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * decay_mul;
+        const float mi = m[i] * beta1 + gi * one_m_beta1;
+        const float vi = v[i] * beta2 + (one_m_beta2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi + neg_step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+extern "C" int eod_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                                      double weight_decay, int step, int* state, int* scratch, int scratch_len, void* stream) {
+    EOD_REQUIRE(p && g && m && v && n > 0 && step >= 1 && state && scratch && scratch_len >= 1, "adamw_step_guarded: bad args");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = lr / bc1;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    int cb = (int)(blocks < scratch_len ? blocks : scratch_len);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nonfinite_blocks_kernel, dim3((unsigned)cb), dim3(256), 0, st, g, (long long)n, scratch);
+    hipLaunchKernelGGL(nonfinite_fold_kernel, dim3(1), dim3(256), 0, st, (const int*)scratch, cb, state);
+    hipLaunchKernelGGL(adamw_guarded_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, (float)(1.0 - lr * weight_decay),
+                       (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-step_size),
+                       (const int*)state);
+    EOD_CHECK_LAUNCH("adamw_step_guarded");
+    return EOD_OK;
+}
+
 __global__ void ema_kernel(float* __restrict__ avg, const float* __restrict__ p, long long n, float decay, float one_m_decay) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         avg[i] = decay * avg[i] + one_m_decay * p[i];

@@ -48,8 +48,11 @@ def mse_loss(pred, target, want_grad=True):
 class AdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (decoupled weight decay, no amsgrad), one fused launch per parameter group."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, *, skip_nonfinite=True):
+        """skip_nonfinite (default on): a step whose gradients contain inf / NaN (fp16 training overflowing its static loss scale)
+        is skipped on the device -- parameters and moments stay untouched; `skipped_steps()` reads the count (one host sync)."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.skip_nonfinite = bool(skip_nonfinite)
         self._flat = []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
@@ -63,7 +66,8 @@ class AdamW(torch.optim.Optimizer):
             for p, v in zip(ps, views):
                 p.data = v  # same values, now contiguous in one buffer
             st = dict(params=ps, p=flat_p, g=torch.zeros_like(flat_p), m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), step=0,
-                      gviews=[None] * len(ps))
+                      gviews=[None] * len(ps), guard=torch.zeros((2,), dtype=torch.int32, device=dev),
+                      scratch=torch.zeros((8192,), dtype=torch.int32, device=dev))
             off = 0
             for k, p in enumerate(ps):
                 st["gviews"][k] = st["g"][off:off + p.numel()].view(p.shape)
@@ -86,14 +90,24 @@ class AdamW(torch.optim.Optimizer):
                     gv.copy_(p.grad)
             st["step"] += 1
             b1, b2 = group["betas"]
-            check(L.eod_adamw_step(ptr(st["p"]), ptr(st["g"]), ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]), float(b1),
-                                   float(b2), float(group["eps"]), float(group["weight_decay"]), st["step"], current_stream_ptr(st["p"].device)),
-                  "eod_adamw_step")
+            if self.skip_nonfinite:
+                check(L.eod_adamw_step_guarded(ptr(st["p"]), ptr(st["g"]), ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]),
+                                               float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), st["step"],
+                                               ptr(st["guard"]), ptr(st["scratch"]), 8192, current_stream_ptr(st["p"].device)),
+                      "eod_adamw_step_guarded")
+            else:
+                check(L.eod_adamw_step(ptr(st["p"]), ptr(st["g"]), ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]), float(b1),
+                                       float(b2), float(group["eps"]), float(group["weight_decay"]), st["step"], current_stream_ptr(st["p"].device)),
+                      "eod_adamw_step")
             for p, keep in untouched:  # (zero gradient -> m, v stay as they were; only the decoupled weight decay has to be undone)
                 p.detach().copy_(keep)
             for p in st["params"]:  # written through the flat buffer: advance torch's version counters (the packed-weight
                 torch.autograd.graph.increment_version(p)  # caches of the kernels key on them); no kernel is launched
         return loss
+
+    def skipped_steps(self):
+        """number of steps skipped because of non-finite gradients (host synchronisation)"""
+        return sum(int(st["guard"][1]) for st in self._flat if st is not None)
 
 
 class ExponentialMovingAverage(torch.nn.Module):

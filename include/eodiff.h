@@ -380,6 +380,12 @@ int eod_mse_loss(const float* pred, const float* target, int64_t n, float* loss,
  * fp32 buffers; `step` is the 1-based update count */
 int eod_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int step, void* stream);
+/* the same step behind an overflow guard (fp16 training with a static loss scale): if any gradient is inf / NaN the step is SKIPPED
+ * (p, m, v untouched).  state (device, 2 ints, zero-initialised by the caller once) = {this step was skipped, steps skipped so far};
+ * scratch: scratch_len (>= 1, up to 8192 used) ints.  The caller advances `step` only for steps that were applied, or accepts the
+ * slightly early bias correction.  No host synchronisation. */
+int eod_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, int step, int* state, int* scratch, int scratch_len, void* stream);
 /* EMA of script_utils/utils.py:56-67: avg = decay*avg + (1-decay)*p */
 int eod_ema_update(float* avg, const float* p, int64_t n, double decay, void* stream);
 

@@ -203,9 +203,9 @@ def test_a1_13ch_training_step_vs_oracle_autograd(prec):
             worst = (name, e)
     print(f"A1 13ch @128 training step [{prec}]: {n_checked} gradients, worst rel-L2 = {worst}")
     assert n_checked > 150
-    assert worst[1] < (2e-4 if prec == "fp32" else 4e-2), worst
+    assert worst[1] < (2e-4 if prec == "fp32" else 1e-2), worst
     for k in ("input_blocks.0.0.weight", "out.2.weight", "out.2.bias"):
-        assert rel_l2(dict(m.named_parameters())[k].grad.cpu(), gref[k]) < (2e-4 if prec == "fp32" else 4e-2), k
+        assert rel_l2(dict(m.named_parameters())[k].grad.cpu(), gref[k]) < (2e-4 if prec == "fp32" else 1e-2), k
 
 
 # ------------------------------------------------------------------------------------------------ ddpm.py rows (a21, a23-a25)

@@ -120,3 +120,29 @@ def test_out_of_range_timestep_is_loud_and_memory_safe():
     assert bits_equal(bad[0], ok[0]) and bool(torch.isnan(bad[1]).all())
     bad = model._ddpm_update(x, z, z, torch.tensor([-5, 7], device=DEV), clip=True)
     assert bool(torch.isnan(bad[0]).all()) and bool(torch.isfinite(bad[1]).all())
+
+
+def test_fused_adamw_skips_steps_with_nonfinite_gradients():
+    """fp16 training with a static loss scale: an overflowing gradient must not poison the weights -- the fused AdamW skips that
+    step on the device (parameters AND moments untouched), counts it, and carries on with the next finite one"""
+    from eo_diffusion_amd.optim import AdamW
+    ps = [torch.nn.Parameter(synth_input(f"nf_p{k}", shp, 1).to(DEV)) for k, shp in enumerate([(64, 32, 3, 3), (64,), (1000, 7)])]
+    opt = AdamW(ps, lr=1e-2)
+    ref = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-2)
+    grads = [[synth_input(f"nf_g{s}{k}", p.shape, 2).to(DEV) for k, p in enumerate(ps)] for s in range(3)]
+    for s in range(3):
+        for p, q, g in zip(ps, ref.param_groups[0]["params"], grads[s]):
+            p.grad, q.grad = g.clone(), g.clone()
+        if s == 1:
+            ps[2].grad[17, 3] = float("inf")   # this step overflows
+            before = [p.detach().clone() for p in ps]
+            opt.step()
+            assert all(bits_equal(p.detach(), b) for p, b in zip(ps, before))
+            continue
+        opt.step()
+        ref.step()
+    assert opt.skipped_steps() == 1
+    # two applied steps; the fused optimizer's step counter also advanced on the skipped one (documented: slightly early bias correction)
+    for p, q in zip(ps, ref.param_groups[0]["params"]):
+        assert torch.allclose(p.detach(), q.detach(), rtol=2e-2, atol=2e-3)
+        assert bool(torch.isfinite(p).all())

@@ -11,7 +11,7 @@ from tests.synth import synth_input, synth_state_dict
 pytestmark = pytest.mark.gpu
 
 # gradient tolerances (rel-L2 per parameter tensor, vs fp32 autograd on the CPU)
-GTOL = {"fp32": 2e-4, "fp16": 4e-2}
+GTOL = {"fp32": 2e-4, "fp16": 1e-2}  # (observed worst over all cases below: fp32 2.4e-6; fp16 passes at 1e-2)
 
 
 def _setup(prec, size, base, mults, nrb, N, in_ch=3, attn=(), heads=1, extra=None):
