@@ -82,21 +82,44 @@ class AdamW(torch.optim.Optimizer):
             if st is None:
                 continue
             untouched = []  # torch.optim.AdamW skips parameters without a gradient (no decay, no state update): keep their values
-            for p, gv in zip(st["params"], st["gviews"]):
-                if p.grad is None:
-                    gv.zero_()
-                    untouched.append((p, p.detach().clone()))
-                elif p.grad.data_ptr() != gv.data_ptr():
-                    gv.copy_(p.grad)
+            # Fast path: the gradients already lie in ONE flat buffer with this optimizer's own layout (UNetTrainer.flat_grad: same
+            # parameter order, same 16-byte-aligned offsets) -> the kernel reads it in place, no per-tensor copies.
+            gptr, base, off = ptr(st["g"]), None, 0
+            in_place = True
+            for p in st["params"]:
+                if p.grad is not None:
+                    b = p.grad.data_ptr() - 4 * off
+                    if base is None:
+                        base = b
+                    in_place = in_place and b == base and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+                off += (p.numel() + 3) // 4 * 4
+            if in_place and base is not None and base % 16 == 0:
+                owner = next(p.grad for p in st["params"] if p.grad is not None)
+                in_place = owner.untyped_storage().data_ptr() <= base and \
+                    base + 4 * st["p"].numel() <= owner.untyped_storage().data_ptr() + owner.untyped_storage().nbytes()
+            else:
+                in_place = False
+            if in_place:
+                gptr = base
+                for p in st["params"]:
+                    if p.grad is None:  # (its slice of the flat buffer is never written by the backward: zeros)
+                        untouched.append((p, p.detach().clone()))
+            else:
+                for p, gv in zip(st["params"], st["gviews"]):
+                    if p.grad is None:
+                        gv.zero_()
+                        untouched.append((p, p.detach().clone()))
+                    elif p.grad.data_ptr() != gv.data_ptr():
+                        gv.copy_(p.grad)
             st["step"] += 1
             b1, b2 = group["betas"]
             if self.skip_nonfinite:
-                check(L.eod_adamw_step_guarded(ptr(st["p"]), ptr(st["g"]), ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]),
+                check(L.eod_adamw_step_guarded(ptr(st["p"]), gptr, ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]),
                                                float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), st["step"],
                                                ptr(st["guard"]), ptr(st["scratch"]), 8192, current_stream_ptr(st["p"].device)),
                       "eod_adamw_step_guarded")
             else:
-                check(L.eod_adamw_step(ptr(st["p"]), ptr(st["g"]), ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]), float(b1),
+                check(L.eod_adamw_step(ptr(st["p"]), gptr, ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]), float(b1),
                                        float(b2), float(group["eps"]), float(group["weight_decay"]), st["step"], current_stream_ptr(st["p"].device)),
                       "eod_adamw_step")
             for p, keep in untouched:  # (zero gradient -> m, v stay as they were; only the decoupled weight decay has to be undone)
