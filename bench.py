@@ -43,8 +43,8 @@ ARCHS = {
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  fp32x3 issues fp16 MFMAs (three per algorithmic product), so it is
 # priced against the fp16 matrix peak: `frac` = ALGORITHMIC flops / 2.5 PFLOP/s can reach at most 1/3.
 PEAK = {"fp32": 157.3e12, "fp32x3": 2.5e15, "fp16": 2.5e15}
-PEAK_NOTE = {"fp32x3": "fp32 storage; each product = 3 v_mfma_f32_32x32x16_f16 on split (hi + lo) operands, so the ceiling of frac "
-                       "(algorithmic flops / fp16 MFMA peak) is 1/3; executed MFMA flops = 3 x achieved"}
+PEAK_NOTE = {"fp32x3": "fp32 storage; each product = 3 fp16 MFMAs (v_mfma_f32_16x16x32_f16) on split (hi + lo) operands, so the ceiling "
+                       "of frac (algorithmic flops / fp16 MFMA peak) is 1/3; executed MFMA flops = 3 x achieved"}
 DTYPE_NAME = {"fp32": "f32", "fp32x3": "f32", "fp16": "f16"}
 TOLERANCE = {"fp32": "rel-L2 <= 1e-5 per UNet forward vs the fp32 CPU oracle (fp32 storage, exact fp32 MFMA)",
              "fp32x3": "rel-L2 <= 1e-5 per UNet forward vs the fp32 CPU oracle -- the SAME gate as the exact-fp32 mode (fp32 storage; "

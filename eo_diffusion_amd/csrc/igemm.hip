@@ -438,15 +438,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     }
 }
 
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmP p) {
     static_assert(!SPLIT || (sizeof(T) == 4 && CONV && STAGES == 2), "split-fp16 product: fp32 conv, 2-stage ring");
+    static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only (see conv3x3_halo_kernel)");
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
     constexpr int BKB = 128;       // bytes of K per row per K-step
     constexpr int BK = BKB / ES;   // elements per K-step
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int TM = WM / MS, TN = WN / MS;
     constexpr int NW = WAVES_M * WAVES_N;                // waves per workgroup (4 or 8)
     constexpr int GA = BM / 8, GB = BN / 8;              // 8-row groups (one LDS-DMA instruction each)
     constexpr int LA = GA / NW, LB = GB / NW;            // groups per wave
@@ -655,16 +656,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         for (int i = 0; i < LB; ++i) issue_b(i, sbase);
     };
 
-    f32x16 acc[TM][TN];
+    typename AccLayout<MS>::vec acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < AccLayout<MS>::R; ++r) acc[i][j][r] = 0.0f;
 
-    // ---- fragment read offsets: row (wm*WM + i*32 + lr), chunk (2s + lh) ^ ((row>>1)&7) ----
-    const int lr = lane & 31, lh = lane >> 5;
+    // ---- fragment read offsets: row (wm*WM + i*MS + lr), chunk (2s + lh) ^ ((row>>1)&7) ----
+    const int lr = lane & (MS - 1), lh = MS == 32 ? lane >> 5 : lane >> 4;
     const int sw = (lr >> 1) & 7;  // (row>>1)&7 == (lr>>1)&7: the wave / tile row offsets are multiples of 16
     int coff[4];
 #pragma unroll
@@ -707,7 +708,53 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         // (issuing the DMA instructions one by one between the MFMA sub-steps was measured: no gain, -5..10 %)
         if (kt + STAGES - 1 < KT) issue_loads((kt + STAGES - 1) % STAGES);
         const char* sb = smem + (kt % STAGES) * STAGE;
-        if constexpr (SPLIT) {
+        if constexpr (MS == 16 && SPLIT) {
+            // one 16x16x32 sub-step per K-step; lane quarter lh supplies chunk pair {0, 3, 1, 2}[lh] (see conv3x3_halo_kernel)
+            const int ch = 2 * ((0x2130 >> (4 * lh)) & 3);
+            const int ohi = (ch ^ sw) * 16, olo = ((ch + 1) ^ sw) * 16;
+            i32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * MS * BKB + olo);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * MS * BKB + ohi);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * MS * BKB + ohi);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * MS * BKB + olo);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+            continue;
+        } else if constexpr (MS == 16) {
+            // fp16: two 16x16x32 sub-steps per K-step, lane quarter lh of sub-step s reads chunk 4 s + lh
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int o = ((4 * s + lh) ^ sw) * 16;
+                i32x4 fa16[TM], fb16[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa16[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * MS * BKB + o);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb16[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * MS * BKB + o);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa16[i]), __builtin_bit_cast(half8, fb16[j]), acc[i][j], 0, 0, 0);
+            }
+            continue;
+        } else if constexpr (SPLIT) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int ch = 2 * (2 * s + lh);
@@ -738,6 +785,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             }
             continue;
         }
+        if constexpr (MS == 32) {
         // fragments are read one sub-step ahead of their MFMAs and the {ds_read group, MFMA group} order is pinned
         // (see conv3x3_halo_kernel): +5 % over hipcc's own read-then-wait schedule
         i32x4 fa[2][TM], fb[2][TN];
@@ -762,17 +810,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                 for (int j = 0; j < TN; ++j) Mma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
         }
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my fragment reads are done ...
     __builtin_amdgcn_s_barrier();        // ... and so are everybody else's: the ring can be reused by the epilogue
 
     if constexpr (sizeof(T) == 4) {
-        igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(pe, g, acc, smem, wave, lane, n0);
+        igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0);
     } else {
         if (CONV ? p.splitk > 1 : p.c_f32 != 0)
-            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true>(pe, g, acc, smem, wave, lane, n0);
+            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0);
         else
-            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, false>(pe, g, acc, smem, wave, lane, n0);
+            igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, false, MS>(pe, g, acc, smem, wave, lane, n0);
     }
 }
 
@@ -1230,14 +1279,14 @@ static int igemm_forced_cfg() {
     return v;
 }
 
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32>
 static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, NW = WAVES_M * WAVES_N;
     const size_t ring = STAGES * (size_t)(BM + BN) * 128;
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES, SPLIT>;
+    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES, SPLIT, MS>;
     static bool attr_done = false;  // >64 KiB dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1316,6 +1365,13 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
 }
 
 template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (halo_mfma_shape() == 16 && p.force_cfg != 2) {  // fp16 products on v_mfma_f32_16x16x32_f16
+            if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2, false, 16>(p, batch, st);
+            if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2, false, 16>(p, batch, st);
+            return launch_cfg<T, CONV, 128, 128, 2, 2, 2, false, 16>(p, batch, st);
+        }
+    }
     if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2>(p, batch, st);
     if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2>(p, batch, st);
     // 256x128 tile / 8 waves / 3-stage ring (144 KiB LDS, one workgroup per CU, DMA prefetched 2 K-steps deep) is kept
@@ -1326,6 +1382,11 @@ template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipSt
 
 // fp32 conv as the split-fp16 product on the generic kernel (1x1, stride 2, ragged maps)
 static int launch_conv_split(IgemmP& p, int batch, hipStream_t st) {
+    if (halo_mfma_shape() == 16) {
+        if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true, 16>(p, batch, st);
+        if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true, 16>(p, batch, st);
+        return launch_cfg<float, true, 128, 128, 2, 2, 2, true, 16>(p, batch, st);
+    }
     if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true>(p, batch, st);
     if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true>(p, batch, st);
     return launch_cfg<float, true, 128, 128, 2, 2, 2, true>(p, batch, st);
