@@ -370,13 +370,37 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int P, in
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cpg = Ctot / groups, c0 = g * cpg;
     const double mean = (double)mr[((long long)n * groups + g) * 2 + 0], rstd = (double)mr[((long long)n * groups + g) * 2 + 1];
+    // per-channel slab sums A_c, B_c: the 256 threads are cpg channels x nseg slab segments (a lone thread per channel walking
+    // all P slabs took 45 us per launch); partial sums meet in LDS and are combined in a fixed order
+    const int nseg = cpg <= 256 ? 256 / cpg : 1;
+    {
+        const int cl = tid % cpg, sg = tid / cpg;
+        double A = 0.0, B = 0.0;
+        if (sg < nseg && cpg <= 256) {
+            for (int p = sg; p < P; p += nseg) {
+                const float* pp = part + (((long long)n * P + p) * Ctot + c0 + cl) * 2;
+                A += (double)pp[0];
+                B += (double)pp[1];
+            }
+        }
+        r1[tid] = A;
+        r2[tid] = B;
+    }
+    __syncthreads();
     double s1 = 0.0, s2 = 0.0;
     for (int c = c0 + tid; c < c0 + cpg; c += 256) {
         double A = 0.0, B = 0.0;
-        for (int p = 0; p < P; ++p) {
-            const float* pp = part + (((long long)n * P + p) * Ctot + c) * 2;
-            A += (double)pp[0];
-            B += (double)pp[1];
+        if (cpg <= 256) {
+            for (int k = 0; k < nseg; ++k) {
+                A += r1[k * cpg + (c - c0)];
+                B += r2[k * cpg + (c - c0)];
+            }
+        } else {
+            for (int p = 0; p < P; ++p) {
+                const float* pp = part + (((long long)n * P + p) * Ctot + c) * 2;
+                A += (double)pp[0];
+                B += (double)pp[1];
+            }
         }
         const double bh = rstd * (B - mean * A);  // sum dy * xh
         const double fs = film ? 1.0 + (double)film[(long long)n * film_stride + c] : 1.0;
@@ -390,6 +414,7 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int P, in
         s1 += ge * A;
         s2 += ge * bh;
     }
+    __syncthreads();  // (the slab partials in r1 / r2 have been consumed)
     r1[tid] = s1;
     r2[tid] = s2;
     __syncthreads();
@@ -1141,22 +1166,34 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
 // produces per-(image, slab, channel) sums  part[n][p][c][0];  this reduces them:
 //   dbias[c] = scale * sum_{n,p} part[n][p][c][0],   demb[n][c] = sum_p part[n][p][c][0]   (fixed order)
 // ---------------------------------------------------------------------------------------------
-__global__ void channel_sums_finish_kernel(const float* __restrict__ part, int N, int P, int C, int cvalid, float scale, float* __restrict__ pern,
-                                           float* __restrict__ demb, long long demb_ld) {
-    // grid (channel blocks, N): one image per block row; per-image totals go to pern[n][c] (scaled) for the bias gradient
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
-    if (c >= cvalid) return;
+__global__ __launch_bounds__(512) void channel_sums_finish_kernel(const float* __restrict__ part, int N, int P, int C, int cvalid, float scale,
+                                                                  float* __restrict__ pern, float* __restrict__ demb, long long demb_ld) {
+    // grid (64-channel blocks, N): one image per block row.  512 threads = 64 channels x 8 slab segments: every thread sums its
+    // contiguous share of the P slabs, the 8 partial sums of a channel are then combined in a FIXED order (deterministic);
+    // per-image totals go to pern[n][c] (scaled) for the bias gradient
+    __shared__ float seg[8][64];
+    const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+    const int per = (P + 7) / 8, p0 = sg * per, p1 = min(P, p0 + per);
     float a = 0.0f;
-    for (int p = 0; p < P; ++p) a += part[(((long long)n * P + p) * C + c) * 2];
-    if (demb) demb[(long long)n * demb_ld + c] = a;
-    if (pern) pern[(long long)n * cvalid + c] = a * scale;
+    if (c < cvalid)
+        for (int p = p0; p < p1; ++p) a += part[(((long long)n * P + p) * C + c) * 2];
+    seg[sg][cl] = a;
+    __syncthreads();
+    if (sg == 0 && c < cvalid) {
+        float t = seg[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += seg[k][cl];
+        if (demb) demb[(long long)n * demb_ld + c] = t;
+        if (pern) pern[(long long)n * cvalid + c] = t * scale;
+    }
 }
 
 extern "C" int eod_channel_sums_finish(const float* part, int N, int P, int C, int cvalid, float scale, float* dbias, float* demb,
                                        int64_t demb_ld, float* scratch, void* stream) {
     EOD_REQUIRE(part && N > 0 && P > 0 && C > 0 && cvalid > 0 && cvalid <= C && (dbias || demb) && N <= 65535, "channel_sums_finish: bad args");
     EOD_REQUIRE(!dbias || scratch, "channel_sums_finish: the bias gradient needs a scratch of N*cvalid floats");
-    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((cvalid + 63) / 64, N), dim3(64), 0, (hipStream_t)stream, part, N, P, C, cvalid, scale,
+    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((cvalid + 63) / 64, N), dim3(512), 0, (hipStream_t)stream, part, N, P, C, cvalid, scale,
                        dbias ? scratch : nullptr, demb, (long long)demb_ld);
     if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3((cvalid + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, N, cvalid, dbias);
     EOD_CHECK_LAUNCH("channel_sums_finish");
