@@ -43,6 +43,14 @@ class AttnDesc(C.Structure):
                 ("C", i32), ("heads", i32), ("d", i32), ("dpad", i32), ("k_off", i32)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", vp), ("dst", vp), ("kind", i32), ("Cout", i32), ("Cin", i32), ("taps", i32), ("ci0", i32), ("nci", i32),
+                ("cpad", i32), ("_pad", i32)]
+
+
+PACK_CHUNK = 4096
+
+
 class SmallDesc(C.Structure):
     _fields_ = [("p", vp * 6), ("l", i64 * 4), ("i", i32 * 10), ("f", f32 * 2)]
 
@@ -67,6 +75,7 @@ SYMBOLS = {
     "eod_conv_tapmajor_ldk": (i32, [i32, i32]),
     # training path (csrc/train.hip)
     "eod_pack_conv_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eod_pack_jobs": (i32, [vp, vp, vp, i32, i32, vp]),
     "eod_transpose_gather": (i32, [vp, i32, i32, i32, i32, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_rowsum_segments": (i32, [vp, i32, i32, i64, i32, i64, f32, vp, i64, vp]),
     "eod_colsum": (i32, [vp, i32, i32, vp, vp]),

@@ -59,6 +59,50 @@ extern "C" int eod_pack_conv_weight_dgrad(const float* w, void* dst, int dtype, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// All weight re-packs of a training step in ONE launch.  The optimizer changes every parameter every step, so the forward
+// ([tap][Cout][cin_pad]) and backward-data ([taps-1-tap][ci][cout_pad]) packings of every conv are refreshed before each
+// forward: ~200 tiny launches (1.5 ms at A0) become one.  The host cuts each job into blocks of EOD_PACK_CHUNK elements once
+// (blk_job[b] = job of block b, blk_first[b] = its first destination element).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const eod_pack_job* __restrict__ jobs, const int* __restrict__ blk_job,
+                                                        const long long* __restrict__ blk_first) {
+    const eod_pack_job j = jobs[blk_job[blockIdx.x]];
+    const long long total = (long long)j.taps * (j.kind ? (long long)j.nci * j.cpad : (long long)j.Cout * j.cpad);
+    const long long i0 = blk_first[blockIdx.x];
+    const float* __restrict__ w = j.w;
+    T* __restrict__ dst = reinterpret_cast<T*>(j.dst);
+    // (32-bit index arithmetic: a job has < 2^31 destination elements -- checked on the host side of the conv kernels -- and 64-bit
+    //  divisions per element would dominate this kernel)
+    const unsigned cpad = (unsigned)j.cpad, rows = (unsigned)(j.kind ? j.nci : j.Cout), utotal = (unsigned)total;
+#pragma unroll 4
+    for (int k = 0; k < EOD_PACK_CHUNK / 256; ++k) {
+        const unsigned i = (unsigned)i0 + k * 256 + threadIdx.x;
+        if (i >= utotal) break;
+        const unsigned r = i / cpad, c = i - r * cpad;   // c: fastest destination index (ci for kind 0, co for kind 1)
+        const unsigned t = r / rows, m = r - t * rows;   // m: co (kind 0) / ci (kind 1); t: destination tap slot
+        float v;
+        if (j.kind == 0) {
+            v = (int)c < j.Cin ? w[((long long)m * j.Cin + c) * j.taps + t] : 0.0f;
+        } else {
+            v = (int)c < j.Cout ? w[((long long)c * j.Cin + j.ci0 + m) * j.taps + (j.taps - 1 - t)] : 0.0f;
+        }
+        dst[i] = cvt_to<T>(v);
+    }
+}
+
+extern "C" int eod_pack_jobs(const eod_pack_job* jobs, const int32_t* blk_job, const int64_t* blk_first, int nblocks, int dtype, void* stream) {
+    EOD_REQUIRE(jobs && blk_job && blk_first && nblocks > 0, "pack_jobs: bad args");
+    EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "pack_jobs: bad dtype %d", dtype);
+    if (dtype == EOD_F16)
+        hipLaunchKernelGGL(pack_jobs_kernel<half_t>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, jobs, blk_job, (const long long*)blk_first);
+    else
+        hipLaunchKernelGGL(pack_jobs_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, jobs, blk_job, (const long long*)blk_first);
+    EOD_CHECK_LAUNCH("pack_jobs");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // transpose + gather: NHWC [N][H][W][C] -> [C][K],  K = N * (Ho + 2*rp) * Wo (+ nothing else), element
 //   dst[c][(n*(Ho+2rp) + ho + rp)*Wo + wo] = src[n][hi][wi][c],  (hi, wi) = (ho*stride - pad + dy, wo*stride - pad + dx),
 //   with ups: (hi >> 1, wi >> 1) of the stored half-resolution tensor; zero outside the image and in the rp pad rows.

@@ -19,7 +19,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ._lib import OP_DROPOUT, OP_TRANSPOSE, EodError, check, ptr
+from ._lib import OP_DROPOUT, OP_TRANSPOSE, PACK_CHUNK, EodError, PackJob, check, ptr
 from .engine import Act, Program, current_stream_ptr, round_up
 
 
@@ -100,7 +100,8 @@ class UNetTrainer:
         self.bwd = []        # backward launches in execution order: ("op", Op) | ("call", fn, args)
         self.contrib = {}    # id(Act) -> [Act, ...] gradient contributions
         self.pgrad = {}      # Parameter -> fp32 gradient tensor
-        self.repack = []     # closures refreshing packed weights from the (updated) parameters
+        self.repack = []     # closures refreshing derived tensors from the (updated) parameters (timestep-MLP concatenations)
+        self.pack_jobs = []  # weight re-packs (forward and backward-data layouts of every conv): ONE launch per forward
         self.recs = []
         self._keep = []
         self._scratch, self._scratch_all = {}, []
@@ -219,7 +220,7 @@ class UNetTrainer:
     def _conv_fwd(self, srcs, conv, *, ksize=3, stride=1, upsample=False, res=None, emb=None, stats=True, src_needs_grad=True):
         prog = self.prog
         w = prog.pack_conv(conv.weight)
-        self.repack.append(lambda w=w, conv=conv: self._repack_conv(w, conv))
+        self._add_pack_job(0, conv, w)
         kw = {}
         if emb is not None:
             kw = dict(cbias=emb[0], cbias_stride=emb[1])
@@ -229,12 +230,33 @@ class UNetTrainer:
                                   src_needs_grad=src_needs_grad))
         return y
 
-    def _repack_conv(self, dst, conv, cin_pad=None):
+    def _add_pack_job(self, kind, conv, dst, cpad=None, ci0=0, nci=0):
+        """kind 0: forward packing [tap][Cout][cpad = cin_pad]; kind 1: backward-data packing of input channels [ci0, ci0 + nci)
+        [taps-1-tap][ci][cpad = cout_pad] (eod_pack_jobs)"""
         w = conv.weight.detach()
-        cout, cin = w.shape[0], w.shape[1]
-        ks = w.shape[2]
-        check(self.L.eod_pack_conv_weight(ptr(w), ptr(dst), self.dt, cout, cin, ks, cin_pad or cin, current_stream_ptr(self.device)),
-              "pack_conv_weight")
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        j = PackJob()
+        j.w, j.dst, j.kind, j.Cout, j.Cin, j.taps = ptr(w), ptr(dst), kind, cout, cin, ks * ks
+        j.ci0, j.nci, j.cpad = ci0, nci, (cpad or (cin if kind == 0 else cout))
+        self.pack_jobs.append(j)
+
+    def _finish_pack_jobs(self):
+        n = len(self.pack_jobs)
+        arr = (PackJob * n)(*self.pack_jobs)
+        blk_job, blk_first = [], []
+        for k, j in enumerate(self.pack_jobs):
+            total = j.taps * (j.nci * j.cpad if j.kind else j.Cout * j.cpad)
+            for first in range(0, total, PACK_CHUNK):
+                blk_job.append(k)
+                blk_first.append(first)
+        self._pack_tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self._pack_blk_job = torch.tensor(blk_job, dtype=torch.int32, device=self.device)
+        self._pack_blk_first = torch.tensor(blk_first, dtype=torch.int64, device=self.device)
+        self._pack_nblocks = len(blk_job)
+
+    def _run_pack_jobs(self):
+        check(self.L.eod_pack_jobs(ptr(self._pack_tab), ptr(self._pack_blk_job), ptr(self._pack_blk_first), self._pack_nblocks, self.dt,
+                                   current_stream_ptr(self.device)), "eod_pack_jobs")
 
     def _gn_fwd(self, srcs, gn, silu=True, film=None):
         prog = self.prog
@@ -472,7 +494,7 @@ class UNetTrainer:
         # ---- encoder / middle / decoder ----
         conv0 = unet.input_blocks[0][0]
         w0 = prog.pack_conv(conv0.weight, cin_pad=c_pad)
-        self.repack.append(lambda: self._repack_conv(w0, conv0, c_pad))
+        self._add_pack_job(0, conv0, w0, cpad=c_pad)
         h, _ = prog.conv(a0, w0, prog.f32(conv0.bias), conv0.out_channels, stats=True)
         self.recs.append(_ConvRec([a0], conv0, h, src_needs_grad=False))
         hs = [h]
@@ -488,13 +510,14 @@ class UNetTrainer:
         self.cout = unet.out_channels
         self.cout_pad = round_up(self.cout, prog.epc)
         wh = prog.pack_conv(conv.weight)
-        self.repack.append(lambda: self._repack_conv(wh, conv))
+        self._add_pack_job(0, conv, wh)
         self.pred = torch.empty((N, self.cout, H, W), dtype=torch.float32, device=self.device)
         _, i_out = prog.conv(a, wh, prog.f32(conv.bias), self.cout, out_nchw_f32=True)
         prog.ops[i_out].u.conv.y = self.pred.data_ptr()
         self.head = (a, conv)
         prog.finalize()
         self._build_backward()
+        self._finish_pack_jobs()
 
     def _refresh_cat(self):
         torch.cat([b.emb_layers[1].weight.detach().float() for b in self.ctx.blocks], 0, out=self.wcat)
@@ -675,11 +698,7 @@ class UNetTrainer:
         for xs in rec.srcs:
             cs = xs.C
             wd = bp.empty((ks * ks, cs, dy.C))
-            pack = (lambda wd=wd, ci0=ci0, cs=cs: check(L.eod_pack_conv_weight_dgrad(
-                ptr(conv.weight.detach()), ptr(wd), dt, conv.out_channels, cin_total, ks, ci0, cs, dy.C, current_stream_ptr(self.device)),
-                "pack_conv_weight_dgrad"))
-            pack()
-            self.repack.append(pack)
+            self._add_pack_job(1, conv, wd, cpad=dy.C, ci0=ci0, nci=cs)
             odd = stride == 2 and ((xs.H % 2) or (xs.W % 2))  # stride-2 conv of an odd map (unet_openai.py:262-264, e.g. 7 -> 4)
             prev = None if (rec.upsample or odd) else self._pop_single(xs)
             g, _ = self._bop(lambda: bp.conv(dy, wd, None, cs, ksize=ks, stride=1, pad=ks // 2, upsample=(2 if stride == 2 else False),
@@ -786,6 +805,7 @@ class UNetTrainer:
             raise EodError("UNetTrainer: the UNet's parameter storage moved after this trainer was built (optimizer flat buffer, "
                            ".to(), load_state_dict(assign=True)); build the optimizer first or create a new UNetTrainer")
         self.step_id += 1
+        self._run_pack_jobs()
         for fn in self.repack:
             fn()
         self._x = x.contiguous().float()

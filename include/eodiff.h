@@ -301,6 +301,16 @@ int eod_resample2x(const void* x, int dtype, int N, int H, int W, int C, int mod
 /* OIHW fp32 -> [taps-1-tap][ci - ci0][cout_pad]: packed weights of the conv dY -> dX[:, ci0:ci0+nci] */
 int eod_pack_conv_weight_dgrad(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int ksize, int ci0, int nci,
                                int cout_pad, void* stream);
+/* every weight re-pack of a training step in one launch: jobs (device array) of kind 0 = eod_pack_conv_weight (cpad = cin_pad) or
+ * kind 1 = eod_pack_conv_weight_dgrad (cpad = cout_pad); the caller cuts each job's destination into blocks of EOD_PACK_CHUNK
+ * elements: blk_job[b] = job index, blk_first[b] = first destination element of block b (device arrays, nblocks entries) */
+#define EOD_PACK_CHUNK 4096
+typedef struct {
+    const float* w;  /* OIHW fp32 parameter */
+    void* dst;       /* packed destination, storage dtype */
+    int32_t kind, Cout, Cin, taps, ci0, nci, cpad, _pad;
+} eod_pack_job;
+int eod_pack_jobs(const eod_pack_job* jobs, const int32_t* blk_job, const int64_t* blk_first, int nblocks, int dtype, void* stream);
 /* NHWC [N][H][W][C] -> [C][ld_dst], column k = (n*(Ho+2*row_pad) + ho + row_pad)*Wo + wo holds
  * src[n][ho*stride - pad + dy][wo*stride - pad + dx][c] (ups: of the nearest-2x image), zero outside / in pad rows */
 int eod_transpose_gather(const void* src, int dtype, int N, int H, int W, int C, void* dst, int64_t ld_dst, int Ho, int Wo,
