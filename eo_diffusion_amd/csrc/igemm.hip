@@ -104,7 +104,11 @@ template <> struct Mma<float> {
 // 2 MFMA sub-steps; lane half h of sub-step s reads pair 2s+h: hi at chunk 2(2s+h), lo at chunk 2(2s+h)+1 -- the same
 // ds_read_b128 / XOR-swizzle machinery as the other modes, 16 reads and 24 MFMAs per K-step and wave.
 // Measured and rejected here (A/B on MI355X, tools/conv_bench.py): reading both sub-steps' fragments ahead of the MFMAs (two register
-// sets, pinned order; 246-256 VGPRs): -1..-3 %; rewriting the patch piece before instead of after a step's MFMAs: +-0.
+// sets, pinned order; 246-256 VGPRs): -1..-3 %; rewriting the patch piece before instead of after a step's MFMAs: +-0; an 8-wave
+// 16x16-pixel tile with a 3-stage weight ring (half the weight DMA per MFMA) on 16x16x32: +-1 %; a pixel permutation inside the
+// 16-row MFMA blocks that makes the patch reads bank-conflict free (PMC: SQ_LDS_BANK_CONFLICT 26 % -> 1 % of LDS_IDX_ACTIVE):
+// fp16 +-0 (LDS is not the limiter), fp32x3 -13 % (57-62 spilled VGPRs).  PMC of the split kernel (tools/pmc_stall.txt): waves are
+// 32 % issuing, 44 % stalled on issue (the matrix pipe shared by two waves), 24 % parked at s_waitcnt / s_barrier.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define EOD_SPLIT_ASCALE 16.0f
 __device__ __forceinline__ void mma_f16(const i32x4& a, const i32x4& b, f32x16& c) {
