@@ -166,6 +166,25 @@ def cpu_baseline(arch, size, batch, seconds_budget=25.0):
     return out
 
 
+def parity_probe(m, arch, size):
+    """In-run evidence that the timed precision mode computes the reference's function: ONE UNet forward of the benchmarked model at
+    the metric's image size (batch 2, t = [999, 3], fixed inputs) against the CPU oracle evaluated on the SAME weights.  The oracle
+    is the checker here, never the thing timed (its cost: two 256x256 images, ~4 s on the host cores)."""
+    from oracle import unet_ref
+    dev = next(m.parameters()).device
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 3, size, size), generator=g)
+    t = torch.tensor([999, 3])
+    cfg = dict(image_size=size, in_channels=3, out_channels=3, **ARCHS[arch])
+    with torch.no_grad():
+        got = m.model(x.to(dev), t.to(dev)).float().cpu()
+        sd = {k: v.detach().float().cpu() for k, v in m.model.state_dict().items()}
+        ref = unet_ref.unet_forward(sd, cfg, x, t)
+    err = float((got.double() - ref.double()).norm() / ref.double().norm())
+    return {"rel_l2_vs_cpu_oracle": err, "what": f"UNet forward, {size}x{size}, batch 2, t = [999, 3], same weights, precision mode "
+            f"{m.model.precision}", "probe_output": got}
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -344,6 +363,12 @@ def main():
         args.no_op_timing = True  # the event-bracketing executor cannot be captured
     dt, x_t, roof = time_sampling(args, m, dev, rank, world, use_dist, dist)
     finite = bool(torch.isfinite(x_t).all())
+    parity = None
+    if not stub and world == 1 and not args.no_cpu_baseline and not args.graph:
+        try:
+            parity = parity_probe(m, args.arch, S)
+        except Exception as e:  # the measurement stands on its own; say why the probe is missing
+            parity = {"error": repr(e)}
 
     secondary = {}
     if not stub and not args.no_secondary:
@@ -355,9 +380,16 @@ def main():
             torch.cuda.empty_cache()
             m2 = build_model(args.arch, S, prec, dev)
             dt2, x2, roof2 = time_sampling(args, m2, dev, rank, world, use_dist, dist)
-            secondary[{"fp32": "fp32_exact_mfma", "fp16": "fp16"}[prec]] = {
-                "value": world * args.steps / dt2, "unit": "steps/s", "ms_per_step": dt2 / args.steps * 1e3, "dtype": DTYPE_NAME[prec],
-                "precision_mode": prec, "tolerance": TOLERANCE[prec], "outputs_finite": bool(torch.isfinite(x2).all()), "roofline": roof2}
+            entry = {"value": world * args.steps / dt2, "unit": "steps/s", "ms_per_step": dt2 / args.steps * 1e3, "dtype": DTYPE_NAME[prec],
+                     "precision_mode": prec, "tolerance": TOLERANCE[prec], "outputs_finite": bool(torch.isfinite(x2).all()), "roofline": roof2}
+            if parity and "probe_output" in parity:  # same seed -> same weights: how far is this mode from the headline mode's output?
+                with torch.no_grad():
+                    g = torch.Generator().manual_seed(11)
+                    xp = torch.randn((2, 3, S, S), generator=g).to(dev)
+                    o2 = m2.model(xp, torch.tensor([999, 3], device=dev)).float().cpu()
+                ref = parity["probe_output"]
+                entry["rel_l2_vs_headline_mode_output"] = float((o2.double() - ref.double()).norm() / ref.double().norm())
+            secondary[{"fp32": "fp32_exact_mfma", "fp16": "fp16"}[prec]] = entry
             del m2, x2
 
     if rank == 0:
@@ -377,6 +409,9 @@ def main():
         }
         if stub:
             res["stub"] = True
+        if parity:
+            parity.pop("probe_output", None)
+            res["parity_probe"] = parity
         if roof:
             res["roofline"] = roof
         res.update(secondary)
