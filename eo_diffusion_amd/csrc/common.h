@@ -65,3 +65,24 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float v) {
         return v / (1.0f + expf(-v));
     }
 }
+
+// Slab decomposition shared by the streaming GroupNorm passes (gn_apply in norm.hip, the backward apply in train.hip): block =
+// (cpp = C / EPC chunk columns, ry pixel rows), thread (tx, ty) owns ONE 16-byte channel chunk for its whole slab, so the
+// per-channel tables live in registers (no per-chunk table loads, no 64-bit index divisions) and consecutive threads still cover
+// consecutive chunks of consecutive pixels.  U pixels per thread are in flight per trip.
+struct GnSlab {
+    int cpp, ry, per, P;
+};
+static inline GnSlab gn_slab(int N, int HW, int C, int epc, int unroll) {
+    GnSlab g;
+    g.cpp = C / epc;
+    g.ry = 256 / g.cpp;
+    if (g.ry < 1) g.ry = 1;
+    const int quantum = g.ry * unroll;
+    long long want = (4096 + N - 1) / N;  // ~16 workgroups per CU over the batch
+    long long per = (HW + want - 1) / want;
+    per = (per + quantum - 1) / quantum * quantum;
+    g.per = (int)per;
+    g.P = (int)((HW + per - 1) / per);
+    return g;
+}

@@ -70,6 +70,12 @@ struct IgemmP {
     int force_cfg; // 0 auto, 1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage (EOD_IGEMM_CFG, tuning only)
     float alpha;
     const float* w_scale;  // split-fp16 mode: device {s, 1/(s*A_SCALE)} of the packed weights (eod_pack_conv_weight_split)
+    // row-decode grid: the M axis enumerates (image, Hd x Wd) positions.  Normally that is the output map (Hd = Ho, Wd = Wo).  Parity
+    // mode (par = 1; zero-insertion upsampling = the backward-data of a stride-2 conv): one launch per output parity class (par_y,
+    // par_x), rows enumerate the (Ho/2) x (Wo/2) positions of that class, output pixel = (2 hd + par_y, 2 wd + par_x), and the K loop
+    // walks only the taps that meet stored (even) input positions for that class: taplist holds them, 4 bits each, `taps` of them.
+    int Hd, Wd, HWd, par, par_y, par_x;
+    unsigned taplist;
 };
 
 template <typename T> struct Mma;
@@ -161,16 +167,24 @@ __device__ __forceinline__ bool decode_row(const IgemmP& p, const TileGeom& g, i
         nrel = 0;
         ho = g.ty0 + (r >> p.tw_log2);
         wo = g.tx0 + (r & ((1 << p.tw_log2) - 1));
+        if (p.par) {
+            ho = 2 * ho + p.par_y;
+            wo = 2 * wo + p.par_x;
+        }
         return true;
     }
     int rem = g.rem_first + r;
     nrel = 0;
-    if (rem >= p.HoWo) {  // a tile may straddle images (or span several when the map is tiny)
-        nrel = rem / p.HoWo;
-        rem -= nrel * p.HoWo;
+    if (rem >= p.HWd) {  // a tile may straddle images (or span several when the map is tiny)
+        nrel = rem / p.HWd;
+        rem -= nrel * p.HWd;
     }
-    ho = rem / p.Wo;
-    wo = rem - ho * p.Wo;
+    ho = rem / p.Wd;
+    wo = rem - ho * p.Wd;
+    if (p.par) {
+        ho = 2 * ho + p.par_y;
+        wo = 2 * wo + p.par_x;
+    }
     return (long long)g.tile_m * BM + r < p.M;
 }
 
@@ -187,8 +201,8 @@ __device__ __forceinline__ TileGeom make_geom(const IgemmP& p, int tile_m) {
             g.tx0 = (t - ty * p.tiles_pw) << p.tw_log2;
         } else {
             const long long m0 = (long long)tile_m * BM;
-            g.n_first = (int)(m0 / p.HoWo);
-            g.rem_first = (int)(m0 - (long long)g.n_first * p.HoWo);
+            g.n_first = (int)(m0 / p.HWd);
+            g.rem_first = (int)(m0 - (long long)g.n_first * p.HWd);
         }
     } else {
         const int z = blockIdx.y;
@@ -249,7 +263,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     bool cb_per_row = false;
     if constexpr (CONV) {
         if (p.cbias) {
-            const bool one_image = (p.tw_log2 >= 0) || (g.rem_first + BM <= p.HoWo);
+            const bool one_image = (p.tw_log2 >= 0) || (g.rem_first + BM <= p.HWd);
             if (one_image) {
                 const float* cbp = p.cbias + (long long)g.n_first * p.cbias_stride;
 #pragma unroll
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             a_nh[i] = nrel * p.H;
             unsigned mask = 0;
             if (ok) {
-                for (int t = 0; t < p.taps; ++t) {
+                for (int t = 0; t < p.KS * p.KS; ++t) {
                     const int dy = (p.KS == 3) ? t / 3 : 0, dx = (p.KS == 3) ? t - dy * 3 : 0;
                     bool in = (unsigned)(bh + dy) < (unsigned)p.Heff && (unsigned)(bw + dx) < (unsigned)p.Weff;
                     if (p.ups == 2) in = in && (((bh + dy) | (bw + dx)) & 1) == 0;  // zero-insertion: only even positions hold data
@@ -588,15 +602,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             ss.src = st_src;
             ss.cw = st_src ? p.C1 : p.C0;                         // channels of the current source
             ss.kin = st_cc * BK;                                  // first channel of this chunk inside the source
-            ss.dy = (p.KS == 3) ? (st_tap * 11) >> 5 : 0;         // tap / 3 for tap < 9
-            ss.dx = (p.KS == 3) ? st_tap - ss.dy * 3 : 0;
+            const int tap = p.par ? (int)((p.taplist >> (4 * st_tap)) & 15u) : st_tap;  // parity mode: the st_tap-th tap of the class
+            ss.dy = (p.KS == 3) ? (tap * 11) >> 5 : 0;            // tap / 3 for tap < 9
+            ss.dx = (p.KS == 3) ? tap - ss.dy * 3 : 0;
             // the tap displacement goes into the per-lane offset (border rows hold a wrapped negative base that only
             // becomes a valid in-window offset after this add); the channel chunk goes into the SGPR offset
             ss.tapbytes = (unsigned)((ss.dy * p.W + ss.dx) * ss.cw * ES);
             ss.soffA = (unsigned)(ss.kin * ES);
-            ss.soffB = (unsigned)(st_tap * tapstride + ((st_src ? p.C0 : 0) + ss.kin) * ES);
+            ss.soffB = (unsigned)(tap * tapstride + ((st_src ? p.C0 : 0) + ss.kin) * ES);
             ss.ktail = ss.kin + BK > ss.cw;                       // uniform: only the last chunk of a source
-            ss.tapbit = 1u << st_tap;
+            ss.tapbit = 1u << tap;
             // advance (tap inner, chunk, source outer)
             if (++st_tap == p.taps) {
                 st_tap = 0;
@@ -1309,14 +1324,14 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     if (CONV) {
         // patch mode: TW = min(16, Wo) if it is a power of two dividing Wo and TH = BM/TW divides Ho
         int tw = 16;
-        while (tw > p.Wo) tw >>= 1;
-        if (tw >= 4 && p.Wo % tw == 0 && (BM % tw) == 0 && p.Ho % (BM / tw) == 0) {
+        while (tw > p.Wd) tw >>= 1;
+        if (tw >= 4 && p.Wd % tw == 0 && (BM % tw) == 0 && p.Hd % (BM / tw) == 0) {
             int l = 0;
             while ((1 << l) < tw) ++l;
             p.tw_log2 = l;
             p.th = BM / tw;
-            p.tiles_pw = p.Wo / tw;
-            p.tiles_pi = p.tiles_pw * (p.Ho / p.th);
+            p.tiles_pw = p.Wd / tw;
+            p.tiles_pi = p.tiles_pw * (p.Hd / p.th);
             p.tiles_m = p.tiles_pi * p.N;
         } else {
             p.tiles_m = (int)((p.M + BM - 1) / BM);
@@ -1421,6 +1436,17 @@ static int conv_bm(const eod_conv_desc* d, bool halo, int force) { return (!halo
 // pairs (8 channels) per source; every kernel variant has it except the thin-input (tap-major) first conv
 static bool conv_split_ok(const eod_conv_desc* d, int Ho, int Wo, int force) {
     return d->dtype == EOD_F32 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && !d->w_tapmajor && d->upsample != 2 && force != 7;
+}
+// zero-insertion upsampling through the four parity-class launches (see eod_conv2d_igemm); EOD_CONV_PARITY=0 keeps the single
+// full-grid launch that multiplies the inserted zeros (tuning / A-B only)
+static bool conv_parity_ok(const eod_conv_desc* d, int Ho, int Wo) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EOD_CONV_PARITY");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return on && d->upsample == 2 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && !d->out_nchw_f32 && !d->stats &&
+           !d->w_tapmajor && !d->w_split && Ho % 2 == 0 && Wo % 2 == 0;
 }
 extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
     if (!d) return 0;
@@ -1528,6 +1554,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     p.N = d->N; p.H = d->H; p.W = d->W; p.C0 = d->C0; p.C1 = d->C1; p.Cin = d->C0 + d->C1; p.Cout = d->Cout;
     p.KS = d->ksize; p.stride = d->stride; p.pad = d->pad; p.ups = d->upsample; p.pad_tl = d->pad_tl;
     p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo; p.Heff = Heff; p.Weff = Weff;
+    p.Hd = Ho; p.Wd = Wo; p.HWd = Ho * Wo;
     p.M = (long long)d->N * Ho * Wo;
     p.Ncols = d->Cout;
     p.taps = d->ksize * d->ksize;
@@ -1629,6 +1656,27 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         return EOD_OK;
     }
     if (d->w_split) return launch_conv_split(p, 1, st);
+    if (conv_parity_ok(d, Ho, Wo)) {
+        // zero-insertion upsampling (backward-data of a stride-2 conv): 3/4 of the (output position, tap) pairs meet an inserted zero,
+        // and WHICH taps do depends only on the parity of the output position -> four launches, one per parity class, each over the
+        // quarter grid with its 1 / 2 / 2 / 4 live taps (9 tap-visits per 4 outputs instead of 36)
+        p.par = 1;
+        p.Hd = Ho / 2; p.Wd = Wo / 2; p.HWd = p.Hd * p.Wd;
+        p.M = (long long)d->N * p.HWd;
+        for (int cls = 0; cls < 4; ++cls) {
+            IgemmP q = p;
+            q.par_y = cls >> 1; q.par_x = cls & 1;
+            // output row ho reads upsampled row ho - 1 + dy, stored iff even: ho even -> dy = 1, ho odd -> dy in {0, 2} (same for x)
+            const int ndy = q.par_y ? 2 : 1, ndx = q.par_x ? 2 : 1;
+            const int dys[2] = {q.par_y ? 0 : 1, 2}, dxs[2] = {q.par_x ? 0 : 1, 2};
+            q.taps = 0; q.taplist = 0;
+            for (int a = 0; a < ndy; ++a)
+                for (int b = 0; b < ndx; ++b) q.taplist |= (unsigned)(dys[a] * 3 + dxs[b]) << (4 * q.taps++);
+            const int rc = d->dtype == EOD_F16 ? launch_T<half_t, true>(q, 1, st) : launch_T<float, true>(q, 1, st);
+            if (rc != EOD_OK) return rc;
+        }
+        return EOD_OK;
+    }
     return d->dtype == EOD_F16 ? launch_T<half_t, true>(p, 1, st) : launch_T<float, true>(p, 1, st);
 }
 

@@ -158,45 +158,57 @@ extern "C" int eod_gn_finalize(const float* part0, int P0, int C0, const float* 
 
 // ---------------------------------------------------------------------------------------------
 // apply: y[n][pix][coff + c] = act(x[n][pix][c] * scale[n][coff+c] + shift[n][coff+c])
-// grid-stride over 16-byte chunks; y rows are Ctot wide (materialises the concat, normalised).
+// slab decomposition of common.h (gn_slab); y rows are Ctot wide (materialises the concat, normalised).
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool SILU>
-__global__ void gn_apply_kernel(const T* __restrict__ x, long long nchunks, int HW, int C, const float* __restrict__ ss,
-                                int Ctot, int coff, T* __restrict__ y) {
-    constexpr int EPC = dt<T>::epc;
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int HW, int C, const float* __restrict__ ss, int Ctot,
+                                                      int coff, T* __restrict__ y, int per) {
+    constexpr int EPC = dt<T>::epc, U = 4;
     constexpr bool FAST = (EPC == 8);
-    const int cpp = C / EPC;
-    const long long per_n = (long long)HW * cpp;
-    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < nchunks; f += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(f / per_n);
-        const long long rem = f - (long long)n * per_n;
-        const long long pix = rem / cpp;
-        const int c = (int)(rem - pix * cpp) * EPC;
-        const i32x4 raw = *reinterpret_cast<const i32x4*>(x + f * EPC);
-        const float* sp = ss + ((long long)n * Ctot + coff + c) * 2;
-        i32x4 outv;
-        if constexpr (EPC == 8) {
-            const half8 h = __builtin_bit_cast(half8, raw);
-            half8 o;
+    const int tx = threadIdx.x, ty = threadIdx.y, RY = blockDim.y;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+    float sc[EPC], sh[EPC];
+    const float* sp = ss + ((long long)n * Ctot + coff + tx * EPC) * 2;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = (float)h[e] * sp[2 * e] + sp[2 * e + 1];
-                if (SILU) v = silu_f<FAST>(v);
-                o[e] = (half_t)v;
-            }
-            outv = __builtin_bit_cast(i32x4, o);
-        } else {
-            const f32x4 fv = __builtin_bit_cast(f32x4, raw);
-            f32x4 o;
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = sp[2 * e];
+        sh[e] = sp[2 * e + 1];
+    }
+    const T* xb = x + (long long)n * HW * C + tx * EPC;
+    T* yb = y + (long long)n * HW * Ctot + coff + tx * EPC;
+    for (int pix = p0 + ty; pix < p1; pix += U * RY) {
+        i32x4 raw[U];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = fv[e] * sp[2 * e] + sp[2 * e + 1];
-                if (SILU) v = silu_f<FAST>(v);
-                o[e] = v;
+        for (int u = 0; u < U; ++u)
+            if (pix + u * RY < p1) raw[u] = *reinterpret_cast<const i32x4*>(xb + (long long)(pix + u * RY) * C);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pix + u * RY >= p1) break;
+            i32x4 outv;
+            if constexpr (EPC == 8) {
+                const half8 h = __builtin_bit_cast(half8, raw[u]);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = (float)h[e] * sc[e] + sh[e];
+                    if (SILU) v = silu_f<FAST>(v);
+                    o[e] = (half_t)v;
+                }
+                outv = __builtin_bit_cast(i32x4, o);
+            } else {
+                const f32x4 fv = __builtin_bit_cast(f32x4, raw[u]);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fv[e] * sc[e] + sh[e];
+                    if (SILU) v = silu_f<FAST>(v);
+                    o[e] = v;
+                }
+                outv = __builtin_bit_cast(i32x4, o);
             }
-            outv = __builtin_bit_cast(i32x4, o);
+            *reinterpret_cast<i32x4*>(yb + (long long)(pix + u * RY) * Ctot) = outv;
         }
-        *reinterpret_cast<i32x4*>(y + (((long long)n * HW + pix) * Ctot + coff + c)) = outv;
     }
 }
 
@@ -205,12 +217,12 @@ extern "C" int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, cons
     EOD_REQUIRE(x && y && scale_shift && N > 0 && HW > 0 && C > 0, "gn_apply: bad args");
     const int epc = 16 / eod_esize(dtype);
     EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_apply: channel alignment");
+    EOD_REQUIRE(C / epc <= 256 && N <= 65535, "gn_apply: C=%d / N=%d unsupported", C, N);
     EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(y), "gn_apply: alignment");
-    const long long nchunks = (long long)N * HW * (C / epc);
-    long long blocks = (nchunks + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const GnSlab g = gn_slab(N, HW, C, epc, 4);
+    const dim3 grid(g.P, N), block(g.cpp, g.ry);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(T, S) hipLaunchKernelGGL((gn_apply_kernel<T, S>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, nchunks, HW, C, scale_shift, Ctot, coff, (T*)y)
+#define LAUNCH(T, S) hipLaunchKernelGGL((gn_apply_kernel<T, S>), grid, block, 0, st, (const T*)x, HW, C, scale_shift, Ctot, coff, (T*)y, g.per)
     if (dtype == EOD_F16) {
         if (silu) LAUNCH(half_t, true); else LAUNCH(half_t, false);
     } else {

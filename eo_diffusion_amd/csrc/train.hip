@@ -351,17 +351,28 @@ __global__ void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restri
     }
     const T* xb = x + (long long)n * HW * C + (long long)tx * EPC;
     const T* db = dy + (long long)n * HW * Ctot + coff + (long long)tx * EPC;
-    for (int pix = p0 + ty; pix < p1; pix += RY) {
-        T xv[EPC], dv[EPC];
-        *reinterpret_cast<i32x4*>(xv) = *reinterpret_cast<const i32x4*>(xb + (long long)pix * C);
-        *reinterpret_cast<i32x4*>(dv) = *reinterpret_cast<const i32x4*>(db + (long long)pix * Ctot);
+    constexpr int U = 2;  // pixels in flight per thread; the accumulation order stays pixel-ascending per thread
+    for (int pix = p0 + ty; pix < p1; pix += U * RY) {
+        T xv[U][EPC], dv[U][EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float xf = (float)xv[e];
-            float dz = (float)dv[e];
-            if (silu) dz *= dsilu_f<FAST>(xf * sc[e] + sh[e]);
-            sa[e] += dz;
-            sb[e] += dz * xf;
+        for (int u = 0; u < U; ++u) {
+            const long long pu = pix + u * RY;
+            if (pu < p1) {
+                *reinterpret_cast<i32x4*>(xv[u]) = *reinterpret_cast<const i32x4*>(xb + pu * C);
+                *reinterpret_cast<i32x4*>(dv[u]) = *reinterpret_cast<const i32x4*>(db + pu * Ctot);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pix + u * RY >= p1) break;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float xf = (float)xv[u][e];
+                float dz = (float)dv[u][e];
+                if (silu) dz *= dsilu_f<FAST>(xf * sc[e] + sh[e]);
+                sa[e] += dz;
+                sb[e] += dz * xf;
+            }
         }
     }
     const int W2 = CPP * EPC * 2;
@@ -514,36 +525,73 @@ extern "C" int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, 
 }
 
 // apply: dx[n][pix][c] = k1*dz + k2*x + k3 (+ add[n][pix][c]);  one concat source per launch (C channels at coff)
-template <typename T>
-__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ ss,
-                                    const float* __restrict__ coef, const T* __restrict__ add, long long nchunks, int HW, int C, int Ctot,
-                                    int coff, int silu, T* __restrict__ dx) {
-    constexpr int EPC = dt<T>::epc;
+// (slab decomposition of common.h: the 5 per-channel coefficients of a thread's chunk stay in registers)
+template <typename T, bool SILU, bool ADD>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ ss,
+                                                          const float* __restrict__ coef, const T* __restrict__ add, int HW, int C, int Ctot,
+                                                          int coff, T* __restrict__ dx, int per) {
+    constexpr int EPC = dt<T>::epc, U = 2;
     constexpr bool FAST = (EPC == 8);
-    const int cpp = C / EPC;
-    const long long per_n = (long long)HW * cpp;
-    for (long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x; f < nchunks; f += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(f / per_n);
-        const long long rem = f - (long long)n * per_n;
-        const long long pix = rem / cpp;
-        const int c = (int)(rem - pix * cpp) * EPC;
-        T xv[EPC], dv[EPC], av[EPC], ov[EPC];
-        *reinterpret_cast<i32x4*>(xv) = *reinterpret_cast<const i32x4*>(x + f * EPC);
-        *reinterpret_cast<i32x4*>(dv) = *reinterpret_cast<const i32x4*>(dy + ((long long)n * HW + pix) * Ctot + coff + c);
-        if (add) *reinterpret_cast<i32x4*>(av) = *reinterpret_cast<const i32x4*>(add + f * EPC);
-        const float* sp = ss + ((long long)n * Ctot + coff + c) * 2;
-        const float* kp = coef + ((long long)n * Ctot + coff + c) * 3;
+    const int tx = threadIdx.x, ty = threadIdx.y, RY = blockDim.y;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+    float sc[EPC], sh[EPC], k1[EPC], k2[EPC], k3[EPC];
+    const float* sp = ss + ((long long)n * Ctot + coff + tx * EPC) * 2;
+    const float* kp = coef + ((long long)n * Ctot + coff + tx * EPC) * 3;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float xf = (float)xv[e];
-            float dz = (float)dv[e];
-            if (silu) dz *= dsilu_f<FAST>(xf * sp[2 * e] + sp[2 * e + 1]);
-            float v = kp[3 * e] * dz + kp[3 * e + 1] * xf + kp[3 * e + 2];
-            if (add) v += (float)av[e];
-            ov[e] = (T)v;
-        }
-        *reinterpret_cast<i32x4*>(dx + f * EPC) = *reinterpret_cast<const i32x4*>(ov);
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = sp[2 * e];
+        sh[e] = sp[2 * e + 1];
+        k1[e] = kp[3 * e];
+        k2[e] = kp[3 * e + 1];
+        k3[e] = kp[3 * e + 2];
     }
+    const long long xoff = (long long)n * HW * C + tx * EPC;
+    const T* xb = x + xoff;
+    const T* ab = ADD ? add + xoff : nullptr;
+    T* ob = dx + xoff;
+    const T* db = dy + (long long)n * HW * Ctot + coff + tx * EPC;
+    for (int pix = p0 + ty; pix < p1; pix += U * RY) {
+        T xv[U][EPC], dv[U][EPC], av[U][EPC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long pu = pix + u * RY;
+            if (pu < p1) {
+                *reinterpret_cast<i32x4*>(xv[u]) = *reinterpret_cast<const i32x4*>(xb + pu * C);
+                *reinterpret_cast<i32x4*>(dv[u]) = *reinterpret_cast<const i32x4*>(db + pu * Ctot);
+                if (ADD) *reinterpret_cast<i32x4*>(av[u]) = *reinterpret_cast<const i32x4*>(ab + pu * C);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long pu = pix + u * RY;
+            if (pu >= p1) break;
+            T ov[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float xf = (float)xv[u][e];
+                float dz = (float)dv[u][e];
+                if (SILU) dz *= dsilu_f<FAST>(xf * sc[e] + sh[e]);
+                float v = k1[e] * dz + k2[e] * xf + k3[e];
+                if (ADD) v += (float)av[u][e];
+                ov[e] = (T)v;
+            }
+            *reinterpret_cast<i32x4*>(ob + pu * C) = *reinterpret_cast<const i32x4*>(ov);
+        }
+    }
+}
+
+template <typename T>
+static void launch_gn_bwd_apply(const GnSlab& g, int N, bool silu, hipStream_t st, const T* x, const T* dy, const float* ss, const float* coef,
+                                const T* add, int HW, int C, int Ctot, int coff, T* dx) {
+    const dim3 grid(g.P, N), block(g.cpp, g.ry);
+#define LAUNCH(S, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, S, A>), grid, block, 0, st, x, dy, ss, coef, add, HW, C, Ctot, coff, dx, g.per)
+    if (silu) {
+        if (add) LAUNCH(true, true); else LAUNCH(true, false);
+    } else {
+        if (add) LAUNCH(false, true); else LAUNCH(false, false);
+    }
+#undef LAUNCH
 }
 
 extern "C" int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype, int N,
@@ -551,15 +599,14 @@ extern "C" int eod_gn_bwd_apply(const void* x, const void* dy, const float* scal
     EOD_REQUIRE(x && dy && scale_shift && coef && dx && N > 0 && HW > 0 && C > 0, "gn_bwd_apply: bad args");
     const int epc = 16 / eod_esize(dtype);
     EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_bwd_apply: channel alignment");
+    EOD_REQUIRE(C / epc <= 256 && N <= 65535, "gn_bwd_apply: C=%d / N=%d unsupported", C, N);
     EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(dy) && eod_aligned16(dx) && (!add || eod_aligned16(add)), "gn_bwd_apply: alignment");
-    const long long nchunks = (long long)N * HW * (C / epc);
-    long long blocks = (nchunks + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const GnSlab g = gn_slab(N, HW, C, epc, 2);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EOD_F16)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const half_t*)x, (const half_t*)dy, scale_shift, coef, (const half_t*)add, nchunks, HW, C, Ctot, coff, silu, (half_t*)dx);
+        launch_gn_bwd_apply<half_t>(g, N, silu != 0, st, (const half_t*)x, (const half_t*)dy, scale_shift, coef, (const half_t*)add, HW, C, Ctot, coff, (half_t*)dx);
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (const float*)dy, scale_shift, coef, (const float*)add, nchunks, HW, C, Ctot, coff, silu, (float*)dx);
+        launch_gn_bwd_apply<float>(g, N, silu != 0, st, (const float*)x, (const float*)dy, scale_shift, coef, (const float*)add, HW, C, Ctot, coff, (float*)dx);
     EOD_CHECK_LAUNCH("gn_bwd_apply");
     return EOD_OK;
 }
@@ -1258,9 +1305,12 @@ struct GemmTnP {
     char* c;
     long long lda, ldb, ldc, sa0, sa1, sb0, sb1, sc0, sc1;  // elements
     int M, N, K, nb1, tiles_m, tiles_n;
+    int k_total;  // > 0: batch level 0 walks K-ranges of ONE operand pair (split-K): batch b0 owns rows [b0*K, min(k_total, (b0+1)*K))
     float alpha;
 };
 
+// F32OUT: fp32 C (the split-K partial tiles of the 1x1 backward-weights, eod_conv1x1_wgrad), alpha not applied
+template <bool F32OUT>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnP p) {
     constexpr int ROWS = 64, ROWB = 256, TILE = ROWS * ROWB, STAGE = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A tile | B tile]
@@ -1278,6 +1328,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnP p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(B), 0, 0x7fffffff, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    const int K = p.k_total > 0 ? max(0, min(p.K, p.k_total - b0 * p.K)) : p.K;
     const int drow = lane >> 4, dslot = lane & 15;
     auto issue = [&](int strip, int stage) {
         char* sa = smem + stage * STAGE;
@@ -1288,8 +1339,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnP p) {
             const int chunk = dslot ^ wg_swz(row);
             const long long k = (long long)strip * 64 + row;
             const int cm = m0 + chunk * 8, cn = n0 + chunk * 8;
-            const unsigned va = (k < p.K && cm < p.M) ? (unsigned)((k * p.lda + cm) * 2) : OOB;
-            const unsigned vb = (k < p.K && cn < p.N) ? (unsigned)((k * p.ldb + cn) * 2) : OOB;
+            const unsigned va = (k < K && cm < p.M) ? (unsigned)((k * p.lda + cm) * 2) : OOB;
+            const unsigned vb = (k < K && cn < p.N) ? (unsigned)((k * p.ldb + cn) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sa + (wave + 4 * i) * 1024), 16, va, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + (wave + 4 * i) * 1024), 16, vb, 0, 0, 0);
         }
@@ -1313,8 +1364,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int strips = (p.K + 63) / 64;
-    issue(0, 0);
+    const int strips = (K + 63) / 64;
+    if (strips > 0) issue(0, 0);
     for (int s = 0; s < strips; ++s) {
         const int stage = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1344,7 +1395,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnP p) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
-    half_t* C = reinterpret_cast<half_t*>(p.c) + b0 * p.sc0 + b1 * p.sc1;
+    half_t* C = reinterpret_cast<half_t*>(p.c) + (F32OUT ? 2 : 1) * (b0 * p.sc0 + b1 * p.sc1);
+    float* Cf = reinterpret_cast<float*>(C);
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1354,7 +1406,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTnP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M && n < p.N) C[(long long)m * p.ldc + n] = (half_t)(acc[i][j][r] * p.alpha);
+                if (m < p.M && n < p.N) {
+                    if constexpr (F32OUT)
+                        Cf[(long long)m * p.ldc + n] = acc[i][j][r];
+                    else
+                        C[(long long)m * p.ldc + n] = (half_t)(acc[i][j][r] * p.alpha);
+                }
             }
         }
 }
@@ -1371,7 +1428,7 @@ extern "C" int eod_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ld
     GemmTnP p;
     p.a = (const char*)a; p.b = (const char*)b; p.c = (char*)c;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sa0 = sa0; p.sa1 = sa1; p.sb0 = sb0; p.sb1 = sb1; p.sc0 = sc0; p.sc1 = sc1;
-    p.M = M; p.N = N; p.K = K; p.nb1 = nb1; p.alpha = alpha;
+    p.M = M; p.N = N; p.K = K; p.nb1 = nb1; p.alpha = alpha; p.k_total = 0;
     p.tiles_m = (M + 127) / 128;
     p.tiles_n = (N + 127) / 128;
     const long long grid = (long long)p.tiles_m * p.tiles_n * nb0 * nb1;
@@ -1379,11 +1436,44 @@ extern "C" int eod_gemm_tn(const void* a, int64_t lda, const void* b, int64_t ld
     const size_t lds = 2 * 2 * 64 * 256;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     EOD_CHECK_LAUNCH("gemm_tn");
+    return EOD_OK;
+}
+
+// backward-weights of a 1x1 / stride-1 conv (the skip connections and the attention projections) with the same machinery:
+//   dW[co][ci] = sum_pix dY[pix][co] * X[pix][ci]      (both tensors pixel-major as stored: no transposed copies in HBM)
+// split over S pixel ranges; fp32 partial tiles partial[split][co][ldp] (the layout eod_wgrad_reduce takes with ksize 1).
+extern "C" int eod_conv1x1_wgrad(const void* dy, const void* x, int dtype, int64_t npix, int Cx, int Cy, int Cout, float* partial, int ldp,
+                                 int S, void* stream) {
+    EOD_REQUIRE(dy && x && partial && npix > 0 && Cx > 0 && Cy > 0 && Cout > 0 && Cout <= Cy && S > 0 && ldp >= Cx, "conv1x1_wgrad: bad args");
+    EOD_REQUIRE(dtype == EOD_F16, "conv1x1_wgrad: fp16 only (transposed LDS reads are 16-bit)");
+    EOD_REQUIRE(Cx % 8 == 0 && Cy % 8 == 0 && eod_aligned16(dy) && eod_aligned16(x), "conv1x1_wgrad: channel counts must be multiples of 8, pointers 16-byte aligned");
+    EOD_REQUIRE(npix * Cy * 2 < 0x7fffffffLL && npix * Cx * 2 < 0x7fffffffLL, "conv1x1_wgrad: tensors exceed the 2 GiB buffer window");
+    const long long strips = (npix + 63) / 64;
+    const long long per = (strips + S - 1) / S;
+    GemmTnP p;
+    p.a = (const char*)dy; p.b = (const char*)x; p.c = (char*)partial;
+    p.lda = Cy; p.ldb = Cx; p.ldc = ldp;
+    p.K = (int)(per * 64); p.k_total = (int)npix;
+    p.sa0 = (long long)p.K * Cy; p.sb0 = (long long)p.K * Cx; p.sc0 = (long long)Cout * ldp;
+    p.sa1 = p.sb1 = p.sc1 = 0;
+    p.M = Cout; p.N = Cx; p.nb1 = 1; p.alpha = 1.0f;
+    p.tiles_m = (Cout + 127) / 128;
+    p.tiles_n = (Cx + 127) / 128;
+    const long long grid = (long long)p.tiles_m * p.tiles_n * S;
+    EOD_REQUIRE(grid <= 0x7fffffffLL, "conv1x1_wgrad: grid too large");
+    const size_t lds = 2 * 2 * 64 * 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
+    EOD_CHECK_LAUNCH("conv1x1_wgrad");
     return EOD_OK;
 }
 

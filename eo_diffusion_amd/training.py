@@ -601,23 +601,29 @@ class UNetTrainer:
             ci0 += cs_real
 
     def _wgrad_direct(self, rec, dy, cout):
-        """3x3 / stride-1 backward-weights through conv3x3_wgrad_kernel (pixel-major staging + transposed LDS reads)"""
+        """3x3 / stride-1 and 1x1 backward-weights straight from the NHWC tensors: conv3x3_wgrad_kernel / gemm_tn_kernel
+        (pixel-major staging + transposed LDS reads), split over pixel ranges into fp32 partial tiles"""
         L, bp, dt = self.L, self.bprog, self.dt
         conv = rec.conv
         cin_total = conv.weight.shape[1]
         dW = self._param_grad(conv.weight)
-        strips = dy.N * (dy.H * dy.W // 64)
+        ks = rec.ksize
+        npix = dy.N * dy.H * dy.W
+        strips = dy.N * (dy.H * dy.W // 64) if ks == 3 else (npix + 63) // 64
         ci0 = 0
         for xs in rec.srcs:
             cs = xs.C
             cs_real = min(cs, cin_total - ci0)
             ldp = round_up(cs, 4)
-            tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 3
+            tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * ks
             S = max(1, min(strips, (int(os.environ.get("EOD_WGRAD_WGS", "512")) + tiles - 1) // tiles))
-            partial = bp.empty((S * 9 * cout * ldp,), torch.float32)
-            self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, int(bool(rec.upsample)),
-                       ptr(partial), ldp, S)
-            self._call(L.eod_wgrad_reduce, ptr(partial), S, 3, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(dW))
+            partial = bp.empty((S * ks * ks * cout * ldp,), torch.float32)
+            if ks == 3:
+                self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, int(bool(rec.upsample)),
+                           ptr(partial), ldp, S)
+            else:
+                self._call(L.eod_conv1x1_wgrad, ptr(dy.t), ptr(xs.t), dt, npix, cs, dy.C, cout, ptr(partial), ldp, S)
+            self._call(L.eod_wgrad_reduce, ptr(partial), S, ks, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(dW))
             ci0 += cs_real
 
     def _conv_bwd(self, rec):
@@ -646,7 +652,9 @@ class UNetTrainer:
         ld = S * Kper
         shift_dy = None
         # dedicated backward-weights kernel (no transposed copies) where it applies; the GEMM path otherwise
-        direct = (s1 and self.prog.precision == "fp16" and (Wo % 64 == 0 or (Wo in (16, 32) and (Ho * Wo) % 64 == 0))
+        geom = ((s1 and (Wo % 64 == 0 or (Wo in (16, 32) and (Ho * Wo) % 64 == 0)))
+                or (ks == 1 and stride == 1 and not rec.upsample))
+        direct = (geom and self.prog.precision == "fp16"
                   and dy.C % 8 == 0 and all(x.C % 8 == 0 for x in rec.srcs)
                   and dy.t.numel() * es < 2**31 and all(x.t.numel() * es < 2**31 for x in rec.srcs)
                   and os.environ.get("EOD_WGRAD", "direct") != "gemm")

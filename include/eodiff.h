@@ -331,6 +331,11 @@ int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout, int nci, 
  * fp32 partial tiles partial[S][9][Cout][ldp] that eod_wgrad_reduce sums (csrc/train.hip: conv3x3_wgrad_kernel) */
 int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N, int H, int W, int Cx, int Ho, int Wo, int Cy, int Cout,
                       int ups, float* partial, int ldp, int S, void* stream);
+/* the same for a 1x1 / stride-1 conv (skip connections, attention projections; F.conv2d / conv1d backward-weights behind
+ * unet_openai.py:345,409,413): dW[co][ci] = sum_pix dY[pix][co] X[pix][ci] over npix = N*H*W pixel-major rows, split over S
+ * pixel ranges into partial[S][1][Cout][ldp] (fp16, channels % 8 == 0; csrc/train.hip: gemm_tn_kernel) */
+int eod_conv1x1_wgrad(const void* dy, const void* x, int dtype, int64_t npix, int Cx, int Cy, int Cout, float* partial, int ldp,
+                      int S, void* stream);
 /* GroupNorm32 (+SiLU) backward (unet_openai.py:11-13,312-316): see csrc/train.hip for the algebra */
 int eod_gn_mean_rstd(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW, int groups,
                      float eps, float* mean_rstd, void* stream);

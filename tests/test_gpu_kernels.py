@@ -59,6 +59,35 @@ def test_conv_vs_torch(prec, case):
     assert rel_l2(got, ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("case", [
+    (2, 64, 16, 16, 128, True),    # four parity-class launches, patch-mode tiles on the quarter grid, residual
+    (1, 96, 12, 20, 192, False),   # raster tiles (20 % 16), K tail, N tail
+    (3, 128, 32, 32, 128, True),   # tiles of one class span whole images
+    (2, 32, 4, 4, 32, False),      # small map: split-K route (single full-grid launch that multiplies the inserted zeros)
+])
+def test_conv_zero_insertion_upsample_vs_torch(prec, case):
+    """upsample=2 (zero insertion: the backward-data of a stride-2 conv, unet_openai.py:107-125 Downsample): the conv over the
+    zero-stuffed (2H x 2W) map, computed per output parity class with only the taps that meet stored samples"""
+    N, Cin, H, W, Cout, with_res = case
+    x = synth_input(f"zx{case}", (N, Cin, H, W), 41)
+    w = synth_input(f"zw{case}", (Cout, Cin, 3, 3), 41, scale=1.0 / math.sqrt(Cin * 9 / 4))
+    r = synth_input(f"zr{case}", (N, Cout, 2 * H, 2 * W), 41)
+
+    def emit(prog, a):
+        from eo_diffusion_amd.engine import Act
+        rr = Act(prog.own(r.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), N, 2 * H, 2 * W, Cout) if with_res else None
+        y, _ = prog.conv(a, prog.pack_conv(w.to(DEV)), None, Cout, ksize=3, stride=1, pad=1, upsample=2, res=rr)
+        return y
+
+    got = run_program(prec, x, emit)
+    xin = torch.zeros(N, Cin, 2 * H, 2 * W)
+    xin[:, :, ::2, ::2] = x
+    ref = F.conv2d(xin, w, None, padding=1) + (r if with_res else 0)
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < TOL[prec]
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("dims", [(2, 64, 32, 8, 8, 64), (2, 64, 32, 16, 16, 128), (1, 128, 96, 32, 16, 256)])
 def test_conv_fused_epilogue_concat_residual_temb(prec, dims):
