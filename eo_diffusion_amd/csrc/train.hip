@@ -233,17 +233,51 @@ extern "C" int eod_colsum(const float* seg, int S, int C, float* out, void* stre
 // ---------------------------------------------------------------------------------------------
 // weight gradient, second pass: dW_oihw[co][ci0 + ci][tap] = scale * sum_s partial[s][tap][co][ci]  (ci < nci <= ldp)
 // ---------------------------------------------------------------------------------------------
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int taps, int Cout, int nci, int ldp, int ci0, int Cin,
-                                    float scale, float* __restrict__ dw) {
-    const long long total = (long long)Cout * nci * taps;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % nci);
-        const long long r = i / nci;
-        const int co = (int)(r % Cout);
-        const int tap = (int)(r / Cout);
-        float a = 0.0f;
-        for (int s = 0; s < S; ++s) a += part[(((long long)s * taps + tap) * Cout + co) * ldp + ci];
-        dw[((long long)co * Cin + ci0 + ci) * taps + tap] = a * scale;
+// One thread = one (co, 4 consecutive ci) quad of ALL taps for a quarter of the splits: 16-byte loads along ci, TAPS independent load
+// streams per thread, and the OIHW rows come out as 4 x TAPS contiguous floats.  The four split groups of a quad are combined
+// through LDS in a fixed order (deterministic).
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int S, int Cout, int nci, int ldp, int ci0, int Cin,
+                                                          float scale, float* __restrict__ dw) {
+    __shared__ f32x4 red[3][64][TAPS];
+    const int ql = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int nq = (nci + 3) >> 2;
+    const long long quad = (long long)blockIdx.x * 64 + ql;
+    const bool valid = quad < (long long)Cout * nq;
+    const int co = valid ? (int)(quad / nq) : 0;
+    const int ci = valid ? (int)(quad - (long long)co * nq) * 4 : 0;
+    const int per = (S + 3) >> 2, s0 = grp * per, s1 = min(S, s0 + per);
+    const long long tap_stride = (long long)Cout * ldp, s_stride = TAPS * tap_stride;
+    const float* base = part + (long long)co * ldp + ci;
+    f32x4 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (valid) {
+        for (int sp = s0; sp < s1; ++sp) {
+            f32x4 v[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) v[t] = *reinterpret_cast<const f32x4*>(base + sp * s_stride + t * tap_stride);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] += v[t];
+        }
+    }
+    if (grp > 0) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) red[grp - 1][ql][t] = acc[t];
+    }
+    __syncthreads();
+    if (grp == 0 && valid) {
+#pragma unroll
+        for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] += red[gq][ql][t];
+        float* out = dw + ((long long)co * Cin + ci0 + ci) * TAPS;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (ci + e < nci) {
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) out[e * TAPS + t] = acc[t][e] * scale;
+            }
     }
 }
 
@@ -251,10 +285,14 @@ extern "C" int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout
                                 float* dw_oihw, void* stream) {
     EOD_REQUIRE(partial && dw_oihw && S > 0 && (ksize == 1 || ksize == 3) && Cout > 0 && nci > 0 && ldp >= nci && ci0 >= 0 && ci0 + nci <= Cin,
                 "wgrad_reduce: bad args");
-    const int taps = ksize * ksize;
-    const long long total = (long long)Cout * nci * taps;
-    const unsigned blocks = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, S, taps, Cout, nci, ldp, ci0, Cin, scale, dw_oihw);
+    EOD_REQUIRE(ldp % 4 == 0 && eod_aligned16(partial), "wgrad_reduce: the partial tiles need 16-byte rows (ldp %% 4 == 0)");
+    const long long quads = (long long)Cout * ((nci + 3) / 4);
+    const long long blocks = (quads + 63) / 64;
+    EOD_REQUIRE(blocks <= 0x7fffffffLL, "wgrad_reduce: grid too large");
+    if (ksize == 3)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, S, Cout, nci, ldp, ci0, Cin, scale, dw_oihw);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, S, Cout, nci, ldp, ci0, Cin, scale, dw_oihw);
     EOD_CHECK_LAUNCH("wgrad_reduce");
     return EOD_OK;
 }
@@ -1045,6 +1083,9 @@ extern "C" int eod_embedding_bwd(const float* dout, const int64_t* y, int N, int
 // transposed copies), and the transposes themselves disappear.
 // Output: fp32 partial tiles partial[split][ky*3+kx][co][ci] (same layout as the GEMM path -> eod_wgrad_reduce).
 // Requirements (checked on the host): fp16, Wo % 64 == 0, channel counts multiples of 8.
+// MFMA shape: 32x32x16.  The 16x16x32 shape that pays in the forward kernels was tried here (round 2) and LOST 17 % on the whole
+// training step: the 192 accumulator registers leave 64 for everything else, four A + two B fragments and their addresses do not
+// fit (38 spilled VGPRs; 9 with the sub-step loop rolled, which then serialises the fragment loads behind the MFMAs).
 // =============================================================================================
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) void lds_void_t;
