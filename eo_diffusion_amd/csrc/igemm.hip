@@ -725,6 +725,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         }
         __builtin_amdgcn_s_barrier();
         // (issuing the DMA instructions one by one between the MFMA sub-steps was measured: no gain, -5..10 %)
+        // (split mode, 1x1 / stride-2 convs, round 2: a 3-stage ring does not help either -- 128x128 / 4 waves / 96 KiB, one workgroup per
+        //  CU: -30 %; 256x128 / 8 waves / 144 KiB: +-1 % -- so DMA latency is not what holds these HBM-streaming shapes at 2.9 TB/s)
         if (kt + STAGES - 1 < KT) issue_loads((kt + STAGES - 1) % STAGES);
         const char* sb = smem + (kt % STAGES) * STAGE;
         if constexpr (MS == 16 && SPLIT) {

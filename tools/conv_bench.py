@@ -15,6 +15,11 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, upsample)
     "l3_512": (16, 32, 32, 512, 512, 3, 1, False),
     "up_256": (16, 128, 128, 256, 256, 3, 1, True),
     "sk_384": (16, 256, 256, 384, 128, 1, 1, False),
+    "sk_256": (16, 256, 256, 256, 128, 1, 1, False),
+    "sk_640": (16, 128, 128, 640, 256, 1, 1, False),
+    "sk_768": (16, 64, 64, 768, 384, 1, 1, False),
+    "dn_128": (16, 256, 256, 128, 128, 3, 2, False),
+    "dn_256": (16, 128, 128, 256, 256, 3, 2, False),
 }
 
 def main():
