@@ -467,3 +467,27 @@ def test_conv3x3_backward_weights_kernel(N, H, W, Cx, Cout, ups):
         _lib.check(L.eod_wgrad_reduce(partial.data_ptr(), S, 3, Cout, Cx, Cx, 0, Cx, 1.0, dw.data_ptr(), st), "wgrad_reduce")
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu(), ref) < 2e-3, (S, rel_l2(dw.cpu(), ref))
+
+
+@pytest.mark.parametrize("N,H,W,Cx,Cy,Cout", [(3, 5, 7, 40, 48, 40), (2, 16, 16, 136, 128, 128), (1, 32, 32, 8, 200, 200), (2, 8, 8, 264, 16, 16)])
+def test_conv1x1_backward_weights_kernel(N, H, W, Cx, Cy, Cout):
+    """eod_conv1x1_wgrad (gemm_tn_kernel over pixel ranges, operands read pixel-major as stored) + eod_wgrad_reduce vs torch's
+    conv2d weight gradient: ragged pixel counts (the last 64-row strip is partial), channel counts that are not tile multiples,
+    Cout < row pitch of dY, split counts that leave trailing splits empty"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    x = synth_input(f"w1x{N}{H}{W}{Cx}", (N, Cx, H, W), 13).half()
+    dy = synth_input(f"w1y{N}{H}{W}{Cy}", (N, Cy, H, W), 14, scale=0.5).half()
+    ref = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cx, 1, 1), dy.float()[:, :Cout])
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    st = current_stream_ptr(torch.device(DEV))
+    npix = N * H * W
+    for S in (1, 3, 7):
+        partial = torch.full((S, 1, Cout, Cx), 7.0, dtype=torch.float32, device=DEV)
+        dw = torch.zeros((Cout, Cx, 1, 1), dtype=torch.float32, device=DEV)
+        _lib.check(L.eod_conv1x1_wgrad(dyd.data_ptr(), xd.data_ptr(), _lib.EOD_F16, npix, Cx, Cy, Cout, partial.data_ptr(), Cx, S, st), "conv1x1_wgrad")
+        _lib.check(L.eod_wgrad_reduce(partial.data_ptr(), S, 1, Cout, Cx, Cx, 0, Cx, 1.0, dw.data_ptr(), st), "wgrad_reduce")
+        torch.cuda.synchronize()
+        assert rel_l2(dw.cpu(), ref) < 2e-3, (S, rel_l2(dw.cpu(), ref))
