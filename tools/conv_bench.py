@@ -9,6 +9,9 @@ from eo_diffusion_amd.engine import Program
 SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, upsample)
     "l0_128": (16, 256, 256, 128, 128, 3, 1, False),
     "l0_384": (16, 256, 256, 384, 128, 3, 1, False),
+    "l0_256": (16, 256, 256, 256, 128, 3, 1, False),
+    "l0_32": (16, 256, 256, 32, 128, 3, 1, False),
+    "l0_64": (16, 256, 256, 64, 128, 3, 1, False),
     "l1_256": (16, 128, 128, 256, 256, 3, 1, False),
     "l1_640": (16, 128, 128, 640, 256, 3, 1, False),
     "l2_384": (16, 64, 64, 384, 384, 3, 1, False),
