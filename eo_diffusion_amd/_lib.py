@@ -91,6 +91,7 @@ SYMBOLS = {
     "eod_add": (i32, [vp, vp, vp, i32, i64, vp]),
     "eod_dropout": (i32, [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "eod_rowdot": (i32, [vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
+    "eod_scale_f32": (i32, [vp, i64, f32, vp]),
     "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),

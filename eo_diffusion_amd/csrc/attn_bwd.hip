@@ -20,6 +20,15 @@
 typedef __fp16 fp16x4b __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) void lds_void_b;
 
+// P and dS enter the second pair of MFMAs as fp16.  Their natural magnitudes are ~1/T and ~(1/T) x |dP - D|: at T = 4096 that is
+// 2e-4 and 1e-6 and below -- the fp16 SUBNORMAL range (min normal 6.1e-5), where every halving of the value costs a mantissa bit
+// (measured at 512 x 512 x 13, T = 4096 / 16384: 6.6 % error on the qkv weight gradients against the exact-fp32 mode).  Both are
+// therefore multiplied by an exact power of two before the conversion and the accumulators divided by it once at the end:
+// P x 2^8 (P <= 1 -> at most 256), dS x 2^12 (overflows fp16 only if P |dP - D| > 16, i.e. with a loss scale far too large -- and an
+// inf there is caught by the guarded optimizer step like any other fp16 overflow).
+#define AB_P_SCALE 256.0f
+#define AB_DS_SCALE 4096.0f
+
 struct AttnBwdP {
     const char* qkv;
     const char* dO;
@@ -166,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float pe = key_ok ? __expf(s[mt][4 * g4 + e] * p.alpha - l4[e]) : 0.0f;
-                    s[mt][4 * g4 + e] = pe;
-                    dp[mt][4 * g4 + e] = pe * (dp[mt][4 * g4 + e] - d4[e]);
+                    s[mt][4 * g4 + e] = pe * AB_P_SCALE;
+                    dp[mt][4 * g4 + e] = pe * (dp[mt][4 * g4 + e] - d4[e]) * AB_DS_SCALE;
                 }
             }
         // ---- dV += P^T dO,  dK += dS^T Q   (contraction over the 64 queries, permuted order) ----
@@ -197,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
                 const int srow = s0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (srow >= p.T) continue;
                 half_t* row = out + (long long)srow * 3 * p.C;
-                row[p.v_off + h * p.hs + j] = (half_t)dv[t][r];
-                row[p.k_off + h * p.hs + j] = (half_t)(dk[t][r] * p.alpha);
+                row[p.v_off + h * p.hs + j] = (half_t)(dv[t][r] * (1.0f / AB_P_SCALE));
+                row[p.k_off + h * p.hs + j] = (half_t)(dk[t][r] * (p.alpha * (1.0f / AB_DS_SCALE)));
             }
         }
     }
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
                     const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     pe = key < p.T ? pe : 0.0f;
                 }
-                dp[mt][r] = pe * (dp[mt][r] - my_D);  // dS^T
+                dp[mt][r] = pe * (dp[mt][r] - my_D) * AB_DS_SCALE;  // dS^T (scaled, see AB_DS_SCALE)
             }
         // ---- dQ += dS K  (contraction over the 64 keys held in registers, permuted order; B = K rows via transposed reads) ----
 #pragma unroll
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
             for (int r = 0; r < 16; ++r) {
                 const int qrow = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (qrow >= p.T) continue;
-                out[(long long)qrow * 3 * p.C + p.q_off + h * p.hs + j] = (half_t)(dq[t][r] * p.alpha);
+                out[(long long)qrow * 3 * p.C + p.q_off + h * p.hs + j] = (half_t)(dq[t][r] * (p.alpha * (1.0f / AB_DS_SCALE)));
             }
         }
     }

@@ -1550,6 +1550,19 @@ extern "C" int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, i
     return EOD_OK;
 }
 
+// x *= s (fp32, in place): puts the softmax-backward row term D on the scale of the scaled dS (see training.py: _attn_bwd)
+__global__ void scale_f32_kernel(float* __restrict__ x, long long n, float s) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= s;
+}
+extern "C" int eod_scale_f32(float* x, int64_t n, float s, void* stream) {
+    EOD_REQUIRE(x && n > 0, "scale_f32: bad args");
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, s);
+    EOD_CHECK_LAUNCH("scale_f32");
+    return EOD_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // nn.Dropout (ResBlock.out_layers[2], unet_openai.py:339): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p).
 // The mask is a pure function of (seed, layer, step, element) through Philox4x32-10 -- the backward re-derives it from the

@@ -423,10 +423,16 @@ class UNetTrainer:
         if Tp == T and os.environ.get("EOD_ATTN_BWD", "flash") != "nt":
             # dS = P * (dP - D) with dP = da v^T formed in the GEMM's accumulators only: D[n][h][t] = sum_j da*a (= rowsum(dP*P))
             # first, then the GEMM epilogue (bias_mode 3) subtracts D and multiplies by P -- the fp32 T x T dP never exists
+            # dS ~ (1/T) |dP - D| is a SUBNORMAL fp16 number at T in the thousands: it is kept on a 2^12 scale (alpha of the GEMM, D
+            # scaled to match), which the dq / dk products below divide out again (same device as csrc/attn_bwd.hip: AB_DS_SCALE)
+            ds_scale = 4096.0 if self.prog.precision == "fp16" else 1.0
             D = self._shared("attn_D", B * T, torch.float32)
             self._call(L.eod_rowdot, ptr(da.t), ptr(rec.a.t), dt, N, nh, T, T * Cc, d, Cc, d, ptr(D))
-            self._bop(lambda: bp.gemm(da.t, qkv.t, dS, T, T, d, Cc, 3 * Cc, Tp, bias=D, bias_mode=3, res=P, nb0=N, nb1=nh,
+            if ds_scale != 1.0:
+                self._call(L.eod_scale_f32, ptr(D), B * T, ds_scale)
+            self._bop(lambda: bp.gemm(da.t, qkv.t, dS, T, T, d, Cc, 3 * Cc, Tp, alpha=ds_scale, bias=D, bias_mode=3, res=P, nb0=N, nb1=nh,
                                       sa=(T * Cc, d), sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), b_off=vo))
+            alpha = alpha / ds_scale
         else:
             # dP[b][t][s] = sum_j da[n][t][h*d+j] * v[n][s][h][j], then the row-wise softmax backward
             dP = self._shared("attn_dP", B * T * Tp, torch.float32)

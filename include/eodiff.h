@@ -357,6 +357,9 @@ int eod_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t 
  * backward's D[n][head][t] = sum_j dO * O over one head's channels (rowsum(dP * P) without forming dP) */
 int eod_rowdot(const void* a, const void* b, int dtype, int64_t n0, int64_t n1, int64_t n2, int64_t s0, int64_t s1, int64_t s2, int d,
                float* out, void* stream);
+/* x[i] *= s (fp32, in place).  Training keeps dS = P (dP - D) of the materialised attention backward on a 2^12 scale so that it stays
+ * a NORMAL fp16 number at T in the thousands (P ~ 1/T): D is scaled with this before the dS GEMM, whose alpha carries the same factor */
+int eod_scale_f32(float* x, int64_t n, float s, void* stream);
 /* softmax backward on rows (QKVAttention, unet_openai.py:479): dS[r][j] = P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]),
  * P / dS storage dtype with row stride ldp, dP fp32 with row stride lds; columns n..ldp-1 of dS are written as zeros */
 /* fused attention forward on the NATURAL qkv layout [N][T][3C] (channel = q_off / k_off / v_off + head*head_stride + j; legacy
