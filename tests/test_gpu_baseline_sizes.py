@@ -209,6 +209,25 @@ def test_a1_13ch_training_step_vs_oracle_autograd(prec):
         assert rel_l2(dict(m.named_parameters())[k].grad.cpu(), gref[k]) < (2e-4 if prec == "fp32" else 1e-2), k
 
 
+def test_config5_full_size_forward_modes_agree():
+    """512 x 512 x 13 forward of the attention architecture (T = 16384 and 4096 keys per head): the fp32x3 mode (split-fp16 convs, fused
+    fp32 attention) and the fp16 mode (fp16 storage, flash attention) against the exact-fp32 mode (fp32 MFMA convs, materialised
+    fp32 attention) on the same weights -- three kernel sets, each pinned to the oracle at 256 x 256 above"""
+    S = 512
+    x = synth_input("c5f_x", (1, 13, S, S), 8).to(DEV)
+    t = torch.tensor([640]).to(DEV)
+    out = {}
+    for prec in ("fp32", "fp32x3", "fp16"):
+        m = _unet("A1", S, prec, 13).to(DEV).eval()
+        with torch.no_grad():
+            out[prec] = m(x, t).float().cpu()
+        del m
+        torch.cuda.empty_cache()
+    e3, e16 = rel_l2(out["fp32x3"], out["fp32"]), rel_l2(out["fp16"], out["fp32"])
+    print(f"A1 512x512x13 forward: fp32x3 vs exact fp32 {e3:.3e}, fp16 vs exact fp32 {e16:.3e}")
+    assert e3 < 1e-5 and e16 < 5e-3
+
+
 @pytest.mark.parametrize("arch,S,ch,N", [("A1", 512, 13, 1), ("A0", 256, 3, 2)])
 def test_full_size_training_step_fp16_vs_exact_fp32_mode(arch, S, ch, N):
     """BASELINE config 5 at its FULL per-GPU shape (512 x 512 x 13, attention at 128^2 = 16384 and 64^2 = 4096 positions, 8 heads) and
