@@ -209,6 +209,20 @@ def test_a1_13ch_training_step_vs_oracle_autograd(prec):
         assert rel_l2(dict(m.named_parameters())[k].grad.cpu(), gref[k]) < (2e-4 if prec == "fp32" else 1e-2), k
 
 
+@pytest.mark.parametrize("prec", ["fp32x3", "fp16"])
+def test_bench_shape_batch16_equals_its_shards_bit_for_bit(prec):
+    """The bench workload itself: A0 @ 256 x 256, batch 16 (8192-tile launches, XCD remap, 1.6 GB concat tensors).  Two DDPM steps with
+    the counter-based noise: the batch of 16 equals eight shards of 2 (what eight ranks of `bench.py --gpus 8` compute with their
+    sample_offset) bit for bit, and -- through the shard that the oracle test above pins -- the whole batch is tied to the oracle."""
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    m = EODiffusion(_unet("A0", 256, prec), timesteps=2, image_size=256, in_channels=3, device=DEV).to(DEV).eval()
+    full = m.sampling(16, device=DEV, rng="philox", seed=11, progress=False)
+    assert bool(torch.isfinite(full).all())
+    for k in (0, 3, 7):
+        part = m.sampling(2, device=DEV, rng="philox", seed=11, sample_offset=2 * k, progress=False)
+        assert torch.equal(part, full[2 * k:2 * k + 2]), k
+
+
 def test_config5_full_size_forward_modes_agree():
     """512 x 512 x 13 forward of the attention architecture (T = 16384 and 4096 keys per head): the fp32x3 mode (split-fp16 convs, fused
     fp32 attention) and the fp16 mode (fp16 storage, flash attention) against the exact-fp32 mode (fp32 MFMA convs, materialised
