@@ -71,11 +71,13 @@ template <bool FAST> __device__ __forceinline__ float silu_f(float v) {
 // per-channel tables live in registers (no per-chunk table loads, no 64-bit index divisions) and consecutive threads still cover
 // consecutive chunks of consecutive pixels.  U pixels per thread are in flight per trip.
 struct GnSlab {
-    int cpp, ry, per, P;
+    int cpp, ry, per, P, nz;  // nz channel blocks of cpp chunk columns (blockIdx.z) cover layers wider than 256 chunks per pixel
 };
 static inline GnSlab gn_slab(int N, int HW, int C, int epc, int unroll) {
     GnSlab g;
-    g.cpp = C / epc;
+    const int cols = C / epc;
+    g.nz = (cols + 255) / 256;
+    g.cpp = (cols + g.nz - 1) / g.nz;
     g.ry = 256 / g.cpp;
     if (g.ry < 1) g.ry = 1;
     const int quantum = g.ry * unroll;

@@ -19,12 +19,14 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, int HW, int C, float*
     const int CPP = blockDim.x, RY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int p = blockIdx.x, n = blockIdx.y;
+    const int col0 = blockIdx.z * CPP;          // first chunk column of this channel block
+    const bool col_ok = col0 + tx < C / EPC;    // (the last block of a wide layer may be partial)
     const int per = (HW + P - 1) / P;
-    const int p0 = p * per, p1 = min(HW, p0 + per);
+    const int p0 = p * per, p1 = col_ok ? min(HW, p0 + per) : 0;
     float s[EPC], q[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.0f;
-    const T* base = x + (long long)n * HW * C + (long long)tx * EPC;
+    const T* base = x + (long long)n * HW * C + (long long)(col0 + tx) * EPC;
     for (int pix = p0 + ty; pix < p1; pix += RY) {
         const i32x4 raw = *reinterpret_cast<const i32x4*>(base + (long long)pix * C);
         if constexpr (EPC == 8) {
@@ -56,8 +58,8 @@ __global__ void gn_partial_kernel(const T* __restrict__ x, int HW, int C, float*
     for (int i = tid; i < W2; i += nthr) {
         float a = 0.0f;
         for (int r = 0; r < RY; ++r) a += red[r * W2 + i];
-        const int c = i >> 1;
-        part[(((long long)n * P + p) * Ctot + coff + c) * 2 + (i & 1)] = a;
+        const int c = col0 * EPC + (i >> 1);
+        if (c < C) part[(((long long)n * P + p) * Ctot + coff + c) * 2 + (i & 1)] = a;
     }
 }
 
@@ -65,13 +67,12 @@ extern "C" int eod_gn_partial(const void* x, int dtype, int N, int HW, int C, fl
                               void* stream) {
     EOD_REQUIRE(x && part && N > 0 && HW > 0 && C > 0 && P > 0 && P <= HW, "gn_partial: bad args");
     const int epc = 16 / eod_esize(dtype);
-    EOD_REQUIRE(C % epc == 0 && C / epc <= 256, "gn_partial: C=%d unsupported", C);
+    EOD_REQUIRE(C % epc == 0 && N <= 65535, "gn_partial: C=%d / N=%d unsupported", C, N);
     EOD_REQUIRE(eod_aligned16(x), "gn_partial: alignment");
-    const int cpp = C / epc;
-    int ry = 256 / cpp;
-    if (ry < 1) ry = 1;
+    const GnSlab gs = gn_slab(N, HW, C, epc, 1);  // (only the channel decomposition is used: the slab count P is the caller's)
+    const int cpp = gs.cpp, ry = gs.ry;
     const size_t lds = (size_t)ry * cpp * epc * 2 * sizeof(float);
-    dim3 grid(P, N), block(cpp, ry);
+    dim3 grid(P, N, gs.nz), block(cpp, ry);
     if (dtype == EOD_F16)
         hipLaunchKernelGGL(gn_partial_kernel<half_t>, grid, block, lds, (hipStream_t)stream, (const half_t*)x, HW, C, part, P, Ctot, coff);
     else
@@ -167,16 +168,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     constexpr bool FAST = (EPC == 8);
     const int tx = threadIdx.x, ty = threadIdx.y, RY = blockDim.y;
     const int n = blockIdx.y;
+    const int col = blockIdx.z * blockDim.x + tx;  // chunk column of this thread (channel blocks along z for wide layers)
+    if (col >= C / EPC) return;
     const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
     float sc[EPC], sh[EPC];
-    const float* sp = ss + ((long long)n * Ctot + coff + tx * EPC) * 2;
+    const float* sp = ss + ((long long)n * Ctot + coff + col * EPC) * 2;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         sc[e] = sp[2 * e];
         sh[e] = sp[2 * e + 1];
     }
-    const T* xb = x + (long long)n * HW * C + tx * EPC;
-    T* yb = y + (long long)n * HW * Ctot + coff + tx * EPC;
+    const T* xb = x + (long long)n * HW * C + col * EPC;
+    T* yb = y + (long long)n * HW * Ctot + coff + col * EPC;
     for (int pix = p0 + ty; pix < p1; pix += U * RY) {
         i32x4 raw[U];
 #pragma unroll
@@ -217,10 +220,10 @@ extern "C" int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, cons
     EOD_REQUIRE(x && y && scale_shift && N > 0 && HW > 0 && C > 0, "gn_apply: bad args");
     const int epc = 16 / eod_esize(dtype);
     EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_apply: channel alignment");
-    EOD_REQUIRE(C / epc <= 256 && N <= 65535, "gn_apply: C=%d / N=%d unsupported", C, N);
+    EOD_REQUIRE(N <= 65535, "gn_apply: N=%d unsupported", N);
     EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(y), "gn_apply: alignment");
     const GnSlab g = gn_slab(N, HW, C, epc, 4);
-    const dim3 grid(g.P, N), block(g.cpp, g.ry);
+    const dim3 grid(g.P, N, g.nz), block(g.cpp, g.ry);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(T, S) hipLaunchKernelGGL((gn_apply_kernel<T, S>), grid, block, 0, st, (const T*)x, HW, C, scale_shift, Ctot, coff, (T*)y, g.per)
     if (dtype == EOD_F16) {

@@ -378,17 +378,20 @@ __global__ void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restri
     const int CPP = blockDim.x, RY = blockDim.y;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int p = blockIdx.x, n = blockIdx.y;
+    const int col0 = blockIdx.z * CPP;          // first chunk column of this channel block (wide layers: several blocks along z)
+    const bool col_ok = col0 + tx < C / EPC;
+    const int colc = col_ok ? col0 + tx : 0;
     const int per = (HW + P - 1) / P;
-    const int p0 = p * per, p1 = min(HW, p0 + per);
+    const int p0 = p * per, p1 = col_ok ? min(HW, p0 + per) : 0;
     float sa[EPC], sb[EPC], sc[EPC], sh[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         sa[e] = sb[e] = 0.0f;
-        sc[e] = ss[((long long)n * Ctot + coff + tx * EPC + e) * 2 + 0];
-        sh[e] = ss[((long long)n * Ctot + coff + tx * EPC + e) * 2 + 1];
+        sc[e] = ss[((long long)n * Ctot + coff + colc * EPC + e) * 2 + 0];
+        sh[e] = ss[((long long)n * Ctot + coff + colc * EPC + e) * 2 + 1];
     }
-    const T* xb = x + (long long)n * HW * C + (long long)tx * EPC;
-    const T* db = dy + (long long)n * HW * Ctot + coff + (long long)tx * EPC;
+    const T* xb = x + (long long)n * HW * C + (long long)colc * EPC;
+    const T* db = dy + (long long)n * HW * Ctot + coff + (long long)colc * EPC;
     constexpr int U = 2;  // pixels in flight per thread; the accumulation order stays pixel-ascending per thread
     for (int pix = p0 + ty; pix < p1; pix += U * RY) {
         T xv[U][EPC], dv[U][EPC];
@@ -424,8 +427,8 @@ __global__ void gn_bwd_partial_kernel(const T* __restrict__ x, const T* __restri
     for (int i = tid; i < W2; i += nthr) {
         float a = 0.0f;
         for (int r = 0; r < RY; ++r) a += red[r * W2 + i];
-        const int c = i >> 1;
-        part[(((long long)n * P + p) * Ctot + coff + c) * 2 + (i & 1)] = a;
+        const int c = col0 * EPC + (i >> 1);
+        if (c < C) part[(((long long)n * P + p) * Ctot + coff + c) * 2 + (i & 1)] = a;
     }
 }
 
@@ -433,13 +436,12 @@ extern "C" int eod_gn_bwd_partial(const void* x, const void* dy, const float* sc
                                   int P, int Ctot, int coff, int silu, void* stream) {
     EOD_REQUIRE(x && dy && scale_shift && part && N > 0 && HW > 0 && C > 0 && P > 0 && P <= HW, "gn_bwd_partial: bad args");
     const int epc = 16 / eod_esize(dtype);
-    EOD_REQUIRE(C % epc == 0 && C / epc <= 256 && Ctot % epc == 0 && coff % epc == 0, "gn_bwd_partial: C=%d Ctot=%d coff=%d unsupported", C, Ctot, coff);
+    EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0 && N <= 65535, "gn_bwd_partial: C=%d Ctot=%d coff=%d unsupported", C, Ctot, coff);
     EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(dy), "gn_bwd_partial: alignment");
-    const int cpp = C / epc;
-    int ry = 256 / cpp;
-    if (ry < 1) ry = 1;
+    const GnSlab gs = gn_slab(N, HW, C, epc, 1);  // (channel decomposition only: the slab count P is the caller's)
+    const int cpp = gs.cpp, ry = gs.ry;
     const size_t lds = (size_t)ry * cpp * epc * 2 * sizeof(float);
-    dim3 grid(P, N), block(cpp, ry);
+    dim3 grid(P, N, gs.nz), block(cpp, ry);
     if (dtype == EOD_F16)
         hipLaunchKernelGGL(gn_bwd_partial_kernel<half_t>, grid, block, lds, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy, scale_shift, HW, C, part, P, Ctot, coff, silu);
     else
@@ -572,10 +574,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     constexpr bool FAST = (EPC == 8);
     const int tx = threadIdx.x, ty = threadIdx.y, RY = blockDim.y;
     const int n = blockIdx.y;
+    const int col = blockIdx.z * blockDim.x + tx;  // chunk column (channel blocks along z for wide layers)
+    if (col >= C / EPC) return;
     const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
     float sc[EPC], sh[EPC], k1[EPC], k2[EPC], k3[EPC];
-    const float* sp = ss + ((long long)n * Ctot + coff + tx * EPC) * 2;
-    const float* kp = coef + ((long long)n * Ctot + coff + tx * EPC) * 3;
+    const float* sp = ss + ((long long)n * Ctot + coff + col * EPC) * 2;
+    const float* kp = coef + ((long long)n * Ctot + coff + col * EPC) * 3;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         sc[e] = sp[2 * e];
@@ -584,11 +588,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         k2[e] = kp[3 * e + 1];
         k3[e] = kp[3 * e + 2];
     }
-    const long long xoff = (long long)n * HW * C + tx * EPC;
+    const long long xoff = (long long)n * HW * C + col * EPC;
     const T* xb = x + xoff;
     const T* ab = ADD ? add + xoff : nullptr;
     T* ob = dx + xoff;
-    const T* db = dy + (long long)n * HW * Ctot + coff + tx * EPC;
+    const T* db = dy + (long long)n * HW * Ctot + coff + col * EPC;
     for (int pix = p0 + ty; pix < p1; pix += U * RY) {
         T xv[U][EPC], dv[U][EPC], av[U][EPC];
 #pragma unroll
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
 template <typename T>
 static void launch_gn_bwd_apply(const GnSlab& g, int N, bool silu, hipStream_t st, const T* x, const T* dy, const float* ss, const float* coef,
                                 const T* add, int HW, int C, int Ctot, int coff, T* dx) {
-    const dim3 grid(g.P, N), block(g.cpp, g.ry);
+    const dim3 grid(g.P, N, g.nz), block(g.cpp, g.ry);
 #define LAUNCH(S, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, S, A>), grid, block, 0, st, x, dy, ss, coef, add, HW, C, Ctot, coff, dx, g.per)
     if (silu) {
         if (add) LAUNCH(true, true); else LAUNCH(true, false);
@@ -637,7 +641,7 @@ extern "C" int eod_gn_bwd_apply(const void* x, const void* dy, const float* scal
     EOD_REQUIRE(x && dy && scale_shift && coef && dx && N > 0 && HW > 0 && C > 0, "gn_bwd_apply: bad args");
     const int epc = 16 / eod_esize(dtype);
     EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_bwd_apply: channel alignment");
-    EOD_REQUIRE(C / epc <= 256 && N <= 65535, "gn_bwd_apply: C=%d / N=%d unsupported", C, N);
+    EOD_REQUIRE(N <= 65535, "gn_bwd_apply: N=%d unsupported", N);
     EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(dy) && eod_aligned16(dx) && (!add || eod_aligned16(add)), "gn_bwd_apply: alignment");
     const GnSlab g = gn_slab(N, HW, C, epc, 2);
     hipStream_t st = (hipStream_t)stream;

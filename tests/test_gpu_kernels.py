@@ -118,7 +118,8 @@ def test_conv_fused_epilogue_concat_residual_temb(prec, dims):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
-@pytest.mark.parametrize("shape", [(2, 32, 8, 8), (2, 96, 7, 7), (1, 128, 32, 32), (3, 224, 5, 3), (2, 1024, 4, 4)])
+@pytest.mark.parametrize("shape", [(2, 32, 8, 8), (2, 96, 7, 7), (1, 128, 32, 32), (3, 224, 5, 3), (2, 1024, 4, 4),
+                                   (2, 1280, 6, 5), (1, 2560, 3, 3)])  # (the last two: more than 256 16-byte chunks per pixel -> channel blocks)
 @pytest.mark.parametrize("silu", [True, False])
 def test_group_norm_silu(prec, shape, silu):
     x = synth_input(f"gx{shape}", shape, 33, scale=2.0) + 0.5
@@ -491,3 +492,55 @@ def test_conv1x1_backward_weights_kernel(N, H, W, Cx, Cy, Cout):
         _lib.check(L.eod_wgrad_reduce(partial.data_ptr(), S, 1, Cout, Cx, Cx, 0, Cx, 1.0, dw.data_ptr(), st), "wgrad_reduce")
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu(), ref) < 2e-3, (S, rel_l2(dw.cpu(), ref))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("N,C0,C1,H,W,silu", [(2, 64, 0, 8, 8, True), (2, 104, 88, 7, 5, True), (1, 1280, 0, 6, 5, True), (2, 1536, 1024, 3, 3, False)])
+def test_group_norm_silu_backward_kernels(prec, N, C0, C1, H, W, silu):
+    """the GroupNorm32(+SiLU) backward chain (statistics -> eod_gn_mean_rstd -> eod_gn_bwd_partial -> _finalize -> _params / _apply)
+    over one or two concat sources against torch autograd, called through the C ABI; the wide cases need several channel blocks
+    (more than 256 16-byte chunks per pixel) and a group that straddles the concat seam"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    td, dt = (torch.float32, _lib.EOD_F32) if prec == "fp32" else (torch.float16, _lib.EOD_F16)
+    Ct, HW, G = C0 + C1, H * W, 32
+    x = (synth_input(f"gbx{N}{Ct}{H}", (N, Ct, H, W), 51, scale=1.5) + 0.3).to(td).float()
+    dy = synth_input(f"gby{N}{Ct}{H}", (N, Ct, H, W), 52).to(td).float()
+    gam = 1.0 + 0.2 * synth_input("gbg", (Ct,), 53)
+    bet = 0.1 * synth_input("gbb", (Ct,), 53)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = F.group_norm(xr, G, gr, br, eps=1e-5)
+    if silu:
+        y = F.silu(y)
+    y.backward(dy)
+    st = current_stream_ptr(torch.device(DEV))
+    nhwc = lambda t4: t4.permute(0, 2, 3, 1).contiguous().to(td).to(DEV)
+    srcs = [(nhwc(x[:, :C0]), C0, 0)] + ([(nhwc(x[:, C0:]), C1, C0)] if C1 else [])
+    dyd = nhwc(dy)
+    P = max(1, min(256, HW // 64))
+    f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=DEV)
+    parts = [f32(N, P, c, 2) for _, c, _ in srcs]
+    for (xs, c, _), pt in zip(srcs, parts):
+        _lib.check(L.eod_gn_partial(xs.data_ptr(), dt, N, HW, c, pt.data_ptr(), P, c, 0, st), "gn_partial")
+    p1 = (parts[1].data_ptr(), P, C1) if C1 else (0, 0, 0)
+    ss, mr = f32(N, Ct, 2), f32(N, G, 2)
+    gd, bd = gam.to(DEV), bet.to(DEV)
+    _lib.check(L.eod_gn_finalize(parts[0].data_ptr(), P, C0, p1[0], p1[1], p1[2], N, HW, G, 1e-5, gd.data_ptr(), bd.data_ptr(), 0, 0, ss.data_ptr(), st), "gn_finalize")
+    _lib.check(L.eod_gn_mean_rstd(parts[0].data_ptr(), P, C0, p1[0], p1[1], p1[2], N, HW, G, 1e-5, mr.data_ptr(), st), "gn_mean_rstd")
+    part, coef, gb = f32(N, P, Ct, 2), f32(N, Ct, 3), f32(N, Ct, 2)
+    for xs, c, off in srcs:
+        _lib.check(L.eod_gn_bwd_partial(xs.data_ptr(), dyd.data_ptr(), ss.data_ptr(), dt, N, HW, c, part.data_ptr(), P, Ct, off, int(silu), st), "gn_bwd_partial")
+    _lib.check(L.eod_gn_bwd_finalize(part.data_ptr(), P, Ct, N, HW, G, mr.data_ptr(), gd.data_ptr(), bd.data_ptr(), 0, 0, 0, 0, coef.data_ptr(), gb.data_ptr(), st), "gn_bwd_finalize")
+    dgam, dbet = f32(Ct), f32(Ct)
+    _lib.check(L.eod_gn_bwd_params(gb.data_ptr(), N, Ct, 1.0, dgam.data_ptr(), dbet.data_ptr(), st), "gn_bwd_params")
+    dxs = []
+    for xs, c, off in srcs:
+        dx = torch.empty_like(xs)
+        _lib.check(L.eod_gn_bwd_apply(xs.data_ptr(), dyd.data_ptr(), ss.data_ptr(), coef.data_ptr(), 0, dt, N, HW, c, Ct, off, int(silu), dx.data_ptr(), st), "gn_bwd_apply")
+        dxs.append(dx.float().cpu().permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    tol = 2e-5 if prec == "fp32" else 3e-3
+    assert rel_l2(torch.cat(dxs, 1), xr.grad) < tol
+    assert rel_l2(dgam.cpu(), gr.grad) < tol and rel_l2(dbet.cpu(), br.grad) < tol
