@@ -244,7 +244,7 @@ def test_config5_full_size_forward_modes_agree():
     assert e3 < 1e-5 and e16 < 5e-3
 
 
-@pytest.mark.parametrize("arch,S,ch,N", [("A1", 512, 13, 1), ("A0", 256, 3, 2)])
+@pytest.mark.parametrize("arch,S,ch,N", [("A1", 512, 13, 1), ("A0", 256, 3, 2), ("A1", 256, 3, 2)])
 def test_full_size_training_step_fp16_vs_exact_fp32_mode(arch, S, ch, N):
     """BASELINE config 5 at its FULL per-GPU shape (512 x 512 x 13, attention at 128^2 = 16384 and 64^2 = 4096 positions, 8 heads) and
     the metric's architecture at 256 x 256 (one 512-wide head over 1024 positions: the materialised attention backward).  The CPU
