@@ -28,6 +28,13 @@ typedef __attribute__((address_space(3))) void lds_void_b;
 // inf there is caught by the guarded optimizer step like any other fp16 overflow).
 #define AB_P_SCALE 256.0f
 #define AB_DS_SCALE 4096.0f
+// The softmax work per score element is what bounds these kernels at small head dims (d = 32: ~8 VALU slots per element against 2 x 32
+// MACs), so the scales cost nothing: they ride in the exponent.  P x 2^8 = exp2(s * alpha*log2(e) - (lse*log2(e) - 8)) is ONE fma + one
+// v_exp_f32 with the per-row constant prepared where lse is staged; dS x 2^12 = (P x 2^8) * (16 dP - 16 D) is one fma + one multiply.
+#define AB_LOG2E 1.4426950408889634f
+#define AB_P_LOG2 8.0f                                  // log2(AB_P_SCALE)
+#define AB_DS_LOG2 12.0f                                // log2(AB_DS_SCALE)
+#define AB_DS_OVER_P (AB_DS_SCALE / AB_P_SCALE)         // 16
 
 struct AttnBwdP {
     const char* qkv;
@@ -123,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
         ab_stage(ro, rsC, ob, qt * 64, 8, p.d, sO + buf * 64 * AB_ROWB, wave, lane, 4, p.T);
         if (tid < 64) {  // rows beyond T: lse = +inf makes their P exactly 0
             const bool in = qt * 64 + tid < p.T;
-            sL[buf * 64 + tid] = in ? lse[qt * 64 + tid] : INFINITY;
-            sL[128 + buf * 64 + tid] = in ? Dv[qt * 64 + tid] : 0.0f;
+            sL[buf * 64 + tid] = in ? lse[qt * 64 + tid] * AB_LOG2E - AB_P_LOG2 : INFINITY;   // exponent offset of P x 2^8 (log2 domain)
+            sL[128 + buf * 64 + tid] = in ? Dv[qt * 64 + tid] * AB_DS_OVER_P : 0.0f;         // 16 D
         }
     };
     stage_q(0, 0);
@@ -137,6 +144,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
 
     const int nqt = (p.T + 63) / 64;
     const bool key_ok = s0 + wave * 32 + lr < p.T;  // this lane's key column exists (ragged last key tile)
+    const bool ragged_keys = s0 + 128 > p.T;         // block-uniform: only the last key block of a ragged sequence needs the mask
+    const float a2 = p.alpha * AB_LOG2E;
     for (int qt = 0; qt < nqt; ++qt) {
         const int buf = qt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -174,9 +183,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(tD + qrow);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pe = key_ok ? __expf(s[mt][4 * g4 + e] * p.alpha - l4[e]) : 0.0f;
-                    s[mt][4 * g4 + e] = pe * AB_P_SCALE;
-                    dp[mt][4 * g4 + e] = pe * (dp[mt][4 * g4 + e] - d4[e]) * AB_DS_SCALE;
+                    float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][4 * g4 + e], a2, -l4[e]));  // P x 2^8 (0 for rows beyond T: l4 = +inf)
+                    if (ragged_keys) pe = key_ok ? pe : 0.0f;
+                    s[mt][4 * g4 + e] = pe;
+                    dp[mt][4 * g4 + e] = pe * fmaf(dp[mt][4 * g4 + e], AB_DS_OVER_P, -d4[e]);  // dS x 2^12
                 }
             }
         // ---- dV += P^T dO,  dK += dS^T Q   (contraction over the 64 queries, permuted order) ----
@@ -234,8 +244,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
     const long long qb = (long long)(p.q_off + h * p.hs) * 2, kb_ = (long long)(p.k_off + h * p.hs) * 2, vb = (long long)(p.v_off + h * p.hs) * 2;
     const long long ob = (long long)h * p.d * 2;
     const int myq = q0 + wave * 32 + lr;
-    const float my_lse = myq < p.T ? p.lse[((long long)n * p.heads + h) * p.T + myq] : INFINITY;  // +inf: P = 0 for rows beyond T
+    // exponent offset of P x 2^12 in the log2 domain (+inf: P = 0 for rows beyond T)
+    const float my_l2 = myq < p.T ? p.lse[((long long)n * p.heads + h) * p.T + myq] * AB_LOG2E - AB_DS_LOG2 : INFINITY;
     const float my_D = myq < p.T ? p.D[((long long)n * p.heads + h) * p.T + myq] : 0.0f;
+    const float a2 = p.alpha * AB_LOG2E;
 
     ab_stage(rq, rs3, qb, q0, 16, p.d, sQ, wave, lane, 4, p.T);
     ab_stage(ro, rsC, ob, q0, 16, p.d, sO, wave, lane, 4, p.T);
@@ -280,12 +292,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pe = __expf(s[mt][r] * p.alpha - my_lse);
+                float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][r], a2, -my_l2));  // P x 2^12
                 if ((kt + 1) * 64 > p.T) {  // wave-uniform: ragged last key tile, keys beyond T contribute nothing
                     const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     pe = key < p.T ? pe : 0.0f;
                 }
-                dp[mt][r] = pe * (dp[mt][r] - my_D) * AB_DS_SCALE;  // dS^T (scaled, see AB_DS_SCALE)
+                dp[mt][r] = pe * (dp[mt][r] - my_D);  // dS^T x 2^12
             }
         // ---- dQ += dS K  (contraction over the 64 keys held in registers, permuted order; B = K rows via transposed reads) ----
 #pragma unroll
@@ -382,16 +394,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float t = s[mt][r] * p.scale_log2;
+                float t = s[mt][r];  // raw q.k: the 1/sqrt(d) * log2(e) factor is positive, so the maximum is taken before it ...
                 if (ragged) {
                     const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     t = key < p.T ? t : -INFINITY;
+                    s[mt][r] = t;
                 }
-                s[mt][r] = t;
                 mloc = fmaxf(mloc, t);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);   // finite: every tile has at least one valid key
+        const float m_new = fmaxf(m_run, mloc * p.scale_log2);   // finite: every tile has at least one valid key
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // raw v_exp_f32: arguments are <= 0; 0 on the first tile
         m_run = m_new;
         float lsum = 0.0f;
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[mt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[mt][r], p.scale_log2, -m_new));  // ... and applied inside the exponent's fma
                 s[mt][r] = e;
                 lsum += e;
             }

@@ -171,24 +171,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float t = s[mt][r] * p.scale_log2;
+                float t = s[mt][r];  // raw scores: the (positive) scale is applied inside the exponent's fma below -- one rounding
                 if (ragged) {
                     const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     t = key < p.T ? t : -INFINITY;
+                    s[mt][r] = t;
                 }
-                s[mt][r] = t;
                 mloc = fmaxf(mloc, t);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, mloc * p.scale_log2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // raw v_exp_f32 (1 ulp; arguments <= 0, underflow to 0 is the intent)
         m_run = m_new;
         float lsum = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[mt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[mt][r], p.scale_log2, -m_new));
                 s[mt][r] = e;
                 lsum += e;
             }
