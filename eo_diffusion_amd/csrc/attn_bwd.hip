@@ -16,6 +16,7 @@
 // dO / O [N][T][C], lse / D [N][heads][T] fp32, dqkv [N][T][3C].  Any T (rows / keys beyond T are zero-filled and masked through
 // lse = +inf / P = 0), d % 8 == 0, d <= 64.
 #include "common.h"
+#include <type_traits>
 
 typedef __fp16 fp16x4b __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) void lds_void_b;
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
         for (int r = 0; r < 16; ++r) dv[t][r] = dk[t][r] = 0.0f;
 
     const int nqt = (p.T + 63) / 64;
-    const bool key_ok = s0 + wave * 32 + lr < p.T;  // this lane's key column exists (ragged last key tile)
-    const bool ragged_keys = s0 + 128 > p.T;         // block-uniform: only the last key block of a ragged sequence needs the mask
+    // Keys beyond T need no mask here: a key is a LANE of both products' outputs (dV / dK rows), its column of P / dS feeds only its
+    // own two rows, and rows >= T are never stored (K / V rows beyond T are zero-filled, so those values are finite).
     const float a2 = p.alpha * AB_LOG2E;
     for (int qt = 0; qt < nqt; ++qt) {
         const int buf = qt & 1;
@@ -183,8 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(tD + qrow);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][4 * g4 + e], a2, -l4[e]));  // P x 2^8 (0 for rows beyond T: l4 = +inf)
-                    if (ragged_keys) pe = key_ok ? pe : 0.0f;
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][4 * g4 + e], a2, -l4[e]));  // P x 2^8 (0 for rows beyond T: l4 = +inf)
                     s[mt][4 * g4 + e] = pe;
                     dp[mt][4 * g4 + e] = pe * fmaf(dp[mt][4 * g4 + e], AB_DS_OVER_P, -d4[e]);  // dS x 2^12
                 }
@@ -292,11 +292,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][r], a2, -my_l2));  // P x 2^12
-                if ((kt + 1) * 64 > p.T) {  // wave-uniform: ragged last key tile, keys beyond T contribute nothing
-                    const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    pe = key < p.T ? pe : 0.0f;
-                }
+                // (keys beyond T need no mask: their K rows are zero-filled, so a finite dS there adds exactly 0 to dQ)
+                const float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][r], a2, -my_l2));  // P x 2^12
                 dp[mt][r] = pe * (dp[mt][r] - my_D);  // dS^T x 2^12
             }
         // ---- dQ += dS K  (contraction over the 64 keys held in registers, permuted order; B = K rows via transposed reads) ----
@@ -369,7 +366,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
         for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;  // running max (log2 domain) / this lane's share of the running sum
     const int nkt = (p.T + 63) / 64;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one key tile; RAGGED (compile-time) = the last tile of a sequence that is not a multiple of 64: only that instance carries the
+    // per-element key mask (as a run-time `if` inside one body the compiler turned it into a compare + select per element in EVERY
+    // tile: 10 VALU instructions per score element instead of 4.5, profiles/r02_c_attention_pmc.txt)
+    auto tile = [&](const int kt, auto ragged_c) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -389,18 +390,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
         }
         // ---- online softmax over this tile's 64 keys (32 in this lane's registers, 32 in lane ^ 32) ----
         float mloc = -INFINITY;
-        const bool ragged = (kt + 1) * 64 > p.T;  // wave-uniform: only the last tile of a ragged sequence needs the key mask
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float t = s[mt][r];  // raw q.k: the 1/sqrt(d) * log2(e) factor is positive, so the maximum is taken before it ...
-                if (ragged) {
+                if constexpr (RAGGED) {
                     const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    t = key < p.T ? t : -INFINITY;
-                    s[mt][r] = t;
+                    s[mt][r] = key < p.T ? s[mt][r] : -INFINITY;
                 }
-                mloc = fmaxf(mloc, t);
+                mloc = fmaxf(mloc, s[mt][r]);  // raw q.k: the 1/sqrt(d) * log2(e) factor is positive, so the maximum is taken before it ...
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc * p.scale_log2);   // finite: every tile has at least one valid key
@@ -431,7 +429,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
 #pragma unroll
                 for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab_tr_frag(tV, mt * 32 + 16 * kb, t * 32, lane), fp, o[t], 0, 0, 0);
             }
-    }
+    };
+    const int nfull = (p.T & 63) ? nkt - 1 : nkt;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nkt - 1, std::true_type{});
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int q = q0 + wave * 32 + lr;

@@ -14,6 +14,7 @@
 // Layout: qkv [N][T][3C] fp32 as produced by the qkv projection (channel = q_off / k_off / v_off + head*head_stride + j),
 // out [N][T][C] fp32, optional lse [N][heads][T].  Any T, d % 8 == 0, d <= 64.
 #include "common.h"
+#include <type_traits>
 
 typedef __fp16 fp16x4c __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -145,7 +146,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
     float m_run = -INFINITY, l_run = 0.0f;
     const int nkt = (p.T + 63) / 64;
     load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one key tile; RAGGED (compile-time) = the last tile of a sequence that is not a multiple of 64 keys: only that instance carries
+    // the per-element key mask (see attn_fwd_nat_kernel in attn_bwd.hip)
+    auto tile = [&](const int kt, auto ragged_c) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
         __syncthreads();  // every wave is done reading the previous tile
         store_tile();     // (waits for this tile's global loads)
         __syncthreads();  // tile kt is visible
@@ -166,18 +170,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
             }
         // ---- online softmax over this tile's 64 keys (32 in this lane's registers, 32 in lane ^ 32), fp32 ----
         float mloc = -INFINITY;
-        const bool ragged = (kt + 1) * 64 > p.T;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float t = s[mt][r];  // raw scores: the (positive) scale is applied inside the exponent's fma below -- one rounding
-                if (ragged) {
+                if constexpr (RAGGED) {
                     const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    t = key < p.T ? t : -INFINITY;
-                    s[mt][r] = t;
+                    s[mt][r] = key < p.T ? s[mt][r] : -INFINITY;
                 }
-                mloc = fmaxf(mloc, t);
+                mloc = fmaxf(mloc, s[mt][r]);  // raw scores: the (positive) scale is applied inside the exponent's fma below -- one rounding
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc * p.scale_log2);
@@ -219,7 +220,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[t], 0, 0, 0);
                 }
             }
-    }
+    };
+    const int nfull = (p.T & 63) ? nkt - 1 : nkt;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nkt - 1, std::true_type{});
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / (l_tot * AX_SCALE);
     const int q = q0 + wave * 32 + lr;
