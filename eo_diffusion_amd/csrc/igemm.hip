@@ -900,8 +900,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 
     // ---- patch pieces of this wave: group gi = wave + 4*i, patch row = gi*8 + (lane>>3), slot = lane&7 ----
     const int srow = lane >> 3, sslot = lane & 7;
-    unsigned pv0[LAH], pv1[LAH];
-    int pchunk[LAH];
+    // Register diet (the GN + split instance sits at the 256-VGPR limit of two workgroups per CU): the swizzled slot of a lane is the
+    // SAME for all of its pieces -- row = (wave + NW*i)*8 + srow, and (NW*i*8) >> 1 is a multiple of 8 -- so one register serves every
+    // piece (pchunk0, also for the weight rows), and a piece keeps its pixel index only (the byte offset of either concat source is
+    // one multiply at issue time, six times per chunk).
+    unsigned ppix[LAH];
+    const int pchunk0 = sslot ^ ((4 * wave + (srow >> 1)) & 7);
     unsigned pvalid = 0;  // bit i: this lane's row of piece i lies inside the image (zero padding must stay zero)
 #pragma unroll
     for (int i = 0; i < LAH; ++i) {
@@ -909,19 +913,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         const int py = prow / PW, px = prow - py * PW;
         const int hi = (UPS ? g.ty0 / 2 : g.ty0) - 1 + py, wi = (UPS ? g.tx0 / 2 : g.tx0) - 1 + px;
         const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        pchunk[i] = sslot ^ ((prow >> 1) & 7);
         if (ok) pvalid |= 1u << i;
-        const unsigned pix = (unsigned)(hi * p.W + wi);
-        pv0[i] = ok ? pix * (unsigned)(p.C0 * ES) + pchunk[i] * 16 : EOD_OOB;
-        pv1[i] = ok ? pix * (unsigned)(p.C1 * ES) + pchunk[i] * 16 : EOD_OOB;
+        ppix[i] = (unsigned)(hi * p.W + wi);
     }
     unsigned b_v[LB];
-    int b_chunk[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int row = (wave + NW * i) * 8 + srow;
-        b_chunk[i] = sslot ^ ((row >> 1) & 7);
-        b_v[i] = (n0 + row < p.Ncols) ? (unsigned)(row * p.Cin * ES) + b_chunk[i] * 16 : EOD_OOB;
+        b_v[i] = (n0 + row < p.Ncols) ? (unsigned)(row * p.Cin * ES) + pchunk0 * 16 : EOD_OOB;
     }
     const __amdgpu_buffer_rsrc_t rsA0 = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES);
     const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(p.a1 ? p.a1 + (long long)g.n_first * p.H * p.W * p.C1 * ES : p.a0);
@@ -950,8 +949,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         return c;
     };
     auto issue_patch_piece = [&](int i, const Chunk& c, char* abuf) {
-        unsigned v = c.src ? pv1[i] : pv0[i];
-        if (c.ktail) v = (c.kin + pchunk[i] * EPC < c.cw) ? v : EOD_OOB;
+        unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(c.cw * ES) + pchunk0 * 16 : EOD_OOB;
+        if (c.ktail) v = (c.kin + pchunk0 * EPC < c.cw) ? v : EOD_OOB;
         if (c.src)
             blds16(rsA1, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
         else
@@ -967,12 +966,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void*)ssbuf, 16, v, 0, 0, 0);
     };
     auto transform_piece = [&](int i, const Chunk& c, char* abuf, const char* ssbuf) {
-        const bool ok = ((pvalid >> i) & 1u) && (!c.ktail || (c.kin + pchunk[i] * EPC < c.cw));
+        const bool ok = ((pvalid >> i) & 1u) && (!c.ktail || (c.kin + pchunk0 * EPC < c.cw));
         char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
         const i32x4 raw = *reinterpret_cast<const i32x4*>(ptr);
         i32x4 outv = raw;
         if constexpr (GN) {
-            const float* sp = reinterpret_cast<const float*>(ssbuf) + pchunk[i] * EPC * 2;
+            const float* sp = reinterpret_cast<const float*>(ssbuf) + pchunk0 * EPC * 2;
             if constexpr (ES == 2) {
                 const half8 h = __builtin_bit_cast(half8, raw);
                 half8 o;
@@ -1008,7 +1007,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
             f32x4 f = __builtin_bit_cast(f32x4, outv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
-            *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk[i] & 1) != 0);
+            *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk0 & 1) != 0);
         } else {
             if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
         }
@@ -1018,7 +1017,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             unsigned v = b_v[i];
-            if (c.ktail) v = (c.kin + (SPLIT ? (b_chunk[i] >> 1) * 8 : b_chunk[i] * EPC) < c.cw) ? v : EOD_OOB;
+            if (c.ktail) v = (c.kin + (SPLIT ? (pchunk0 >> 1) * 8 : pchunk0 * EPC) < c.cw) ? v : EOD_OOB;
             blds16(rsB, v, soff, bst + (wave + NW * i) * 1024);
         }
     };
