@@ -900,12 +900,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 
     // ---- patch pieces of this wave: group gi = wave + 4*i, patch row = gi*8 + (lane>>3), slot = lane&7 ----
     const int srow = lane >> 3, sslot = lane & 7;
-    // Register diet (the GN + split instance sits at the 256-VGPR limit of two workgroups per CU): the swizzled slot of a lane is the
-    // SAME for all of its pieces -- row = (wave + NW*i)*8 + srow, and (NW*i*8) >> 1 is a multiple of 8 -- so one register serves every
-    // piece (pchunk0, also for the weight rows), and a piece keeps its pixel index only (the byte offset of either concat source is
-    // one multiply at issue time, six times per chunk).
+    // PATCH SWIZZLE: the 16-byte chunk c of patch row (py, px) lives in slot c ^ key(px), key(px) = (px >> 1) & 7 -- a function of the
+    // patch COLUMN only.  A fragment read covers 16 consecutive columns of one patch row, so the conflict-free property is the one of
+    // the (row >> 1) & 7 key of the GEMM tiles, and a tap shift by (dy, dx) changes the key only through dx: the fragment addresses of a
+    // lane are three registers (one per dx) plus compile-time offsets (see `acur` below) instead of ~40 VALU instructions per tap.
+    // Register diet (the GN + split instance sits at the 256-VGPR limit of two workgroups per CU): the chunk of a lane's slot is three
+    // bits per piece, packed into one register; a piece keeps its pixel index only (the byte offset of either concat source is one
+    // multiply at issue time, six times per chunk); the weight rows keep the (row >> 1) & 7 key, one value for all pieces of a lane
+    // ((NW*i*8) >> 1 is a multiple of 8).
     unsigned ppix[LAH];
-    const int pchunk0 = sslot ^ ((4 * wave + (srow >> 1)) & 7);
+    const int bchunk0 = sslot ^ ((4 * wave + (srow >> 1)) & 7);
+    unsigned pck = 0;     // 3 bits per piece: chunk held by this lane's slot
     unsigned pvalid = 0;  // bit i: this lane's row of piece i lies inside the image (zero padding must stay zero)
 #pragma unroll
     for (int i = 0; i < LAH; ++i) {
@@ -915,12 +920,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         if (ok) pvalid |= 1u << i;
         ppix[i] = (unsigned)(hi * p.W + wi);
+        pck |= (unsigned)(sslot ^ ((px >> 1) & 7)) << (3 * i);
     }
+    auto pchunk_of = [&](int i) { return (int)((pck >> (3 * i)) & 7u); };
     unsigned b_v[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int row = (wave + NW * i) * 8 + srow;
-        b_v[i] = (n0 + row < p.Ncols) ? (unsigned)(row * p.Cin * ES) + pchunk0 * 16 : EOD_OOB;
+        b_v[i] = (n0 + row < p.Ncols) ? (unsigned)(row * p.Cin * ES) + bchunk0 * 16 : EOD_OOB;
     }
     const __amdgpu_buffer_rsrc_t rsA0 = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES);
     const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(p.a1 ? p.a1 + (long long)g.n_first * p.H * p.W * p.C1 * ES : p.a0);
@@ -949,8 +956,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         return c;
     };
     auto issue_patch_piece = [&](int i, const Chunk& c, char* abuf) {
-        unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(c.cw * ES) + pchunk0 * 16 : EOD_OOB;
-        if (c.ktail) v = (c.kin + pchunk0 * EPC < c.cw) ? v : EOD_OOB;
+        const int pc = pchunk_of(i);
+        unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(c.cw * ES) + pc * 16 : EOD_OOB;
+        if (c.ktail) v = (c.kin + pc * EPC < c.cw) ? v : EOD_OOB;
         if (c.src)
             blds16(rsA1, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
         else
@@ -966,12 +974,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void*)ssbuf, 16, v, 0, 0, 0);
     };
     auto transform_piece = [&](int i, const Chunk& c, char* abuf, const char* ssbuf) {
-        const bool ok = ((pvalid >> i) & 1u) && (!c.ktail || (c.kin + pchunk0 * EPC < c.cw));
+        const int pc = pchunk_of(i);
+        const bool ok = ((pvalid >> i) & 1u) && (!c.ktail || (c.kin + pc * EPC < c.cw));
         char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
         const i32x4 raw = *reinterpret_cast<const i32x4*>(ptr);
         i32x4 outv = raw;
         if constexpr (GN) {
-            const float* sp = reinterpret_cast<const float*>(ssbuf) + pchunk0 * EPC * 2;
+            const float* sp = reinterpret_cast<const float*>(ssbuf) + pc * EPC * 2;
             if constexpr (ES == 2) {
                 const half8 h = __builtin_bit_cast(half8, raw);
                 half8 o;
@@ -1007,7 +1016,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
             f32x4 f = __builtin_bit_cast(f32x4, outv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
-            *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk0 & 1) != 0);
+            *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pc & 1) != 0);
         } else {
             if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
         }
@@ -1017,7 +1026,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             unsigned v = b_v[i];
-            if (c.ktail) v = (c.kin + (SPLIT ? (pchunk0 >> 1) * 8 : pchunk0 * EPC) < c.cw) ? v : EOD_OOB;
+            if (c.ktail) v = (c.kin + (SPLIT ? (bchunk0 >> 1) * 8 : bchunk0 * EPC) < c.cw) ? v : EOD_OOB;
             blds16(rsB, v, soff, bst + (wave + NW * i) * 1024);
         }
     };
@@ -1045,6 +1054,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 #pragma unroll
     for (int s = 0; s < 4; ++s) bcoff[s] = ((2 * s + lh) ^ bsw) * 16;
     const int b_rd = (wn * WN + lr) * BKB;
+    // 16x16x32 paths: a lane's pixel of MFMA row block i is column lr of tile row wm*(WM/16) + i, so for tap (dy, dx) its fragment sits at
+    //   [first tile row of the wave, column (lr + dx)] + (i + dy) patch rows        (UPS: column (lr + dx + 1) >> 1, (i + dy + 1) >> 1 rows)
+    // and the swizzle key depends on dx alone: acur[v][dx] = LDS offset of that fragment in the CURRENT patch buffer for i = dy = 0
+    // (v = 0 / 1: [8 x hi] / [8 x lo] chunk of the lane's pair in split mode, sub-step 0 / 1 in fp16 storage); the (i, dy) part is a
+    // compile-time offset of the ds_read, and the buffer flip at a chunk boundary is one add per register.
+    int acur[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    auto aimm = [](int i, int dy) { return (UPS ? ((i + dy + 1) >> 1) : (i + dy)) * PW * BKB; };
+    if constexpr (MS == 16) {
+        constexpr int LROW = WM / 16;  // tile rows per wave (even)
+        static_assert(LROW % 2 == 0, "the UPS row split needs an even first tile row per wave");
+        const int c0 = SPLIT ? 2 * ((0x2130 >> (4 * lh)) & 3) : lh, c1 = SPLIT ? c0 + 1 : 4 + lh;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int pxc = UPS ? ((lr + dx + 1) >> 1) : lr + dx;
+            const int key = (pxc >> 1) & 7;
+            const int rowb = ((UPS ? (wm * LROW) >> 1 : wm * LROW) * PW + pxc) * BKB;
+            acur[0][dx] = rowb + ((c0 ^ key) << 4);
+            acur[1][dx] = rowb + ((c1 ^ key) << 4);
+        }
+    }
 
     const int KC = p.kc0 + p.kc1;
     const int NSTEP = KC * 9;
@@ -1123,12 +1152,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
             // ---- MFMAs of tap t: A fragments = patch rows shifted by (dy, dx) ----
             const int dy = t / 3, dx = t - dy * 3;
             const char* bst = sB + (step % BSTAGES) * BSTAGE;
-            int arow[TM], asw[TM];
+            int arow[TM], asw[TM];  // (32x32x16 paths; the 16x16x32 ones read through acur)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int prow = UPS ? ((pyo[i] + dy + 1) >> 1) * PW + ((pxo[i] + dx + 1) >> 1) : prow0[i] + dy * PW + dx;
+                const int pxc = UPS ? ((pxo[i] + dx + 1) >> 1) : pxo[i] + dx;   // patch column of this lane's pixel for tap (dy, dx)
+                const int prow = UPS ? ((pyo[i] + dy + 1) >> 1) * PW + pxc : prow0[i] + dy * PW + dx;
                 arow[i] = prow * BKB;
-                asw[i] = (prow >> 1) & 7;
+                asw[i] = (pxc >> 1) & 7;
             }
             if constexpr (MS == 16 && SPLIT) {
                 // the K-step's 32 k are ONE 16x16x32 sub-step: lane quarter lh supplies chunk pair pi(lh) = {0, 3, 1, 2}[lh] (the
@@ -1137,11 +1167,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                 const int ch = 2 * ((0x2130 >> (4 * lh)) & 3);
                 i32x4 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((ch + 1) ^ asw[i]) << 4));
+                for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const i32x4*>(sA + acur[1][dx] + aimm(i, dy));
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * MS * BKB + ((ch ^ bsw) << 4));
 #pragma unroll
-                for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + ((ch ^ asw[i]) << 4));
+                for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const i32x4*>(sA + acur[0][dx] + aimm(i, dy));
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1166,7 +1196,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                     const int ch = 4 * s + lh;
                     i32x4 fa16[TM], fb16[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa16[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + ((ch ^ asw[i]) << 4));
+                    for (int i = 0; i < TM; ++i) fa16[i] = *reinterpret_cast<const i32x4*>(sA + acur[s][dx] + aimm(i, dy));
 #pragma unroll
                     for (int j = 0; j < TN; ++j) fb16[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * MS * BKB + ((ch ^ bsw) << 4));
 #pragma unroll
@@ -1241,6 +1271,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
                 // (spreading these ~110 VALU ops into the MFMA gaps with sched_group_barrier was measured: 3 % SLOWER)
                 if (t >= 2 && t - 2 < LAH && has_next && (wave + NW * (t - 2)) < PG)
                     transform_piece(t - 2, nxt, abuf_next, sS + ((cc + 1) & 1) * 1024);
+            }
+        }
+        if constexpr (MS == 16) {  // the next chunk reads the other patch buffer
+            const int flip = (cc & 1) ? -ABUF : ABUF;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                acur[0][dx] += flip;
+                acur[1][dx] += flip;
             }
         }
     }
