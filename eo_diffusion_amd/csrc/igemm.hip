@@ -854,8 +854,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // (8+2) x (16+2) pixel HALO PATCH of its 8x16 output tile ONCE per 64-channel chunk (180 rows x 128 B, double
 // buffered) and the 9 taps read shifted windows of that patch from LDS: A traffic drops ~7x, the per-tap DMA is only
 // the 128 x 128 B weight tile (L2 resident, shared by all workgroups).
-//   * patch rows are swizzled exactly like GEMM rows (chunk ^ ((prow>>1)&7)); a 32-pixel MFMA row fragment is two
-//     16-pixel patch rows, so ds_read_b128 groups still hit distinct 16-byte slots except for one 2-way pair.
+//   * patch rows are swizzled like GEMM rows but keyed by the patch COLUMN: chunk ^ ((px>>1)&7) for patch row (py, px); a fragment
+//     read covers 16 consecutive columns, so the ds_read_b128 lane groups hit distinct 16-byte slots as in the GEMM tiles, and a tap
+//     shift (dy, dx) changes the key only through dx (three address registers per lane in the 16x16x32 paths, see `acur`).
 //   * DMA schedule per K-step (chunk cc, tap t), per wave: [4 weight-tile pieces for step+1][1 patch piece of chunk cc+1
 //     (taps 0..5)].  vmcnt retires in order, so the wait for step s's weights is vmcnt(1) when a patch piece was
 //     issued after them and vmcnt(0) otherwise: every patch piece gets two full K-steps to land.
