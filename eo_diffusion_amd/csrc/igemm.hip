@@ -1577,7 +1577,8 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     // 128-row tile touches at most 2 images once Ho*Wo >= 128 and at most 129 otherwise
     {
         const long long img_bytes = (long long)d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) * es;
-        const long long span = ((long long)Ho * Wo >= 128) ? 2 : 130;
+        // (maps that split into whole 256-row tiles never put two images into one tile: the window then only has to hold ONE image)
+        const long long span = ((long long)Ho * Wo % 256 == 0) ? 1 : ((long long)Ho * Wo >= 128) ? 2 : 130;
         EOD_REQUIRE(img_bytes * span < 0x7fffffffLL, "conv: one image (%lld bytes) is too large for the 2 GiB tile window", img_bytes);
         EOD_REQUIRE((long long)d->ksize * d->ksize * d->Cout * (d->C0 + d->C1) * es < 0x7fffffffLL, "conv: weights exceed the 2 GiB window");
     }

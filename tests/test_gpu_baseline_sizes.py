@@ -225,22 +225,23 @@ def test_bench_shape_batch16_equals_its_shards_bit_for_bit(prec, batch):
         assert torch.equal(part, full[2 * k:2 * k + 2]), k
 
 
-def test_config5_full_size_forward_modes_agree():
-    """512 x 512 x 13 forward of the attention architecture (T = 16384 and 4096 keys per head): the fp32x3 mode (split-fp16 convs, fused
-    fp32 attention) and the fp16 mode (fp16 storage, flash attention) against the exact-fp32 mode (fp32 MFMA convs, materialised
+@pytest.mark.parametrize("arch,S,ch", [("A1", 512, 13), ("A0", 1024, 3)])
+def test_full_size_forward_modes_agree(arch, S, ch):
+    """512 x 512 x 13 forward of the attention architecture (T = 16384 and 4096 keys per head) and a 1024 x 1024 forward of the metric's
+    architecture (1 GiB per image in fp32 storage: the 2 GiB tile window holds exactly one image): the fp32x3 mode (split-fp16 convs,
+    fused fp32 attention) and the fp16 mode (fp16 storage, flash attention) against the exact-fp32 mode (fp32 MFMA convs, materialised
     fp32 attention) on the same weights -- three kernel sets, each pinned to the oracle at 256 x 256 above"""
-    S = 512
-    x = synth_input("c5f_x", (1, 13, S, S), 8).to(DEV)
+    x = synth_input(f"c5f_x{S}", (1, ch, S, S), 8).to(DEV)
     t = torch.tensor([640]).to(DEV)
     out = {}
     for prec in ("fp32", "fp32x3", "fp16"):
-        m = _unet("A1", S, prec, 13).to(DEV).eval()
+        m = _unet(arch, S, prec, ch).to(DEV).eval()
         with torch.no_grad():
             out[prec] = m(x, t).float().cpu()
         del m
         torch.cuda.empty_cache()
     e3, e16 = rel_l2(out["fp32x3"], out["fp32"]), rel_l2(out["fp16"], out["fp32"])
-    print(f"A1 512x512x13 forward: fp32x3 vs exact fp32 {e3:.3e}, fp16 vs exact fp32 {e16:.3e}")
+    print(f"{arch} {S}x{S}x{ch} forward: fp32x3 vs exact fp32 {e3:.3e}, fp16 vs exact fp32 {e16:.3e}")
     assert e3 < 1e-5 and e16 < 5e-3
 
 
