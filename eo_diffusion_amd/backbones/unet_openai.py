@@ -203,6 +203,11 @@ class Upsample(_Emitter):
         pad_tl = h.H == 3 and h.W == 3  # the 3x3 -> 7x7 hack of unet_openai.py:237-239
         if not self.use_conv:
             return prog.resample2x(h, 1, pad_tl)
+        if not pad_tl and prog.conv_up4_ok(h, self.out_channels):
+            # parity-class form (engine.pack_conv_up4): every output parity is a 2x2-tap conv of the stored map -> 4/9 of the MACs
+            y, _ = prog.conv(h, prog.pack_conv_up4(self.conv.weight), prog.f32(self.conv.bias), self.out_channels,
+                             ksize=3, stride=1, pad=1, upsample="up4", stats=True)
+            return y
         y, _ = prog.conv(h, prog.pack_conv(self.conv.weight), prog.f32(self.conv.bias), self.out_channels,
                          ksize=3, stride=1, pad=1, upsample=True, pad_tl=pad_tl, stats=True)
         return y

@@ -1294,6 +1294,283 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
     }
 }
 
+// =============================================================================================
+// conv_up4_halo_kernel: 3x3 / pad 1 conv of the NEAREST-2x upsampling of x (Upsample.conv, unet_openai.py:236-241) in 4/9 of the MACs.
+//
+// Output pixel (2i+p, 2j+q) reads upsampled rows 2i+p-1 .. 2i+p+1, i.e. stored rows {i-1, i, i} (p = 0) or {i, i, i+1} (p = 1), and the
+// same for columns: every output PARITY CLASS (p, q) is a 2x2-tap conv of the stored (H x W) map whose weights are sums of the original
+// taps (rows: p = 0 -> [w0 | w1+w2], p = 1 -> [w0+w1 | w2]).  The host packs those sums as ONE weight tensor with 4*Cout output columns,
+// column block `cls` = 2p+q holding its 2x2 kernel in the 3x3 tap slots (dy' in {p, p+1}, dx' in {q, q+1}; the other five slots are never
+// read), in the usual [tap][4*Cout][Cin] format (split fp16 pairs for fp32 storage).  A workgroup = one 8x16 tile of STORED positions x
+// one class x 128 output channels: the ordinary (8+2) x (16+2) halo patch of the stored tensor, FOUR taps per 32/64-channel chunk instead
+// of nine, and the epilogue scatters to the (2i+p, 2j+q) positions of the (2H x 2W) output (decode_row, parity mode).
+// Schedule per chunk (4 K-steps): step s issues the weight tile of step s+1 and patch pieces 2s, 2s+1 of the NEXT chunk (s < 3); a
+// piece is split in place (fp32 storage) one step after it was issued, behind that step's MFMAs.  16x16x32 MFMAs only.
+// =============================================================================================
+template <typename T, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
+    static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 product is a mode of fp32 storage");
+    static_assert(SPLIT || sizeof(T) == 2, "fp16 storage or split fp32");
+    constexpr int NW = 4, WAVES_M = 2, WAVES_N = 2, BN = 128, BM = 128, MS = 16;
+    constexpr int PH = 10, PW = 18, PR = PH * PW, PG = (PR + 7) / 8, LAH = (PG + NW - 1) / NW;  // 180 rows, 23 groups, 6 pieces per wave
+    constexpr int ES = sizeof(T), EPC = 16 / ES, BKB = 128, BK = BKB / ES;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / MS, TN = WN / MS;
+    constexpr int LB = (BN / 8) / NW;
+    constexpr int ABUF = PG * 1024, BSTAGE = BN * BKB;
+    static_assert(LAH == 6, "schedule: two patch pieces per K-step in steps 0..2");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sA = smem;             // [2][ABUF]
+    char* const sB = smem + 2 * ABUF;  // [2][BSTAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    int tile_m, tile_nn;
+    map_tile(p, tile_m, tile_nn);                 // tile_nn enumerates (class, 128-column tile): the four classes of a tile run together
+    const int tpc = p.tiles_n >> 2;               // column tiles per class
+    const int cls = tile_nn / tpc, n0 = (tile_nn - cls * tpc) * BN;
+    const int par_y = cls >> 1, par_x = cls & 1;
+    const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode on the STORED map: ty0, tx0, n_first
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    unsigned ppix[LAH];
+    const int bchunk0 = sslot ^ ((4 * wave + (srow >> 1)) & 7);
+    unsigned pck = 0, pvalid = 0;
+#pragma unroll
+    for (int i = 0; i < LAH; ++i) {
+        const int prow = (wave + NW * i) * 8 + srow;
+        const int py = prow / PW, px = prow - py * PW;
+        const int hi = g.ty0 - 1 + py, wi = g.tx0 - 1 + px;
+        const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        if (ok) pvalid |= 1u << i;
+        ppix[i] = (unsigned)(hi * p.W + wi);
+        pck |= (unsigned)(sslot ^ ((px >> 1) & 7)) << (3 * i);
+    }
+    auto pchunk_of = [&](int i) { return (int)((pck >> (3 * i)) & 7u); };
+    unsigned b_v[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int row = (wave + NW * i) * 8 + srow;
+        b_v[i] = (n0 + row < p.Cout) ? (unsigned)(row * p.Cin * ES) + bchunk0 * 16 : EOD_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.b + ((long long)cls * p.Cout + n0) * p.Cin * ES);
+    const int tapstride = 4 * p.Cout * p.Cin * ES;  // the packed tensor has 4*Cout rows per tap slot
+
+    struct Chunk {
+        int kin;
+        bool ktail;
+    };
+    auto chunk_of = [&](int cc) {
+        Chunk c;
+        c.kin = cc * BK;
+        c.ktail = c.kin + BK > p.C0;
+        return c;
+    };
+    auto issue_patch_piece = [&](int i, const Chunk& c, char* abuf) {
+        const int pc = pchunk_of(i);
+        unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(p.C0 * ES) + pc * 16 : EOD_OOB;
+        if (c.ktail) v = (c.kin + pc * EPC < p.C0) ? v : EOD_OOB;
+        blds16(rsA, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
+    };
+    auto split_piece = [&](int i, char* abuf) {  // SPLIT: fp32 chunk -> its half of the pair's [8 x hi | 8 x lo] image (zeros stay zeros)
+        char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
+        f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+        *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk_of(i) & 1) != 0);
+    };
+    // tap slot of K-step s (a = s >> 1, b = s & 1): (par_y + a, par_x + b) of the 3x3 frame
+    auto issue_weights = [&](int s, const Chunk& c, char* bst) {
+        const int tap = (par_y + (s >> 1)) * 3 + par_x + (s & 1);
+        const unsigned soff = (unsigned)(tap * tapstride) + (unsigned)(c.kin * ES);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            unsigned v = b_v[i];
+            if (c.ktail) v = (c.kin + (SPLIT ? (bchunk0 >> 1) * 8 : bchunk0 * EPC) < p.C0) ? v : EOD_OOB;
+            blds16(rsB, v, soff, bst + (wave + NW * i) * 1024);
+        }
+    };
+    auto wait_vm = [](int n) {  // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        }
+    };
+
+    typename AccLayout<MS>::vec acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < AccLayout<MS>::R; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment addresses (see conv3x3_halo_kernel): acur[v][b] for the two column taps b of the class, rows via compile-time offsets
+    const int lr = lane & 15, lh = lane >> 4;
+    const int c0 = SPLIT ? 2 * ((0x2130 >> (4 * lh)) & 3) : lh, c1 = SPLIT ? c0 + 1 : 4 + lh;
+    int acur[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int pxc = lr + par_x + b;
+        const int key = (pxc >> 1) & 7;
+        const int rowb = ((wm * (WM / 16) + par_y) * PW + pxc) * BKB;
+        acur[0][b] = rowb + ((c0 ^ key) << 4);
+        acur[1][b] = rowb + ((c1 ^ key) << 4);
+    }
+    const int bsw = (lr >> 1) & 7;
+    const int b_rd = (wn * WN + lr) * BKB;
+    const int boff0 = b_rd + ((c0 ^ bsw) << 4), boff1 = b_rd + ((c1 ^ bsw) << 4);
+
+    const int KC = p.kc0, NSTEP = KC * 4;
+    {  // prologue: whole patch of chunk 0 + weights of step 0
+        const Chunk ch0 = chunk_of(0);
+#pragma unroll
+        for (int i = 0; i < LAH; ++i)
+            if ((wave + NW * i) < PG) issue_patch_piece(i, ch0, sA);
+        issue_weights(0, ch0, sB);
+        if constexpr (SPLIT) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < LAH; ++i)
+                if ((wave + NW * i) < PG) split_piece(i, sA);
+        }
+    }
+    int np_prev = 0;  // patch pieces this wave issued in the previous K-step (they sit behind that step's weight DMA in the vmcnt order)
+    int step = 0;
+    for (int cc = 0; cc < KC; ++cc) {
+        const Chunk cur = chunk_of(cc);
+        const bool has_next = cc + 1 < KC;
+        const Chunk nxt = chunk_of(has_next ? cc + 1 : cc);
+        char* abuf_next = sA + ((cc + 1) & 1) * ABUF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s, ++step) {
+            wait_vm(np_prev);  // this step's weights have landed (only the pieces issued after them may still be in flight)
+            if constexpr (SPLIT) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my in-place splits are written
+            __builtin_amdgcn_s_barrier();
+            const bool w_next = step + 1 < NSTEP;
+            if (w_next) issue_weights((s + 1) & 3, s == 3 ? nxt : cur, sB + ((step + 1) & 1) * BSTAGE);
+            int np = 0;
+            if (s < 3 && has_next) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if ((wave + NW * (2 * s + k)) < PG) {
+                        issue_patch_piece(2 * s + k, nxt, abuf_next);
+                        ++np;
+                    }
+            }
+            // ---- MFMAs of tap (a, b) ----
+            const int a = s >> 1, b = s & 1;
+            const char* bst = sB + (step & 1) * BSTAGE;
+            if constexpr (SPLIT) {
+                i32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const i32x4*>(sA + acur[1][b] + (i + a) * PW * BKB);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const i32x4*>(bst + boff0 + j * MS * BKB);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const i32x4*>(sA + acur[0][b] + (i + a) * PW * BKB);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(bst + boff1 + j * MS * BKB);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {  // fp16 storage: two 32-k sub-steps per 64-channel chunk
+                    i32x4 fa16[TM], fb16[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa16[i] = *reinterpret_cast<const i32x4*>(sA + acur[v][b] + (i + a) * PW * BKB);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb16[j] = *reinterpret_cast<const i32x4*>(bst + (v ? boff1 : boff0) + j * MS * BKB);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa16[i]), __builtin_bit_cast(half8, fb16[j]), acc[i][j], 0, 0, 0);
+                }
+            }
+            if constexpr (SPLIT) {
+                // the pieces issued ONE step ago (2(s-1), 2(s-1)+1): behind them in the vmcnt order are this step's weight DMA and pieces
+                if (s >= 1 && has_next) {
+                    wait_vm((w_next ? LB : 0) + np);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if ((wave + NW * (2 * (s - 1) + k)) < PG) split_piece(2 * (s - 1) + k, abuf_next);
+                }
+            }
+            np_prev = np;
+        }
+        {  // the next chunk reads the other patch buffer
+            const int flip = (cc & 1) ? -ABUF : ABUF;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acur[0][b] += flip;
+                acur[1][b] += flip;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();  // every wave is done with the operand buffers: reuse them for the epilogue
+    // epilogue on the (2H x 2W) output: rows of the tile are positions (i, j) of the stored map, pixel (2i + par_y, 2j + par_x)
+    IgemmP pe = p;
+    pe.par = 1; pe.par_y = par_y; pe.par_x = par_x;
+    pe.Ncols = p.Cout;
+    pe.tiles_per_image = p.tiles_pi * 4;  // statistics slots: (tile of the stored map, class)
+    TileGeom ge = g;
+    ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
+    if constexpr (SPLIT) pe.alpha = p.alpha * p.w_scale[1];
+    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0);
+}
+
+template <typename T, bool SPLIT> static int launch_up4(IgemmP& p, hipStream_t st) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    const size_t ring = 2 * (size_t)(23 * 1024) + 2 * (size_t)128 * 128;
+    const size_t epi = 4 * (size_t)64 * (64 + 4) * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    auto kern = conv_up4_halo_kernel<T, SPLIT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    p.kc0 = (p.C0 + BK - 1) / BK;
+    p.kc1 = 0;
+    p.KT = p.kc0 * 4;
+    p.tiles_n = 4 * ((p.Cout + 127) / 128);  // (class, column tile)
+    p.tw_log2 = 4;                            // 8 x 16 tiles of the STORED map
+    p.th = 8;
+    p.tiles_pw = p.W / 16;
+    p.tiles_pi = p.tiles_pw * (p.H / 8);
+    p.tiles_m = p.tiles_pi * p.N;
+    const long long nblk = (long long)p.tiles_m * p.tiles_n;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        eod_set_error("conv_up4: bad grid %lld", nblk);
+        return EOD_EINVAL;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, p);
+    EOD_CHECK_LAUNCH("conv_up4_halo");
+    return EOD_OK;
+}
+
 // split-K second pass: y[m][c] = alpha * sum_z ws[z][m][c] + bias[c] + cbias[n(m)][c] + res[m][c]   (fixed z order)
 template <typename T>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long M, int Cout, int HoWo, float alpha,
@@ -1488,6 +1765,14 @@ static bool conv_parity_ok(const eod_conv_desc* d, int Ho, int Wo) {
     return on && d->upsample == 2 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && !d->out_nchw_f32 && !d->stats &&
            !d->w_tapmajor && !d->w_split && Ho % 2 == 0 && Wo % 2 == 0;
 }
+// upsample = 3: nearest-2x upsampling + 3x3 conv as four 2x2-tap parity classes with pre-summed weights (conv_up4_halo_kernel)
+static bool conv_up4_ok(const eod_conv_desc* d) {
+    const bool store_ok = d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
+    return d->upsample == 3 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && d->C1 == 0 && !d->x2 && d->Cout > 64 &&
+           d->Cout % 8 == 0 && d->C0 % 8 == 0 && d->W % 16 == 0 && d->H % 8 == 0 && !d->out_nchw_f32 && !d->w_tapmajor && !d->gn_scale_shift &&
+           store_ok && halo_mfma_shape() == 16;
+}
+extern "C" int eod_conv_up4_ok(const eod_conv_desc* d) { return d && conv_up4_ok(d) ? 1 : 0; }
 extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
     if (!d) return 0;
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
@@ -1560,7 +1845,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     const int es = eod_esize(d->dtype), epc = 16 / es;
     EOD_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize %d", d->ksize);
     EOD_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
-    EOD_REQUIRE(d->upsample >= 0 && d->upsample <= 2, "conv: upsample %d", d->upsample);
+    EOD_REQUIRE(d->upsample >= 0 && d->upsample <= 3, "conv: upsample %d", d->upsample);
     EOD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad dims");
     EOD_REQUIRE(d->C0 % epc == 0 && d->C1 % epc == 0, "conv: C0=%d C1=%d must be multiples of %d", d->C0, d->C1, epc);
     EOD_REQUIRE(d->x && d->w && d->y, "conv: null pointer");
@@ -1626,6 +1911,10 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     EOD_REQUIRE(!d->w_split || (conv_split_ok(d, Ho, Wo, p.force_cfg) && d->w_scale),
                 "conv: w_split needs a geometry for which eod_conv_split_ok(d) == 1 and the w_scale of eod_pack_conv_weight_split");
     p.w_scale = d->w_split ? d->w_scale : nullptr;
+    if (d->upsample == 3) {
+        EOD_REQUIRE(conv_up4_ok(d), "conv: upsample = 3 (parity-class form of the nearest-2x conv) needs a geometry for which eod_conv_up4_ok(d) == 1");
+        return d->dtype == EOD_F16 ? launch_up4<half_t, false>(p, st) : launch_up4<float, true>(p, st);
+    }
     const bool m16 = halo_mfma_shape() == 16;
     if (halo_ok && d->w_split) {
         // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)

@@ -10,6 +10,7 @@ torch is used here only for device memory (torch.empty / zeros), stream handles 
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -124,6 +125,24 @@ class Program:
             return _LazyConvW(self, weight, cin_pad)
         return self._pack_conv_plain(weight, cin_pad)
 
+    def pack_conv_up4(self, weight):
+        """3x3 weight (OIHW fp32) of a conv over the nearest-2x upsampling of its input -> the packed [4*Cout][Cin][3][3] tensor of the
+        parity-class form (eod_conv_up4_ok): output pixel (2i+p, 2j+q) reads stored rows {i-1+p, i+p} only, so class (p, q) is a 2x2-tap
+        conv whose taps are sums of the original ones; row block 2p+q holds that kernel in tap slots dy' in {p, p+1}, dx' in {q, q+1}."""
+        w = self.f32(weight)
+        cout, cin = w.shape[0], w.shape[1]
+        # rows: p = 0 -> slots (0: w0, 1: w1+w2); p = 1 -> slots (1: w0+w1, 2: w2); columns alike
+        rsum = [torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2], torch.zeros_like(w[:, :, 0])], 2),
+                torch.stack([torch.zeros_like(w[:, :, 0]), w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2)]
+        blocks = []
+        for pp in range(2):
+            r = rsum[pp]  # [Cout][Cin][3 slots][3 original columns]
+            csum = [torch.stack([r[..., 0], r[..., 1] + r[..., 2], torch.zeros_like(r[..., 0])], 3),
+                    torch.stack([torch.zeros_like(r[..., 0]), r[..., 0] + r[..., 1], r[..., 2]], 3)]
+            blocks += csum
+        wc = torch.cat(blocks, 0).contiguous()  # [4*Cout][Cin][3][3], classes (0,0), (0,1), (1,0), (1,1)
+        return self.pack_conv(self.own(wc))
+
     def _pack_conv_plain(self, weight, cin_pad=None):
         w = self.f32(weight)
         cout, cin = w.shape[0], w.shape[1]
@@ -170,6 +189,16 @@ class Program:
     def bind(self, name, op_index, setter):
         self.bindings.setdefault(name, []).append((op_index, setter))
 
+    def conv_up4_ok(self, x, cout):
+        """True if the library has the parity-class form of `3x3 conv over the nearest-2x upsampling of x` for this geometry"""
+        if os.environ.get("EOD_UP4", "1") == "0" or self.precision == "fp32":
+            return False
+        d = ConvDesc()
+        d.dtype, d.N, d.H, d.W, d.C0, d.C1, d.Cout = self.dt, x.N, x.H, x.W, x.C, 0, cout
+        d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = 3, 1, 1, 3, 0
+        d.w_split = int(self.split)
+        return bool(self.L.eod_conv_up4_ok(C.byref(d)))
+
     def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
              cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None, w_tapmajor=False):
         """gn = (scale_shift tensor from gn_stats(), silu): GroupNorm(+SiLU) of the conv INPUT.  Fused into the conv's
@@ -183,6 +212,8 @@ class Program:
             if not self.L.eod_conv_gn_fusable(C.byref(probe)):
                 x = self.gn_apply([x] + ([x2] if x2 is not None else []), gn[0], silu=gn[1])
                 x2, gn = None, None
+        if upsample == "up4":  # w_packed = pack_conv_up4(weight): the parity-class form of the nearest-2x conv
+            upsample = 3
         ups = 2 if upsample else 1
         heff, weff = x.H * ups + int(pad_tl), x.W * ups + int(pad_tl)
         ho = (heff + 2 * pad - ksize) // stride + 1
@@ -432,9 +463,11 @@ class Program:
                 geo = d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and d.Wo % 16 == 0 and d.Ho % 8 == 0
                 halo = geo and d.Cout > 64 and not d.out_nchw_f32 and not d.w_tapmajor  # mirrors conv_uses_halo() in csrc/igemm.hip
                 head = geo and d.Cout <= 32 and d.out_nchw_f32 and not d.upsample  # 32-column instance (HBM-bound head conv)
-                out.append(dict(kind="conv", flops=fl, bytes=by,
-                                kernel="conv3x3_halo_kernel" if halo else "conv3x3_halo_kernel<BN=32>" if head else "igemm_kernel",
-                                label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"))
+                up4 = d.upsample == 3  # parity-class form of the nearest-2x conv: the algorithm's 9 taps are executed as 4 (pre-summed)
+                out.append(dict(kind="conv", flops=fl, bytes=by, exec_flops=fl * (4.0 / 9.0 if up4 else 1.0),
+                                kernel="conv_up4_halo_kernel" if up4 else "conv3x3_halo_kernel" if halo else
+                                       "conv3x3_halo_kernel<BN=32>" if head else "igemm_kernel",
+                                label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u4' if up4 else 'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"))
             elif k == OP_GEMM:
                 d = op.u.gemm
                 nb = d.nb0 * d.nb1

@@ -61,7 +61,8 @@ typedef struct {
     int32_t pad;         /* 0 or 1 */
     int32_t upsample;    /* 1: A is the nearest-2x upsampling of x (H,W are the stored dims);
                             2: A is x with zeros inserted between the pixels (z[2i][2j] = x[i][j]): the input of the
-                            backward-data conv of a stride-2 conv (training path)                */
+                            backward-data conv of a stride-2 conv (training path);
+                            3: as 1, computed as four 2x2-tap parity classes with pre-summed weights (see eod_conv_up4_ok) */
     int32_t pad_tl;      /* 1: extra zero row/col on top/left after upsampling (3x3 -> 7x7 hack,
                             unet_openai.py:237-239)                                              */
     int32_t Ho, Wo;      /* output spatial dims */
@@ -92,6 +93,12 @@ int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 int eod_conv_stats_slots(const eod_conv_desc* d);
 int eod_conv_gn_fusable(const eod_conv_desc* d);
 int eod_conv_split_ok(const eod_conv_desc* d);
+/* upsample = 3 (Upsample.conv, unet_openai.py:236-241, in 4/9 of the MACs): output pixel (2i+p, 2j+q) of the 3x3 conv over the nearest-2x
+ * image reads only stored rows {i-1+p, i+p} and columns {j-1+q, j+q}, so each parity class (p, q) is a 2x2-tap conv of the STORED map with
+ * summed taps (rows: p = 0 -> [w0 | w1+w2], p = 1 -> [w0+w1 | w2]; columns alike).  w is then ONE packed tensor (eod_pack_conv_weight /
+ * _split) of a [4*Cout][Cin][3][3] weight whose row block 2p+q holds class (p, q)'s kernel in the tap slots (dy' in {p, p+1}, dx' in
+ * {q, q+1}) and zeros elsewhere; Cout stays the real channel count.  1 where this form is available (fp16, or fp32 with w_split). */
+int eod_conv_up4_ok(const eod_conv_desc* d);
 int64_t eod_conv_workspace_size(const eod_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------

@@ -59,6 +59,34 @@ def test_conv_vs_torch(prec, case):
     assert rel_l2(got, ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
+@pytest.mark.parametrize("gn", [False, True])
+@pytest.mark.parametrize("case", [(2, 128, 8, 16, 128), (1, 96, 16, 32, 192), (3, 64, 24, 16, 256), (1, 640, 16, 16, 160)])
+def test_conv_nearest_upsample_parity_class_form_vs_torch(prec, gn, case):
+    """upsample='up4' (conv_up4_halo_kernel): the 3x3 conv over the nearest-2x image as four 2x2-tap parity classes with pre-summed
+    weights (4/9 of the MACs) vs F.interpolate + F.conv2d: one / several patches per image, K tail (96 % 64), N tail, 10 chunks;
+    gn: a GroupNorm behind it consumes the statistics accumulated in the conv's epilogue (one slot per (tile, class, wave row))"""
+    N, Cin, H, W, Cout = case
+    x = synth_input(f"u4x{case}", (N, Cin, H, W), 43)
+    w = synth_input(f"u4w{case}", (Cout, Cin, 3, 3), 43, scale=1.0 / math.sqrt(Cin * 9))
+    b = synth_input(f"u4b{case}", (Cout,), 43, scale=0.1)
+    gam = 1.0 + 0.2 * synth_input("u4g", (Cout,), 43)
+    bet = 0.1 * synth_input("u4e", (Cout,), 43)
+
+    def emit(prog, a):
+        assert prog.conv_up4_ok(a, Cout)
+        y, _ = prog.conv(a, prog.pack_conv_up4(w.to(DEV)), prog.f32(b.to(DEV)), Cout, ksize=3, stride=1, pad=1, upsample="up4", stats=True)
+        assert y.stats is not None and y.stats[1] == (4 * H * W // 128) * 2
+        return prog.group_norm([y], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV)), silu=False) if gn else y
+
+    got = run_program(prec, x, emit)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    if gn:
+        ref = F.group_norm(ref, 32, gam, bet, eps=1e-5)
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < (TOL[prec] if not gn else (2e-5 if prec == "fp32x3" else 3e-3))
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
 @pytest.mark.parametrize("case", [
     (2, 64, 16, 16, 128, True),    # four parity-class launches, patch-mode tiles on the quarter grid, residual
