@@ -17,6 +17,8 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, upsample)
     "l2_384": (16, 64, 64, 384, 384, 3, 1, False),
     "l3_512": (16, 32, 32, 512, 512, 3, 1, False),
     "up_256": (16, 128, 128, 256, 256, 3, 1, True),
+    "up_384": (16, 64, 64, 384, 384, 3, 1, True),
+    "up_512": (16, 32, 32, 512, 512, 3, 1, True),
     "sk_384": (16, 256, 256, 384, 128, 1, 1, False),
     "sk_256": (16, 256, 256, 256, 128, 1, 1, False),
     "sk_640": (16, 128, 128, 640, 256, 1, 1, False),
@@ -31,6 +33,7 @@ def main():
     ap.add_argument("--shapes", default="l0_128,l0_384,l1_256,l1_640,l2_384,l3_512,up_256,sk_384")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--gn", action="store_true")
+    ap.add_argument("--up4", action="store_true", help="upsample shapes through conv_up4_halo_kernel")
     a = ap.parse_args()
     dev = "cuda:0"
     for name in a.shapes.split(","):
@@ -43,6 +46,9 @@ def main():
         gn = None
         if a.gn and not ups and k == 3:
             gn = (prog.gn_stats([x], prog.f32(torch.ones(Cin, device=dev)), prog.f32(torch.zeros(Cin, device=dev))), True)
+        if ups and a.up4 and prog.conv_up4_ok(x, Cout):  # the parity-class form of the nearest-2x conv (4/9 of the MACs; flops below = algorithmic)
+            w = prog.pack_conv_up4(torch.randn((Cout, Cin, k, k), device=dev) * 0.02)
+            ups = "up4"
         y, _ = prog.conv(x, w, b, Cout, ksize=k, stride=stride, pad=k // 2, upsample=ups, gn=gn)
         prog.finalize()
         for _ in range(3): prog.run()
