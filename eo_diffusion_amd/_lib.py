@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("bias", vp), ("res", vp), ("c", vp), ("lda", i64), ("ldb", i64), ("ldc", i64),
                 ("sa0", i64), ("sa1", i64), ("sb0", i64), ("sb1", i64), ("sc0", i64), ("sc1", i64), ("dtype", i32),
                 ("M", i32), ("N", i32), ("K", i32), ("nb0", i32), ("nb1", i32), ("bias_mode", i32), ("c_f32", i32),
-                ("alpha", f32)]
+                ("alpha", f32), ("x3", i32)]
 
 
 class TembDesc(C.Structure):

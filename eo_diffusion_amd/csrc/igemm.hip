@@ -458,7 +458,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
 
 template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmP p) {
-    static_assert(!SPLIT || (sizeof(T) == 4 && CONV && STAGES == 2), "split-fp16 product: fp32 conv, 2-stage ring");
+    static_assert(!SPLIT || (sizeof(T) == 4 && STAGES == 2), "split-fp16 product: fp32 storage, 2-stage ring");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only (see conv3x3_halo_kernel)");
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
@@ -491,7 +491,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         if (p.splitk > 1) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;
     }
     if constexpr (SPLIT) {
-        if (p.splitk <= 1) pe.alpha = p.alpha * p.w_scale[1];  // (split-K: raw partial tiles, the reduce pass rescales)
+        if constexpr (CONV) {
+            if (p.splitk <= 1) pe.alpha = p.alpha * p.w_scale[1];  // (split-K: raw partial tiles, the reduce pass rescales)
+        } else {
+            pe.alpha = p.alpha * (1.0f / (EOD_SPLIT_ASCALE * EOD_SPLIT_ASCALE));  // GEMM: both operands are activations, split in LDS
+        }
     }
     const long long offA = g.offA, offB = g.offB;
 
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     };
     auto issue_b = [&](int i, char* sbase) {
         unsigned v = b_v[i];
-        if (ss.ktail) v = (ss.kin + (SPLIT ? (b_chunk[i] >> 1) * 8 : b_chunk[i] * EPC) < ss.cw) ? v : EOD_OOB;
+        if (ss.ktail) v = (ss.kin + ((SPLIT && CONV) ? (b_chunk[i] >> 1) * 8 : b_chunk[i] * EPC) < ss.cw) ? v : EOD_OOB;
         blds16(rsB, v, ss.soffB, sbase + STAGE_A + (wave + NW * i) * 1024);
     };
     auto issue_loads = [&](int stage) {  // all DMA instructions of one K-step
@@ -720,6 +724,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
                 *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (a_chunk[i] & 1) != 0);
+            }
+            if constexpr (!CONV) {  // GEMM (attention with wide heads): the B operand is an fp32 activation too
+#pragma unroll
+                for (int i = 0; i < LB; ++i) {
+                    char* ptr = sa + STAGE_A + (wave + NW * i) * 1024 + lane * 16;
+                    f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+                    *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (b_chunk[i] & 1) != 0);
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the rewritten pieces are in LDS before the barrier publishes them
         }
@@ -2043,5 +2057,11 @@ extern "C" int eod_gemm_nt(const eod_gemm_desc* d, void* stream) {
     p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
     const int batch = d->nb0 * d->nb1;
+    if (d->x3) {  // fp32 operands, every product as three fp16 MFMAs on operands split in LDS (the fp32x3 mode's attention GEMMs)
+        EOD_REQUIRE(d->dtype == EOD_F32 && d->K % 8 == 0 && halo_mfma_shape() == 16, "gemm: x3 needs fp32 operands and K %% 8 == 0");
+        if (p.Ncols <= 32) return launch_cfg<float, false, 128, 32, 4, 1, 2, true, 16>(p, batch, st);
+        if (p.Ncols <= 64) return launch_cfg<float, false, 128, 64, 4, 1, 2, true, 16>(p, batch, st);
+        return launch_cfg<float, false, 128, 128, 2, 2, 2, true, 16>(p, batch, st);
+    }
     return d->dtype == EOD_F16 ? launch_T<half_t, false>(p, batch, st) : launch_T<float, false>(p, batch, st);
 }

@@ -274,6 +274,7 @@ class Program:
         d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
         d.dtype, d.M, d.N, d.K, d.nb0, d.nb1 = self.dt, M, N, K, nb0, nb1
         d.bias_mode, d.c_f32, d.alpha = (bias_mode if bias is not None else 0), int(c_f32), alpha
+        d.x3 = int(self.split and K % 8 == 0 and os.environ.get("EOD_GEMM_X3", "1") != "0")  # fp32x3 mode: split-fp16 products
         return idx
 
     def _small(self, kind, p=(), l=(), i=(), f=()):

@@ -123,6 +123,8 @@ typedef struct {
                           4 = softmax-rebuild epilogue: c = exp(alpha*acc - bias[z][m])  (P from the scores and their log-sum-exp) */
     int32_t c_f32;     /* 1: store c as fp32 regardless of dtype */
     float alpha;
+    int32_t x3;        /* 1 (dtype EOD_F32, K % 8 == 0): every product as three fp16 MFMAs on operands split into hi + lo halves in LDS
+                          (the fp32x3 precision mode, see eod_conv_desc.w_split); |a|, |b| must stay below 4094 */
 } eod_gemm_desc;
 int eod_gemm_nt(const eod_gemm_desc* d, void* stream);
 

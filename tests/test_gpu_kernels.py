@@ -185,7 +185,7 @@ def test_group_norm_across_concat_seam(prec):
     assert rel_l2(got, ref) < (2e-6 if prec == "fp32" else 2e-3)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])   # fp32x3: both operands split into fp16 pairs in LDS (eod_gemm_desc.x3)
 @pytest.mark.parametrize("mnk", [(128, 128, 64), (200, 72, 48), (49, 49, 128), (1024, 96, 512), (33, 3, 16)])
 def test_gemm_nt_batched(prec, mnk):
     from eo_diffusion_amd.engine import Program
