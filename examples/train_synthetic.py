@@ -52,6 +52,12 @@ def main():
         optimizer = AdamW(model.parameters(), lr=args.lr)
         d = args.model_ema_decay
         model_ema = AveragedModel(model, device, lambda avg, p, n: d * avg + (1 - d) * p, use_buffers=True)  # utils.py:56-67
+    # train.py:76-85: cos warm-up from lr/100 over the first tenth of the run, then lr * exp(-3 * progress of the rest)
+    from eo_diffusion_amd.train_utils import KeyframeLR
+    max_steps, posmax = args.steps, max(1, args.steps // 10)
+    scheduler = KeyframeLR(optimizer=optimizer, units="steps", end=max_steps, frames=[
+        {"position": 0, "lr": args.lr / 100}, {"transition": "cos"}, {"position": posmax, "lr": args.lr},
+        {"transition": lambda last_lr, sf, ef, pos, *_: args.lr * math.exp(-3 * (pos - posmax) / max(1, max_steps - posmax))}])
     loss_fn = nn.MSELoss(reduction="mean")
     g = torch.Generator(device=device).manual_seed(1)
     model.train()
@@ -64,6 +70,7 @@ def main():
         loss.backward()                      # :118
         optimizer.step()                     # :119
         optimizer.zero_grad()                # :120
+        scheduler.step()                     # :121
         model_ema.update_parameters(model)   # :123
         if step % 5 == 0 or step == args.steps - 1:
             torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr]
 
 The reference never travels to the GPU box; only the .npz / .json data written here does.
 Harness-side adaptations (NOT reference behaviour):
@@ -10,7 +10,9 @@ Harness-side adaptations (NOT reference behaviour):
   (3) masked DDIM calls _forward_diffusion(x0, ts) without noise (ddim.py:147) -> noise=randn_like(x0);
   (4) x0 passed explicitly to DDIMSampler.sample (inference.py:125 omits it);
   (5) weights (zero_module ones included) come from tests/synth.py;
-  (6) torch.randn / torch.randn_like are wrapped to RECORD the tensors the reference draws.
+  (6) torch.randn / torch.randn_like are wrapped to RECORD the tensors the reference draws;
+  (7) keyframe_lr: script_utils/train_utils.py imports pytorch_lightning, timm and script_utils/utils at its top for OTHER classes of
+      the file; empty stand-in modules let the file import so that its KeyframeLR class (torch only) can be run.
 """
 import json
 import os
@@ -414,11 +416,61 @@ def gen_training(names=("u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls",
             json.dump(names, f)
 
 
+
+KEYFRAME_CASES = {
+    # train.py:76-85 with lr = 1e-3, 4 "epochs" of 30 steps, warm-up over the first one
+    "train_py": dict(units="steps", end=120, lr=1e-3, posmax=30),
+    "percent_shorthand": dict(units="percent", end=50, frames=[(0.1, 0.01), "cos", {"position": 0.6, "lr": 0.002}, {"position": "end", "lr": 1e-4}]),
+    "implicit_ramps": dict(units="steps", end=40, frames=[{"position": 5, "lr": 0.1}, {"position": 20, "lr": 0.05}]),
+    "edge_transitions": dict(units="percent", end=30, frames=["cos", (0.5, 1.0), "linear"]),
+}
+
+
+def keyframe_frames(name, case):
+    """the frame list of a case (shared with the test: callables cannot be stored in a fixture)"""
+    import math
+    if name == "train_py":
+        lr, posmax, end = case["lr"], case["posmax"], case["end"]
+        return [{"position": 0, "lr": lr / 100}, {"transition": "cos"}, {"position": posmax, "lr": lr},
+                {"transition": lambda last_lr, sf, ef, pos, *_: lr * math.exp(-3 * (pos - posmax) / (end - posmax))}]
+    import copy
+    return copy.deepcopy(case["frames"])
+
+
+def gen_keyframe_lr():
+    """KeyframeLR (script_utils/train_utils.py:17-226) run by the reference: the learning rate of `end` + 2 consecutive steps (the last
+    two lie behind the schedule) and sample_lrs(25), for train.py's own schedule and three that exercise the shorthand forms"""
+    for name, mods in (("pytorch_lightning", ("Callback",)), ("pytorch_lightning.callbacks", ("ModelCheckpoint",)), ("timm", ()),
+                       ("timm.utils", ()), ("timm.utils.model", ("get_state_dict", "unwrap_model")), ("utils", ("ExponentialMovingAverage",))):
+        m = types.ModuleType(name)
+        for attr in mods:
+            setattr(m, attr, type(attr, (), {}))
+        sys.modules.setdefault(name, m)
+    sys.path.insert(1, os.path.join(REF, "script_utils"))
+    import train_utils as RT
+    assert RT.__file__.startswith(REF), RT.__file__
+    out = {}
+    for name, case in KEYFRAME_CASES.items():
+        opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+        sch = RT.KeyframeLR(optimizer=opt, units=case["units"], frames=keyframe_frames(name, case), end=case["end"])
+        lrs = []
+        for _ in range(case["end"] + 2):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[name + "_lrs"] = np.asarray(lrs, dtype=np.float64)
+        opt2 = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+        sch2 = RT.KeyframeLR(optimizer=opt2, units=case["units"], frames=keyframe_frames(name, case), end=case["end"])
+        out[name + "_sample25"] = np.asarray(sch2.sample_lrs(25), dtype=np.float64)
+    save("keyframe_lr", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    if len(sys.argv) > 2 and sys.argv[2] in ("training", "training_13ch", "ldm_tables"):
+    if len(sys.argv) > 2 and sys.argv[2] in ("training", "training_13ch", "ldm_tables", "keyframe_lr"):
         # partial runs (new fixtures of a later round) leave the committed ones untouched
-        {"training": gen_training, "training_13ch": lambda: gen_training(("u_s2_13ch",)), "ldm_tables": gen_ldm_tables}[sys.argv[2]]()
+        {"training": gen_training, "training_13ch": lambda: gen_training(("u_s2_13ch",)), "ldm_tables": gen_ldm_tables,
+         "keyframe_lr": gen_keyframe_lr}[sys.argv[2]]()
         print("done")
         sys.exit(0)
     gen_schedules()
@@ -428,4 +480,5 @@ if __name__ == "__main__":
     gen_keys()
     gen_sampler()
     gen_training()
+    gen_keyframe_lr()
     print("done")

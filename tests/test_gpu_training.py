@@ -1,6 +1,8 @@
 """GPU parity of the training step: UNet forward + backward on the HIP path vs torch
 autograd through the CPU oracle (oracle/unet_ref.py restates unet_openai.py; loss = nn.MSELoss(pred, noise),
 train.py:86,116-118).  fp32 mode: exact-fp32 MFMA, tight tolerance; fp16 mode: fp16 storage with loss scaling."""
+import math
+
 import pytest
 import torch
 
@@ -149,6 +151,12 @@ def test_reference_training_loop_drop_in(use_fp16):
     decay = 0.9
     ema = AveragedModel(model, DEV, lambda avg, p, n: decay * avg + (1 - decay) * p, use_buffers=True)
     opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    # train.py:76-85: KeyframeLR -- cos warm-up from lr/100, then lr * exp(-3 * progress); stepped after the optimizer (:121)
+    from eo_diffusion_amd.train_utils import KeyframeLR
+    sched = KeyframeLR(optimizer=opt, units="steps", end=8, frames=[
+        {"position": 0, "lr": 2e-5}, {"transition": "cos"}, {"position": 2, "lr": 2e-3},
+        {"transition": lambda last_lr, sf, ef, pos, *_: 2e-3 * math.exp(-3 * (pos - 2) / 6)}])
+    assert abs(opt.param_groups[0]["lr"] - 2e-5) < 1e-12
     loss_fn = nn.MSELoss(reduction="mean")
     image = synth_input("img", (4, 3, 16, 16), 5, uniform=True).to(DEV)
     losses = []
@@ -167,6 +175,7 @@ def test_reference_training_loop_drop_in(use_fp16):
             [n for n, p in model.named_parameters() if p.grad is None]
         opt.step()
         opt.zero_grad()
+        sched.step()
         ema.update_parameters(model)
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.8 * losses[0], losses

@@ -317,3 +317,58 @@ def test_oracle_training_gradients_vs_reference(name):
             continue
         assert abs(float(gr.norm()) - ref_n) < 1e-4 * ref_n, k
         assert abs(float((gr * direction).sum()) - ref_d) < 1e-4 * ref_n * float(direction.norm()), k
+
+
+# ------------------------------------------------------------------------------------------------ KeyframeLR (train.py:76-85)
+KEYFRAME_CASES = {
+    "train_py": dict(units="steps", end=120, lr=1e-3, posmax=30),
+    "percent_shorthand": dict(units="percent", end=50, frames=[(0.1, 0.01), "cos", {"position": 0.6, "lr": 0.002}, {"position": "end", "lr": 1e-4}]),
+    "implicit_ramps": dict(units="steps", end=40, frames=[{"position": 5, "lr": 0.1}, {"position": 20, "lr": 0.05}]),
+    "edge_transitions": dict(units="percent", end=30, frames=["cos", (0.5, 1.0), "linear"]),
+}
+
+
+def _keyframe_frames(name, case):
+    import copy
+    import math
+    if name == "train_py":  # the frame list train.py builds (cos warm-up from lr/100, then lr * exp(-3 * progress))
+        lr, posmax, end = case["lr"], case["posmax"], case["end"]
+        return [{"position": 0, "lr": lr / 100}, {"transition": "cos"}, {"position": posmax, "lr": lr},
+                {"transition": lambda last_lr, sf, ef, pos, *_: lr * math.exp(-3 * (pos - posmax) / (end - posmax))}]
+    return copy.deepcopy(case["frames"])
+
+
+@pytest.mark.parametrize("name", list(KEYFRAME_CASES))
+def test_keyframe_lr_reproduces_the_reference_schedule(name):
+    """eo_diffusion_amd.train_utils.KeyframeLR against learning rates the REFERENCE's scheduler produced (script_utils/train_utils.py
+    :17-226 run by tests/golden/make_golden.py keyframe_lr): every step of the schedule plus two behind its end (the reference keeps the
+    last rate there), and sample_lrs(25); train.py's own frame list and the shorthand / implicit-ramp / edge-transition forms"""
+    from eo_diffusion_amd.train_utils import KeyframeLR
+    g = gload("keyframe_lr")
+    case = KEYFRAME_CASES[name]
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    sch = KeyframeLR(optimizer=opt, units=case["units"], frames=_keyframe_frames(name, case), end=case["end"])
+    lrs = []
+    for _ in range(case["end"] + 2):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    ref = np.asarray(g[name + "_lrs"])
+    assert len(lrs) == len(ref)
+    assert np.allclose(np.asarray(lrs), ref, rtol=1e-14, atol=0.0), float(np.abs(np.asarray(lrs) - ref).max())
+    sch2 = KeyframeLR(optimizer=torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-3), units=case["units"],
+                      frames=_keyframe_frames(name, case), end=case["end"])
+    assert np.allclose(np.asarray(sch2.sample_lrs(25)), np.asarray(g[name + "_sample25"]), rtol=1e-14, atol=0.0)
+    assert sch2.last_lr == 0
+
+
+def test_keyframe_lr_rejects_what_the_reference_rejects():
+    from eo_diffusion_amd.train_utils import KeyframeLR
+    mk = lambda: torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
+    with pytest.raises(AssertionError):   # positions must not decrease (train_utils.py:100-102)
+        KeyframeLR(mk(), frames=[(0.5, 1.0), (0.2, 0.5)], end=10)
+    with pytest.raises(AssertionError):   # nor lie behind the end (:103-105)
+        KeyframeLR(mk(), frames=[(0, 1.0), (12, 0.5)], end=10, units="steps")
+    with pytest.raises(ValueError):       # unknown transition name (:144)
+        s = KeyframeLR(mk(), frames=[(0, 1.0), "cubic", (1.0, 0.5)], end=10)
+        s.get_lr_at_pos(0.5)
