@@ -96,6 +96,46 @@ extern "C" int eod_pack_conv_weight_split(const float* w, void* dst, float* scal
     return EOD_OK;
 }
 
+// class kernels of the parity-class form of a conv over a nearest-2x upsampling (eod_conv_up4_ok): wc [4*Cout][Cin][3][3] from
+// w [Cout][Cin][3][3]; row block 2p+q holds class (p, q)'s 2x2 kernel in tap slots dy' in {p, p+1}, dx' in {q, q+1}: per axis
+// class 0 -> slots (w0 | w1+w2 | 0), class 1 -> (0 | w0+w1 | w2).  One thread per (co, ci).
+__global__ void up4_weight_sums_kernel(const float* __restrict__ w, float* __restrict__ wc, int Cout, int Cin) {
+    const long long n = (long long)Cout * Cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[t / 3][t % 3] = w[i * 9 + t];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float r[3][3];  // rows summed for class p
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                r[0][x] = p ? 0.0f : v[0][x];
+                r[1][x] = p ? v[0][x] + v[1][x] : v[1][x] + v[2][x];
+                r[2][x] = p ? v[2][x] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float* o = wc + ((long long)(2 * p + q) * n + i) * 9;
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    o[y * 3 + 0] = q ? 0.0f : r[y][0];
+                    o[y * 3 + 1] = q ? r[y][0] + r[y][1] : r[y][1] + r[y][2];
+                    o[y * 3 + 2] = q ? r[y][2] : 0.0f;
+                }
+            }
+        }
+    }
+}
+extern "C" int eod_conv_up4_weights(const float* w_oihw, float* wc, int Cout, int Cin, void* stream) {
+    EOD_REQUIRE(w_oihw && wc && Cout > 0 && Cin > 0, "conv_up4_weights: bad args");
+    const long long n = (long long)Cout * Cin;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(up4_weight_sums_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, wc, Cout, Cin);
+    EOD_CHECK_LAUNCH("conv_up4_weights");
+    return EOD_OK;
+}
+
 // OIHW fp32 -> [Cout][ldk], k = tap*cin_pad + c (thin-input first conv, eod_conv_desc.w_tapmajor)
 template <typename T>
 __global__ void pack_conv_w_tapmajor_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cout, int Cin, int cin_pad, int ldk) {

@@ -131,16 +131,8 @@ class Program:
         conv whose taps are sums of the original ones; row block 2p+q holds that kernel in tap slots dy' in {p, p+1}, dx' in {q, q+1}."""
         w = self.f32(weight)
         cout, cin = w.shape[0], w.shape[1]
-        # rows: p = 0 -> slots (0: w0, 1: w1+w2); p = 1 -> slots (1: w0+w1, 2: w2); columns alike
-        rsum = [torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2], torch.zeros_like(w[:, :, 0])], 2),
-                torch.stack([torch.zeros_like(w[:, :, 0]), w[:, :, 0] + w[:, :, 1], w[:, :, 2]], 2)]
-        blocks = []
-        for pp in range(2):
-            r = rsum[pp]  # [Cout][Cin][3 slots][3 original columns]
-            csum = [torch.stack([r[..., 0], r[..., 1] + r[..., 2], torch.zeros_like(r[..., 0])], 3),
-                    torch.stack([torch.zeros_like(r[..., 0]), r[..., 0] + r[..., 1], r[..., 2]], 3)]
-            blocks += csum
-        wc = torch.cat(blocks, 0).contiguous()  # [4*Cout][Cin][3][3], classes (0,0), (0,1), (1,0), (1,1)
+        wc = torch.empty((4 * cout, cin, 3, 3), dtype=torch.float32, device=self.device)  # classes (0,0), (0,1), (1,0), (1,1)
+        check(self.L.eod_conv_up4_weights(ptr(w), ptr(wc), cout, cin, current_stream_ptr(self.device)), "conv_up4_weights")
         return self.pack_conv(self.own(wc))
 
     def _pack_conv_plain(self, weight, cin_pad=None):

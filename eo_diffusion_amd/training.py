@@ -102,6 +102,7 @@ class UNetTrainer:
         self.pgrad = {}      # Parameter -> fp32 gradient tensor
         self.repack = []     # closures refreshing derived tensors from the (updated) parameters (timestep-MLP concatenations)
         self.pack_jobs = []  # weight re-packs (forward and backward-data layouts of every conv): ONE launch per forward
+        self.up4_sums = []   # (conv, fp32 class-kernel tensor) of the parity-class upsample convs: re-formed before the re-packs
         self.recs = []
         self._keep = []
         self._scratch, self._scratch_all = {}, []
@@ -219,21 +220,34 @@ class UNetTrainer:
     # ------------------------------------------------------------------ forward emission (training form)
     def _conv_fwd(self, srcs, conv, *, ksize=3, stride=1, upsample=False, res=None, emb=None, stats=True, src_needs_grad=True):
         prog = self.prog
-        w = prog.pack_conv(conv.weight)
-        self._add_pack_job(0, conv, w)
+        fwd_ups = upsample
+        if (upsample and len(srcs) == 1 and res is None and emb is None and ksize == 3 and stride == 1
+                and prog.conv_up4_ok(srcs[0], conv.out_channels)):
+            # forward of a conv over a nearest-2x upsampling in its parity-class form (4/9 of the MACs, engine.pack_conv_up4): the class
+            # kernels are re-formed from the live weight every step (eod_conv_up4_weights), then packed like any weight; the backward
+            # keeps the nine-tap formulation on the original weight (rec.upsample)
+            cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+            wc = prog.empty((4 * cout, cin, 3, 3), torch.float32)
+            self.up4_sums.append((conv, wc))
+            w = prog.empty((9, 4 * cout, cin))
+            self._add_pack_job(0, conv, w, src=wc)
+            fwd_ups = "up4"
+        else:
+            w = prog.pack_conv(conv.weight)
+            self._add_pack_job(0, conv, w)
         kw = {}
         if emb is not None:
             kw = dict(cbias=emb[0], cbias_stride=emb[1])
         y, _ = prog.conv(srcs[0], w, prog.f32(conv.bias), conv.out_channels, x2=srcs[1] if len(srcs) > 1 else None,
-                         ksize=ksize, stride=stride, pad=ksize // 2, upsample=upsample, res=res, stats=stats, **kw)
+                         ksize=ksize, stride=stride, pad=ksize // 2, upsample=fwd_ups, res=res, stats=stats, **kw)
         self.recs.append(_ConvRec(srcs, conv, y, ksize=ksize, stride=stride, upsample=upsample, res=res, emb=emb,
                                   src_needs_grad=src_needs_grad))
         return y
 
-    def _add_pack_job(self, kind, conv, dst, cpad=None, ci0=0, nci=0):
+    def _add_pack_job(self, kind, conv, dst, cpad=None, ci0=0, nci=0, src=None):
         """kind 0: forward packing [tap][Cout][cpad = cin_pad]; kind 1: backward-data packing of input channels [ci0, ci0 + nci)
-        [taps-1-tap][ci][cpad = cout_pad] (eod_pack_jobs)"""
-        w = conv.weight.detach()
+        [taps-1-tap][ci][cpad = cout_pad] (eod_pack_jobs).  src: an fp32 OIHW tensor to pack instead of conv.weight"""
+        w = conv.weight.detach() if src is None else src
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
         j = PackJob()
         j.w, j.dst, j.kind, j.Cout, j.Cin, j.taps = ptr(w), ptr(dst), kind, cout, cin, ks * ks
@@ -819,6 +833,9 @@ class UNetTrainer:
             raise EodError("UNetTrainer: the UNet's parameter storage moved after this trainer was built (optimizer flat buffer, "
                            ".to(), load_state_dict(assign=True)); build the optimizer first or create a new UNetTrainer")
         self.step_id += 1
+        for conv, wc in self.up4_sums:  # class kernels of the parity-class upsample convs from the live weights
+            w = conv.weight.detach()
+            check(self.L.eod_conv_up4_weights(ptr(w), ptr(wc), w.shape[0], w.shape[1], current_stream_ptr(self.device)), "eod_conv_up4_weights")
         self._run_pack_jobs()
         for fn in self.repack:
             fn()

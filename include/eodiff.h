@@ -99,6 +99,9 @@ int eod_conv_split_ok(const eod_conv_desc* d);
  * _split) of a [4*Cout][Cin][3][3] weight whose row block 2p+q holds class (p, q)'s kernel in the tap slots (dy' in {p, p+1}, dx' in
  * {q, q+1}) and zeros elsewhere; Cout stays the real channel count.  1 where this form is available (fp16, or fp32 with w_split). */
 int eod_conv_up4_ok(const eod_conv_desc* d);
+/* the [4*Cout][Cin][3][3] fp32 class-kernel tensor of that form from the OIHW weight (device side: the training step re-forms it from
+ * the live parameter every step, then packs it like any weight) */
+int eod_conv_up4_weights(const float* w_oihw, float* wc, int Cout, int Cin, void* stream);
 int64_t eod_conv_workspace_size(const eod_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------
