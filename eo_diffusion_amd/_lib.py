@@ -113,6 +113,7 @@ SYMBOLS = {
     "eod_conv_split_ok": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_up4_ok": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_up4_weights": (i32, [vp, vp, i32, i32, vp]),
+    "eod_conv_up4_bwd_ok": (i32, [C.POINTER(ConvDesc)]),
     "eod_pack_conv_weight_split": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "eod_conv_workspace_size": (i64, [C.POINTER(ConvDesc)]),
     "eod_gn_apply": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),

@@ -1321,7 +1321,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
 // Schedule per chunk (4 K-steps): step s issues the weight tile of step s+1 and patch pieces 2s, 2s+1 of the NEXT chunk (s < 3); a
 // piece is split in place (fp32 storage) one step after it was issued, behind that step's MFMAs.  16x16x32 MFMAs only.
 // =============================================================================================
-template <typename T, bool SPLIT>
+// BWD = true: the BACKWARD-DATA of that conv with the same machinery (training).  dX[m][n] = sum over the four classes of a 2x2-tap conv
+// of G_pq[i][j] = dY[2i+p][2j+q] (the class's stride-2 view of the output gradient) with the transposed class kernels: class (p, q)
+// uses tap slots dy' in {1-p, 2-p}, dx' in {1-q, 2-q}.  The K loop runs over (channel chunk of dY, class): every (chunk, class) pair is
+// a "chunk" of the forward schedule with its own patch (gathered at pixel stride 2) and four taps, all accumulating into ONE dense
+// (H x W) output tile -- no (2H x 2W) intermediate, no 2x2 sum pool.  Weights: eod_pack_conv_weight_dgrad of the forward class-kernel
+// tensor [4*Cy][Cx][3][3] = [slot][Cx rows][4*Cy], class block `cls` at K offset cls*Cy (the flip of that packing maps the forward slots
+// {p, p+1} to {2-p, 1-p}, exactly the ones above).  p.H, p.W, p.Ho, p.Wo = stored (output) map; dY is (2H x 2W) with p.C0 channels.
+template <typename T, bool SPLIT, bool BWD = false>
 __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 product is a mode of fp32 storage");
     static_assert(SPLIT || sizeof(T) == 2, "fp16 storage or split fp32");
@@ -1342,9 +1349,9 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     int tile_m, tile_nn;
     map_tile(p, tile_m, tile_nn);                 // tile_nn enumerates (class, 128-column tile): the four classes of a tile run together
-    const int tpc = p.tiles_n >> 2;               // column tiles per class
-    const int cls = tile_nn / tpc, n0 = (tile_nn - cls * tpc) * BN;
-    const int par_y = cls >> 1, par_x = cls & 1;
+    const int tpc = BWD ? p.tiles_n : p.tiles_n >> 2;  // column tiles per class
+    const int cls = BWD ? 0 : tile_nn / tpc, n0 = (tile_nn - cls * tpc) * BN;
+    const int par_y = cls >> 1, par_x = cls & 1;        // (forward: the workgroup's class; backward: classes rotate inside the K loop)
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode on the STORED map: ty0, tx0, n_first
 
     const int srow = lane >> 3, sslot = lane & 7;
@@ -1358,7 +1365,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         const int hi = g.ty0 - 1 + py, wi = g.tx0 - 1 + px;
         const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         if (ok) pvalid |= 1u << i;
-        ppix[i] = (unsigned)(hi * p.W + wi);
+        ppix[i] = BWD ? (unsigned)(4 * hi * p.W + 2 * wi)   // pixel (2 hi, 2 wi) of the (2H x 2W) gradient; the class adds (p*2W + q)
+                      : (unsigned)(hi * p.W + wi);
         pck |= (unsigned)(sslot ^ ((px >> 1) & 7)) << (3 * i);
     }
     auto pchunk_of = [&](int i) { return (int)((pck >> (3 * i)) & 7u); };
@@ -1366,19 +1374,22 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int row = (wave + NW * i) * 8 + srow;
-        b_v[i] = (n0 + row < p.Cout) ? (unsigned)(row * p.Cin * ES) + bchunk0 * 16 : EOD_OOB;
+        b_v[i] = (n0 + row < p.Cout) ? (unsigned)(row * (BWD ? 4 * p.C0 : p.Cin) * ES) + bchunk0 * 16 : EOD_OOB;
     }
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.b + ((long long)cls * p.Cout + n0) * p.Cin * ES);
-    const int tapstride = 4 * p.Cout * p.Cin * ES;  // the packed tensor has 4*Cout rows per tap slot
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES * (BWD ? 4 : 1));
+    // forward: [slot][4*Cout rows][Cin];  backward: [slot][Cout (= Cx) rows][4*C0 (= 4*Cy)], class block at K offset cls*C0
+    const int bpitch = BWD ? 4 * p.C0 : p.Cin;
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.b + ((long long)cls * p.Cout + n0) * bpitch * ES);
+    const int tapstride = (BWD ? p.Cout * bpitch : 4 * p.Cout * p.Cin) * ES;
 
     struct Chunk {
-        int kin;
+        int kin, cls;  // first channel of the chunk; backward: class of this (chunk, class) pair
         bool ktail;
     };
     auto chunk_of = [&](int cc) {
         Chunk c;
-        c.kin = cc * BK;
+        c.cls = BWD ? (cc & 3) : cls;
+        c.kin = (BWD ? (cc >> 2) : cc) * BK;
         c.ktail = c.kin + BK > p.C0;
         return c;
     };
@@ -1386,7 +1397,9 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         const int pc = pchunk_of(i);
         unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(p.C0 * ES) + pc * 16 : EOD_OOB;
         if (c.ktail) v = (c.kin + pc * EPC < p.C0) ? v : EOD_OOB;
-        blds16(rsA, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
+        // backward: the class's pixel offset (p*2W + q) rides in the scalar offset
+        const unsigned soff = (unsigned)(c.kin * ES) + (BWD ? (unsigned)(((c.cls >> 1) * 2 * p.W + (c.cls & 1)) * p.C0 * ES) : 0u);
+        blds16(rsA, v, soff, abuf + (wave + NW * i) * 1024);
     };
     auto split_piece = [&](int i, char* abuf) {  // SPLIT: fp32 chunk -> its half of the pair's [8 x hi | 8 x lo] image (zeros stay zeros)
         char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
@@ -1395,10 +1408,11 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
         *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk_of(i) & 1) != 0);
     };
-    // tap slot of K-step s (a = s >> 1, b = s & 1): (par_y + a, par_x + b) of the 3x3 frame
+    // tap slot of K-step s (a = s >> 1, b = s & 1) of the 3x3 frame: forward (par_y + a, par_x + b); backward (1 - p + a, 1 - q + b)
     auto issue_weights = [&](int s, const Chunk& c, char* bst) {
-        const int tap = (par_y + (s >> 1)) * 3 + par_x + (s & 1);
-        const unsigned soff = (unsigned)(tap * tapstride) + (unsigned)(c.kin * ES);
+        const int oy = BWD ? 1 - (c.cls >> 1) : par_y, ox = BWD ? 1 - (c.cls & 1) : par_x;
+        const int tap = (oy + (s >> 1)) * 3 + ox + (s & 1);
+        const unsigned soff = (unsigned)(tap * tapstride) + (unsigned)((c.kin + (BWD ? c.cls * p.C0 : 0)) * ES);
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             unsigned v = b_v[i];
@@ -1430,19 +1444,22 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     const int lr = lane & 15, lh = lane >> 4;
     const int c0 = SPLIT ? 2 * ((0x2130 >> (4 * lh)) & 3) : lh, c1 = SPLIT ? c0 + 1 : 4 + lh;
     int acur[2][2];
+    auto set_acur = [&](int oy, int ox, int aoff) {  // first patch row / column offset of the class, patch buffer offset
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int pxc = lr + par_x + b;
-        const int key = (pxc >> 1) & 7;
-        const int rowb = ((wm * (WM / 16) + par_y) * PW + pxc) * BKB;
-        acur[0][b] = rowb + ((c0 ^ key) << 4);
-        acur[1][b] = rowb + ((c1 ^ key) << 4);
-    }
+        for (int b = 0; b < 2; ++b) {
+            const int pxc = lr + ox + b;
+            const int key = (pxc >> 1) & 7;
+            const int rowb = ((wm * (WM / 16) + oy) * PW + pxc) * BKB + aoff;
+            acur[0][b] = rowb + ((c0 ^ key) << 4);
+            acur[1][b] = rowb + ((c1 ^ key) << 4);
+        }
+    };
+    set_acur(BWD ? 1 : par_y, BWD ? 1 : par_x, 0);  // (backward: class 0 = (0, 0) -> offsets (1, 1))
     const int bsw = (lr >> 1) & 7;
     const int b_rd = (wn * WN + lr) * BKB;
     const int boff0 = b_rd + ((c0 ^ bsw) << 4), boff1 = b_rd + ((c1 ^ bsw) << 4);
 
-    const int KC = p.kc0, NSTEP = KC * 4;
+    const int KC = BWD ? 4 * p.kc0 : p.kc0, NSTEP = KC * 4;  // backward: (chunk, class) pairs
     {  // prologue: whole patch of chunk 0 + weights of step 0
         const Chunk ch0 = chunk_of(0);
 #pragma unroll
@@ -1533,7 +1550,10 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
             }
             np_prev = np;
         }
-        {  // the next chunk reads the other patch buffer
+        if constexpr (BWD) {  // next (chunk, class) pair: its class offsets, the other patch buffer
+            const int ncl = (cc + 1) & 3;
+            set_acur(1 - (ncl >> 1), 1 - (ncl & 1), ((cc + 1) & 1) * ABUF);
+        } else {              // the next chunk reads the other patch buffer
             const int flip = (cc & 1) ? -ABUF : ABUF;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -1546,21 +1566,23 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     __builtin_amdgcn_s_barrier();  // every wave is done with the operand buffers: reuse them for the epilogue
     // epilogue on the (2H x 2W) output: rows of the tile are positions (i, j) of the stored map, pixel (2i + par_y, 2j + par_x)
     IgemmP pe = p;
-    pe.par = 1; pe.par_y = par_y; pe.par_x = par_x;
     pe.Ncols = p.Cout;
-    pe.tiles_per_image = p.tiles_pi * 4;  // statistics slots: (tile of the stored map, class)
     TileGeom ge = g;
-    ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
+    if constexpr (!BWD) {
+        pe.par = 1; pe.par_y = par_y; pe.par_x = par_x;
+        pe.tiles_per_image = p.tiles_pi * 4;  // statistics slots: (tile of the stored map, class)
+        ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
+    }
     if constexpr (SPLIT) pe.alpha = p.alpha * p.w_scale[1];
     igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0);
 }
 
-template <typename T, bool SPLIT> static int launch_up4(IgemmP& p, hipStream_t st) {
+template <typename T, bool SPLIT, bool BWD = false> static int launch_up4(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     const size_t ring = 2 * (size_t)(23 * 1024) + 2 * (size_t)128 * 128;
     const size_t epi = 4 * (size_t)64 * (64 + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv_up4_halo_kernel<T, SPLIT>;
+    auto kern = conv_up4_halo_kernel<T, SPLIT, BWD>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1569,7 +1591,7 @@ template <typename T, bool SPLIT> static int launch_up4(IgemmP& p, hipStream_t s
     p.kc0 = (p.C0 + BK - 1) / BK;
     p.kc1 = 0;
     p.KT = p.kc0 * 4;
-    p.tiles_n = 4 * ((p.Cout + 127) / 128);  // (class, column tile)
+    p.tiles_n = (BWD ? 1 : 4) * ((p.Cout + 127) / 128);  // forward: (class, column tile)
     p.tw_log2 = 4;                            // 8 x 16 tiles of the STORED map
     p.th = 8;
     p.tiles_pw = p.W / 16;
@@ -1787,6 +1809,30 @@ static bool conv_up4_ok(const eod_conv_desc* d) {
            store_ok && halo_mfma_shape() == 16;
 }
 extern "C" int eod_conv_up4_ok(const eod_conv_desc* d) { return d && conv_up4_ok(d) ? 1 : 0; }
+// upsample = 4: backward-data of the parity-class upsample conv (conv_up4_halo_kernel<BWD>): x = dY [N][H][W][C0] on the (2H' x 2W') grid,
+// y = dX [N][Ho = H/2][Wo = W/2][Cout], w = eod_pack_conv_weight_dgrad of the forward class-kernel tensor ([slot][Cout][4*C0])
+static bool conv_up4_bwd_ok(const eod_conv_desc* d) {
+    return d->upsample == 4 && d->dtype == EOD_F16 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && d->C1 == 0 && !d->x2 &&
+           d->Cout > 64 && d->Cout % 8 == 0 && d->C0 % 8 == 0 && d->H % 2 == 0 && d->W % 2 == 0 && d->Ho == d->H / 2 && d->Wo == d->W / 2 &&
+           d->Wo % 16 == 0 && d->Ho % 8 == 0 && !d->out_nchw_f32 && !d->w_tapmajor && !d->gn_scale_shift && !d->stats && !d->w_split &&
+           halo_mfma_shape() == 16;
+}
+extern "C" int eod_conv_up4_bwd_ok(const eod_conv_desc* d) { return d && conv_up4_bwd_ok(d) ? 1 : 0; }
+static int conv_up4_bwd(const eod_conv_desc* d, void* stream) {
+    EOD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->Cout > 0 && d->x && d->w && d->y, "conv (upsample 4): bad args");
+    EOD_REQUIRE(conv_up4_bwd_ok(d), "conv: upsample = 4 needs a geometry for which eod_conv_up4_bwd_ok(d) == 1");
+    EOD_REQUIRE(eod_aligned16(d->x) && eod_aligned16(d->w), "conv: 16-byte alignment");
+    EOD_REQUIRE((long long)d->H * d->W * d->C0 * 2 < 0x7fffffffLL && 9LL * d->Cout * 4 * d->C0 * 2 < 0x7fffffffLL, "conv (upsample 4): operand exceeds the 2 GiB window");
+    IgemmP p = {};
+    p.a0 = (const char*)d->x; p.b = (const char*)d->w; p.bias = d->bias; p.bias_mode = d->bias ? 1 : 0;
+    p.cbias = d->cbias; p.cbias_stride = d->cbias_stride; p.res = (const char*)d->res; p.y = (char*)d->y;
+    p.N = d->N; p.H = d->Ho; p.W = d->Wo;  // the kernel works on the STORED (output) map; the gradient is (2H x 2W)
+    p.C0 = d->C0; p.C1 = 0; p.Cin = d->C0; p.Cout = d->Cout; p.KS = 3; p.stride = 1; p.pad = 1;
+    p.Ho = d->Ho; p.Wo = d->Wo; p.HoWo = d->Ho * d->Wo; p.Heff = d->Ho; p.Weff = d->Wo;
+    p.Hd = d->Ho; p.Wd = d->Wo; p.HWd = d->Ho * d->Wo;
+    p.M = (long long)d->N * d->Ho * d->Wo; p.Ncols = d->Cout; p.taps = 9; p.alpha = d->alpha; p.nb1 = 1; p.tapmajor_log2 = -1;
+    return launch_up4<half_t, false, true>(p, (hipStream_t)stream);
+}
 extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
     if (!d) return 0;
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
@@ -1830,7 +1876,7 @@ static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo, int fo
 
 // bytes of caller-provided fp32 workspace eod_conv2d_igemm needs for this descriptor (0 = none)
 extern "C" int64_t eod_conv_workspace_size(const eod_conv_desc* d) {
-    if (!d) return 0;
+    if (!d || d->upsample == 4) return 0;
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
     const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
@@ -1840,7 +1886,7 @@ extern "C" int64_t eod_conv_workspace_size(const eod_conv_desc* d) {
 }
 
 extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
-    if (!d || d->out_nchw_f32) return 0;
+    if (!d || d->out_nchw_f32 || d->upsample == 4) return 0;
     if (d->Cout % (16 / eod_esize(d->dtype))) return 0;  // statistics are accumulated on full 16-byte output chunks only
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
     const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
@@ -1859,7 +1905,8 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     const int es = eod_esize(d->dtype), epc = 16 / es;
     EOD_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv: ksize %d", d->ksize);
     EOD_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d", d->stride);
-    EOD_REQUIRE(d->upsample >= 0 && d->upsample <= 3, "conv: upsample %d", d->upsample);
+    EOD_REQUIRE(d->upsample >= 0 && d->upsample <= 4, "conv: upsample %d", d->upsample);
+    if (d->upsample == 4) return conv_up4_bwd(d, stream);
     EOD_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad dims");
     EOD_REQUIRE(d->C0 % epc == 0 && d->C1 % epc == 0, "conv: C0=%d C1=%d must be multiples of %d", d->C0, d->C1, epc);
     EOD_REQUIRE(d->x && d->w && d->y, "conv: null pointer");

@@ -191,6 +191,15 @@ class Program:
         d.w_split = int(self.split)
         return bool(self.L.eod_conv_up4_ok(C.byref(d)))
 
+    def conv_up4_bwd_ok(self, dy, cout):
+        """True if the library has the parity-class backward-data (dX at half the resolution of dy, `cout` channels) for this geometry"""
+        if os.environ.get("EOD_UP4", "1") == "0" or self.precision != "fp16" or dy.H % 2 or dy.W % 2:
+            return False
+        d = ConvDesc()
+        d.dtype, d.N, d.H, d.W, d.C0, d.C1, d.Cout = self.dt, dy.N, dy.H, dy.W, dy.C, 0, cout
+        d.ksize, d.stride, d.pad, d.upsample, d.pad_tl, d.Ho, d.Wo = 3, 1, 1, 4, 0, dy.H // 2, dy.W // 2
+        return bool(self.L.eod_conv_up4_bwd_ok(C.byref(d)))
+
     def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
              cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None, w_tapmajor=False):
         """gn = (scale_shift tensor from gn_stats(), silu): GroupNorm(+SiLU) of the conv INPUT.  Fused into the conv's
@@ -206,10 +215,14 @@ class Program:
                 x2, gn = None, None
         if upsample == "up4":  # w_packed = pack_conv_up4(weight): the parity-class form of the nearest-2x conv
             upsample = 3
+        if upsample == "up4b":  # its backward-data: x = dY on the (2Ho x 2Wo) grid, w_packed = dgrad packing of the class kernels
+            upsample = 4
         ups = 2 if upsample else 1
         heff, weff = x.H * ups + int(pad_tl), x.W * ups + int(pad_tl)
         ho = (heff + 2 * pad - ksize) // stride + 1
         wo = (weff + 2 * pad - ksize) // stride + 1
+        if upsample == 4:
+            ho, wo = x.H // 2, x.W // 2
         op, idx = self._push(OP_CONV)
         d = op.u.conv
         d.x, d.x2 = ptr(x.t), ptr(x2.t) if x2 is not None else 0

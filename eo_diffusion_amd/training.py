@@ -231,17 +231,19 @@ class UNetTrainer:
             self.up4_sums.append((conv, wc))
             w = prog.empty((9, 4 * cout, cin))
             self._add_pack_job(0, conv, w, src=wc)
-            fwd_ups = "up4"
+            fwd_ups = wc
         else:
             w = prog.pack_conv(conv.weight)
             self._add_pack_job(0, conv, w)
         kw = {}
         if emb is not None:
             kw = dict(cbias=emb[0], cbias_stride=emb[1])
+        up4_wc = fwd_ups if isinstance(fwd_ups, torch.Tensor) else None
         y, _ = prog.conv(srcs[0], w, prog.f32(conv.bias), conv.out_channels, x2=srcs[1] if len(srcs) > 1 else None,
-                         ksize=ksize, stride=stride, pad=ksize // 2, upsample=fwd_ups, res=res, stats=stats, **kw)
-        self.recs.append(_ConvRec(srcs, conv, y, ksize=ksize, stride=stride, upsample=upsample, res=res, emb=emb,
-                                  src_needs_grad=src_needs_grad))
+                         ksize=ksize, stride=stride, pad=ksize // 2, upsample=("up4" if up4_wc is not None else fwd_ups), res=res, stats=stats, **kw)
+        rec = _ConvRec(srcs, conv, y, ksize=ksize, stride=stride, upsample=upsample, res=res, emb=emb, src_needs_grad=src_needs_grad)
+        rec.up4_wc = up4_wc  # fp32 class-kernel tensor of the parity-class form (its backward-data can use it too)
+        self.recs.append(rec)
         return y
 
     def _add_pack_job(self, kind, conv, dst, cpad=None, ci0=0, nci=0, src=None):
@@ -725,6 +727,15 @@ class UNetTrainer:
         cin_total = conv.weight.shape[1]
         for xs in rec.srcs:
             cs = xs.C
+            if getattr(rec, "up4_wc", None) is not None and bp.conv_up4_bwd_ok(dy, cs):
+                # parity-class backward-data: per output parity a 2x2-tap conv of the stride-2 view of dY with the transposed class kernels,
+                # accumulated in one (H x W) tile -- no (2H x 2W) dX, no 2x2 sum pool (csrc/igemm.hip: conv_up4_halo_kernel<BWD>)
+                wd = bp.empty((9, cs, 4 * dy.C))
+                self._add_pack_job(1, conv, wd, cpad=4 * dy.C, ci0=0, nci=cs, src=rec.up4_wc)
+                g, _ = self._bop(lambda: bp.conv(dy, wd, None, cs, ksize=3, stride=1, pad=1, upsample="up4b", res=self._pop_single(xs)))
+                self._add_grad(xs, g)
+                ci0 += cs
+                continue
             wd = bp.empty((ks * ks, cs, dy.C))
             self._add_pack_job(1, conv, wd, cpad=dy.C, ci0=ci0, nci=cs)
             odd = stride == 2 and ((xs.H % 2) or (xs.W % 2))  # stride-2 conv of an odd map (unet_openai.py:262-264, e.g. 7 -> 4)

@@ -62,7 +62,8 @@ typedef struct {
     int32_t upsample;    /* 1: A is the nearest-2x upsampling of x (H,W are the stored dims);
                             2: A is x with zeros inserted between the pixels (z[2i][2j] = x[i][j]): the input of the
                             backward-data conv of a stride-2 conv (training path);
-                            3: as 1, computed as four 2x2-tap parity classes with pre-summed weights (see eod_conv_up4_ok) */
+                            3: as 1, computed as four 2x2-tap parity classes with pre-summed weights (see eod_conv_up4_ok);
+                            4: the backward-data of 3 (see eod_conv_up4_bwd_ok): x = dY on the (H x W) = (2 Ho x 2 Wo) grid */
     int32_t pad_tl;      /* 1: extra zero row/col on top/left after upsampling (3x3 -> 7x7 hack,
                             unet_openai.py:237-239)                                              */
     int32_t Ho, Wo;      /* output spatial dims */
@@ -102,6 +103,10 @@ int eod_conv_up4_ok(const eod_conv_desc* d);
 /* the [4*Cout][Cin][3][3] fp32 class-kernel tensor of that form from the OIHW weight (device side: the training step re-forms it from
  * the live parameter every step, then packs it like any weight) */
 int eod_conv_up4_weights(const float* w_oihw, float* wc, int Cout, int Cin, void* stream);
+/* upsample = 4 (fp16): dX of that conv straight from dY -- per class (p, q) a 2x2-tap conv of the stride-2 view dY[2i+p][2j+q] with the
+ * transposed class kernels, the four accumulated in one dense (Ho x Wo) tile (no (2Ho x 2Wo) intermediate, no 2x2 sum pool).  w =
+ * eod_pack_conv_weight_dgrad (cout_pad = 4*C0) of the class-kernel tensor of eod_conv_up4_weights; Cout = channels of dX. */
+int eod_conv_up4_bwd_ok(const eod_conv_desc* d);
 int64_t eod_conv_workspace_size(const eod_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------

@@ -572,3 +572,36 @@ def test_group_norm_silu_backward_kernels(prec, N, C0, C1, H, W, silu):
     tol = 2e-5 if prec == "fp32" else 3e-3
     assert rel_l2(torch.cat(dxs, 1), xr.grad) < tol
     assert rel_l2(dgam.cpu(), gr.grad) < tol and rel_l2(dbet.cpu(), br.grad) < tol
+
+
+@pytest.mark.parametrize("case", [(2, 128, 8, 16, 128, False), (1, 96, 16, 32, 192, True), (3, 72, 24, 16, 256, False), (1, 640, 16, 16, 160, True)])
+def test_conv_nearest_upsample_parity_class_backward_data_vs_autograd(case):
+    """upsample='up4b' (conv_up4_halo_kernel<BWD>, fp16): dX of `3x3 conv over the nearest-2x upsampling of x` straight from dY -- four
+    2x2-tap convs over the stride-2 views of dY with the transposed class kernels (eod_conv_up4_weights -> eod_pack_conv_weight_dgrad),
+    accumulated in one tile, plus an optional second gradient branch (`res`) -- vs torch autograd through F.interpolate + F.conv2d"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import Act, current_stream_ptr
+    N, Cx, H, W, Cy, with_res = case
+    x = synth_input(f"u4bx{case}", (N, Cx, H, W), 44).half().float().requires_grad_(True)
+    w = synth_input(f"u4bw{case}", (Cy, Cx, 3, 3), 44, scale=1.0 / math.sqrt(Cx * 9)).half().float()
+    dy = synth_input(f"u4bd{case}", (N, Cy, 2 * H, 2 * W), 44).half().float()
+    r = synth_input(f"u4br{case}", (N, Cx, H, W), 44).half().float()
+    F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, None, padding=1).backward(dy)
+    ref = x.grad + (r if with_res else 0)
+
+    def emit(prog, a):  # a = dY as the program's input activation
+        L = prog.L
+        st = current_stream_ptr(prog.device)
+        assert prog.conv_up4_bwd_ok(a, Cx)
+        wd_ = w.to(DEV).contiguous()
+        wc = prog.own(torch.empty((4 * Cy, Cx, 3, 3), dtype=torch.float32, device=DEV))
+        _lib.check(L.eod_conv_up4_weights(wd_.data_ptr(), wc.data_ptr(), Cy, Cx, st), "conv_up4_weights")
+        wd = prog.empty((9, Cx, 4 * Cy))
+        _lib.check(L.eod_pack_conv_weight_dgrad(wc.data_ptr(), wd.data_ptr(), prog.dt, 4 * Cy, Cx, 3, 0, Cx, 4 * Cy, st), "pack_dgrad")
+        rr = Act(prog.own(r.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), N, H, W, Cx) if with_res else None
+        g, _ = prog.conv(a, wd, None, Cx, ksize=3, stride=1, pad=1, upsample="up4b", res=rr)
+        return g
+
+    got = run_program("fp16", dy, emit)
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
