@@ -82,6 +82,7 @@ SYMBOLS = {
     "eod_channel_sums_finish": (i32, [vp, i32, i32, i32, i32, f32, vp, vp, i64, vp, vp]),
     "eod_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]),
     "eod_conv3x3_wgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "eod_wgrad_up4_map": (i32, [vp, i32, i32, vp, vp]),
     "eod_conv1x1_wgrad": (i32, [vp, vp, i32, i64, i32, i32, i32, vp, i32, i32, vp]),
     "eod_gn_mean_rstd": (i32, [vp, i32, i32, vp, i32, i32, i32, i64, i32, f32, vp, vp]),
     "eod_gn_bwd_partial": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),

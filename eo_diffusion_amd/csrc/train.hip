@@ -283,13 +283,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 extern "C" int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout, int nci, int ldp, int ci0, int Cin, float scale,
                                 float* dw_oihw, void* stream) {
-    EOD_REQUIRE(partial && dw_oihw && S > 0 && (ksize == 1 || ksize == 3) && Cout > 0 && nci > 0 && ldp >= nci && ci0 >= 0 && ci0 + nci <= Cin,
-                "wgrad_reduce: bad args");
+    EOD_REQUIRE(partial && dw_oihw && S > 0 && (ksize == 1 || ksize == 3 || ksize == 4) && Cout > 0 && nci > 0 && ldp >= nci && ci0 >= 0 && ci0 + nci <= Cin,
+                "wgrad_reduce: bad args");  // (ksize 4: the 16 tap planes of the parity-class form, folded by eod_wgrad_up4_map)
     EOD_REQUIRE(ldp % 4 == 0 && eod_aligned16(partial), "wgrad_reduce: the partial tiles need 16-byte rows (ldp %% 4 == 0)");
     const long long quads = (long long)Cout * ((nci + 3) / 4);
     const long long blocks = (quads + 63) / 64;
     EOD_REQUIRE(blocks <= 0x7fffffffLL, "wgrad_reduce: grid too large");
-    if (ksize == 3)
+    if (ksize == 4)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, S, Cout, nci, ldp, ci0, Cin, scale, dw_oihw);
+    else if (ksize == 3)
         hipLaunchKernelGGL(wgrad_reduce_kernel<9>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, S, Cout, nci, ldp, ci0, Cin, scale, dw_oihw);
     else
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, partial, S, Cout, nci, ldp, ci0, Cin, scale, dw_oihw);
@@ -1107,7 +1109,12 @@ __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row
 // WS = image-row width covered by a strip (64: one 64-pixel segment of a row; 32 / 16: 2 / 4 whole rows of a 32- / 16-wide map).
 // Pixel k of the strip lies in image row r = k / WS; its X row for tap kx is staged at  k + 16*r + kx  (every image row gets its own
 // left / right halo, and the 16-row pitch keeps swz(row) invariant under the k -> k + 16 steps of the MFMA sub-steps).
-template <int WS>
+// CLS = true (p.ups == 2): the conv input is the nearest-2x upsampling of X and the weight gradient is taken in the parity-class form of
+// csrc/igemm.hip (conv_up4_halo_kernel): for class (p, q) and row tap a the workgroup correlates the stride-2 view G_pq[i][j] =
+// dY[2i+p][2j+q] with X rows i - 1 + p + a, the two column taps b being X row offsets q + b:
+//   dW'_pq[a][b][co][ci] = sum_{n,i,j} G_pq[i][j][co] * X[i-1+p+a][j-1+q+b][ci]        (16 tap products per stored position, not 36)
+// strips walk the STORED (H x W) map; partial[split][((2p+q)*2 + a)*2 + b][co][ci]; eod_wgrad_up4_map folds the 16 back into the 9.
+template <int WS, bool CLS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
     constexpr int RPS = 64 / WS, RPITCH = WS + 16;                    // image rows per strip, staged-row pitch of an image row
     constexpr int A_ROWS = 64, X_ROWS = ((RPS - 1) * RPITCH + WS + 2 + 3) / 4 * 4, ROWB = 256, XG = X_ROWS / 4;
@@ -1120,11 +1127,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
     int b = blockIdx.x;
     const int tile_ci = b % p.tiles_ci; b /= p.tiles_ci;
     const int tile_co = b % p.tiles_co; b /= p.tiles_co;
-    const int ky = b % 3;
-    const int split = b / 3;
+    constexpr int NKY = CLS ? 8 : 3, NKX = CLS ? 2 : 3;
+    const int kyi = b % NKY;
+    const int split = b / NKY;
+    const int cp = CLS ? kyi >> 2 : 0, cq = CLS ? (kyi >> 1) & 1 : 0;   // class (p, q)
+    const int ky = CLS ? cp + (kyi & 1) : kyi;                          // X row of the strip's image row h: h + ky - 1
     const int co0 = tile_co * 128, ci0 = tile_ci * 128;
     const int s_begin = split * p.strips_per, s_end = min(p.strips_total, s_begin + p.strips_per);
-    const int Heff = p.ups ? 2 * p.H : p.H, Weff = p.ups ? 2 * p.W : p.W;
+    const int Heff = (!CLS && p.ups) ? 2 * p.H : p.H, Weff = (!CLS && p.ups) ? 2 * p.W : p.W;
+    const int Hs = CLS ? p.H : p.Ho, Ws = CLS ? p.W : p.Wo;             // the map the strips walk
 
     // ---- DMA slots: one instruction = 4 tile rows x 16 chunks; this lane: row (4*grp + lane/16), LDS slot lane%16 ----
     const int drow = lane >> 4, dslot = lane & 15;
@@ -1133,10 +1144,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
     constexpr unsigned OOB = 0x80000000u;
     auto issue_strip = [&](int strip, int stage) {
         // strip -> (n, h, w0): 64 consecutive pixels of one image in raster order
-        const int spi = p.Ho * p.Wo / 64;  // strips per image
+        const int spi = Hs * Ws / 64;  // strips per image
         const int n = strip / spi;
         const int pix0 = (strip - n * spi) * 64;
-        const int h = pix0 / p.Wo, w0 = pix0 - h * p.Wo;
+        const int h = pix0 / Ws, w0 = pix0 - h * Ws;
         char* sa = smem + stage * STAGE;
         char* sx = sa + A_BYTES;
         // dY: groups wave, wave+4, wave+8, wave+12 (4 rows each)
@@ -1144,7 +1155,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
         for (int i = 0; i < 4; ++i) {
             const int row = (wave + 4 * i) * 4 + drow;
             const int chunk = dslot ^ wg_swz(row);
-            const long long pix = (long long)n * p.Ho * p.Wo + pix0 + row;
+            long long pix = (long long)n * p.Ho * p.Wo + pix0 + row;
+            if constexpr (CLS) {  // stored position (h + row / WS, w0 + row % WS) -> pixel (2 i + p, 2 j + q) of the (2H x 2W) gradient
+                const int ir = h + row / WS, jc = w0 + row % WS;
+                pix = ((long long)n * p.Ho + 2 * ir + cp) * p.Wo + 2 * jc + cq;
+            }
             const int c = co0 + chunk * 8;
             const unsigned v = c < p.Cy ? (unsigned)((pix * p.Cy + c) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(sa + (wave + 4 * i) * 1024), 16, v, 0, 0, 0);
@@ -1161,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
                 const int c = ci0 + chunk * 8;
                 const bool ok = r < RPS && rr < WS + 2 && (unsigned)hh < (unsigned)Heff && (unsigned)ww < (unsigned)Weff && c < p.Cx;
                 int hs = hh, ws = ww;
-                if (p.ups) {
+                if (!CLS && p.ups) {
                     hs >>= 1;
                     ws >>= 1;
                 }
@@ -1186,7 +1201,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
         for (int i = 0; i < 2; ++i) {
             a_ad[j][i] = tr_addr(row, wm * 64 + i * 32 + (g & 1) * 16 + 4 * pp);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) b_ad[kx][j][i] = A_BYTES + tr_addr(row + kx, wn * 64 + i * 32 + (g & 1) * 16 + 4 * pp);
+            for (int kx = 0; kx < 3; ++kx) b_ad[kx][j][i] = A_BYTES + tr_addr(row + kx + cq, wn * 64 + i * 32 + (g & 1) * 16 + 4 * pp);
         }
     }
 
@@ -1222,7 +1237,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
                 }
             }
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
+            for (int kx = 0; kx < NKX; ++kx) {
                 half8 fb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -1246,8 +1261,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
     // ---- epilogue: C layout (lane&31 = ci column, regs = co rows) -> fp32 partial tile ----
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        float* base = p.partial + ((long long)split * 9 + ky * 3 + kx) * p.Cout * p.ldp;
+    for (int kx = 0; kx < NKX; ++kx) {
+        float* base = p.partial + (CLS ? ((long long)split * 16 + kyi * 2 + kx) : ((long long)split * 9 + ky * 3 + kx)) * p.Cout * p.ldp;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1267,9 +1282,12 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
     EOD_REQUIRE(dy && x && partial && N > 0 && H > 0 && W > 0 && Cx > 0 && Ho > 0 && Wo > 0 && Cy > 0 && Cout > 0 && S > 0 && ldp >= Cx,
                 "conv3x3_wgrad: bad args");
     EOD_REQUIRE(dtype == EOD_F16, "conv3x3_wgrad: fp16 only (the transposed LDS read is a 16-bit instruction)");
-    const int ws = Wo % 64 == 0 ? 64 : Wo;
-    EOD_REQUIRE((ws == 64 || ws == 32 || ws == 16) && (Ho * Wo) % 64 == 0 && Cx % 8 == 0 && Cy % 8 == 0 && Cout <= Cy,
-                "conv3x3_wgrad: needs Wo %% 64 == 0 (or Wo = 32 / 16 with Ho*Wo %% 64 == 0) and channel counts that are multiples of 8");
+    EOD_REQUIRE(ups >= 0 && ups <= 2, "conv3x3_wgrad: ups %d", ups);
+    const bool cls = ups == 2;  // parity-class form: strips walk the stored (H x W) map, 16 tap planes per split
+    const int Hs = cls ? H : Ho, Ws = cls ? W : Wo;
+    const int ws = Ws % 64 == 0 ? 64 : Ws;
+    EOD_REQUIRE((ws == 64 || ws == 32 || ws == 16) && (Hs * Ws) % 64 == 0 && Cx % 8 == 0 && Cy % 8 == 0 && Cout <= Cy,
+                "conv3x3_wgrad: needs a map width %% 64 == 0 (or 32 / 16 with H*W %% 64 == 0) and channel counts that are multiples of 8");
     EOD_REQUIRE(Ho == (ups ? 2 * H : H) && Wo == (ups ? 2 * W : W), "conv3x3_wgrad: stride-1 / pad-1 geometry expected");
     EOD_REQUIRE(eod_aligned16(dy) && eod_aligned16(x), "conv3x3_wgrad: 16-byte alignment");
     EOD_REQUIRE((long long)N * Ho * Wo * Cy * 2 < 0x7fffffffLL && (long long)N * H * W * Cx * 2 < 0x7fffffffLL, "conv3x3_wgrad: tensors exceed the 2 GiB buffer window");
@@ -1279,21 +1297,54 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
     p.tiles_co = (Cout + 127) / 128;
     p.tiles_ci = (Cx + 127) / 128;
     p.strips_w = 0;
-    p.strips_total = N * (Ho * Wo / 64);
+    p.strips_total = N * (Hs * Ws / 64);
     p.strips_per = (p.strips_total + S - 1) / S;
-    const long long grid = (long long)p.tiles_co * p.tiles_ci * 3 * S;
+    const long long grid = (long long)p.tiles_co * p.tiles_ci * (cls ? 8 : 3) * S;
     EOD_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_wgrad: grid too large");
     const int rps = 64 / ws, xrows = ((rps - 1) * (ws + 16) + ws + 2 + 3) / 4 * 4;
     const size_t lds = 2 * (size_t)(64 * 256 + xrows * 256);
-    void (*kern)(const WgradP) = ws == 64 ? conv3x3_wgrad_kernel<64> : ws == 32 ? conv3x3_wgrad_kernel<32> : conv3x3_wgrad_kernel<16>;
-    static bool attr_done[3] = {false, false, false};
+    void (*kern)(const WgradP) =
+        cls ? (ws == 64 ? conv3x3_wgrad_kernel<64, true> : ws == 32 ? conv3x3_wgrad_kernel<32, true> : conv3x3_wgrad_kernel<16, true>)
+            : (ws == 64 ? conv3x3_wgrad_kernel<64, false> : ws == 32 ? conv3x3_wgrad_kernel<32, false> : conv3x3_wgrad_kernel<16, false>);
+    static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
     const int vi = ws == 64 ? 0 : ws == 32 ? 1 : 2;
-    if (!attr_done[vi]) {
+    if (!attr_done[cls][vi]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done[vi] = true;
+        attr_done[cls][vi] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     EOD_CHECK_LAUNCH("conv3x3_wgrad");
+    return EOD_OK;
+}
+
+// dW[co][ci][ky][kx] (+)= sum over the classes of dW'[co][ci][(2p+q)*4 + a(p,ky)*2 + b(q,kx)]: the transpose of the tap sums that form
+// the class kernels (rows: class 0 puts w0 in slot a = 0 and w1 + w2 in a = 1, class 1 puts w0 + w1 in a = 0 and w2 in a = 1)
+__global__ void wgrad_up4_map_kernel(const float* __restrict__ t16, long long n, float* __restrict__ dw) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(v + 4 * k) = *reinterpret_cast<const f32x4*>(t16 + i * 16 + 4 * k);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {
+                    const int p = pq >> 1, q = pq & 1;
+                    const int a = p ? (ky == 2) : (ky != 0), b = q ? (kx == 2) : (kx != 0);
+                    acc += v[pq * 4 + a * 2 + b];
+                }
+                dw[i * 9 + ky * 3 + kx] = acc;
+            }
+    }
+}
+extern "C" int eod_wgrad_up4_map(const float* t16, int Cout, int Cin, float* dw_oihw, void* stream) {
+    EOD_REQUIRE(t16 && dw_oihw && Cout > 0 && Cin > 0 && eod_aligned16(t16), "wgrad_up4_map: bad args");
+    const long long n = (long long)Cout * Cin;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(wgrad_up4_map_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t16, n, dw_oihw);
+    EOD_CHECK_LAUNCH("wgrad_up4_map");
     return EOD_OK;
 }
 

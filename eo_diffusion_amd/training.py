@@ -637,6 +637,21 @@ class UNetTrainer:
             cs = xs.C
             cs_real = min(cs, cin_total - ci0)
             ldp = round_up(cs, 4)
+            up4 = (ks == 3 and getattr(rec, "up4_wc", None) is not None and os.environ.get("EOD_UP4", "1") != "0"
+                   and (xs.W % 64 == 0 or (xs.W in (16, 32) and (xs.H * xs.W) % 64 == 0)))
+            if up4:
+                # parity-class form (csrc/train.hip: conv3x3_wgrad_kernel<WS, CLS>): 16 class / tap correlations of the stride-2 views of dY
+                # with X at its stored resolution -- 4/9 of the MACs of the nine taps over the 2H x 2W gradient -- folded back into dW
+                tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 8
+                strips4 = xs.N * (xs.H * xs.W // 64)
+                S = max(1, min(strips4, (int(os.environ.get("EOD_WGRAD_WGS", "512")) + tiles - 1) // tiles))
+                partial = bp.empty((S * 16 * cout * ldp,), torch.float32)
+                t16 = bp.empty((cout * cin_total * 16,), torch.float32)
+                self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, 2, ptr(partial), ldp, S)
+                self._call(L.eod_wgrad_reduce, ptr(partial), S, 4, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(t16))
+                self._call(L.eod_wgrad_up4_map, ptr(t16), cout, cin_total, ptr(dW))
+                ci0 += cs_real
+                continue
             tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * ks
             S = max(1, min(strips, (int(os.environ.get("EOD_WGRAD_WGS", "512")) + tiles - 1) // tiles))
             partial = bp.empty((S * ks * ks * cout * ldp,), torch.float32)

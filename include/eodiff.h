@@ -348,6 +348,10 @@ int eod_wgrad_reduce(const float* partial, int S, int ksize, int Cout, int nci, 
  * fp32 partial tiles partial[S][9][Cout][ldp] that eod_wgrad_reduce sums (csrc/train.hip: conv3x3_wgrad_kernel) */
 int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N, int H, int W, int Cx, int Ho, int Wo, int Cy, int Cout,
                       int ups, float* partial, int ldp, int S, void* stream);
+/* ups = 2: the same for a conv whose input is the nearest-2x upsampling of X, in the parity-class form (see eod_conv_up4_ok): 16 tap
+ * planes partial[S][((2p+q)*2 + a)*2 + b][Cout][ldp] from the stride-2 views of dY (4/9 of the MACs of ups = 1);
+ * eod_wgrad_reduce(ksize = 4) sums the splits into [Cout][Cin][16], eod_wgrad_up4_map folds those into dW_oihw [Cout][Cin][3][3] */
+int eod_wgrad_up4_map(const float* t16, int Cout, int Cin, float* dw_oihw, void* stream);
 /* the same for a 1x1 / stride-1 conv (skip connections, attention projections; F.conv2d / conv1d backward-weights behind
  * unet_openai.py:345,409,413): dW[co][ci] = sum_pix dY[pix][co] X[pix][ci] over npix = N*H*W pixel-major rows, split over S
  * pixel ranges into partial[S][1][Cout][ldp] (fp16, channels % 8 == 0; csrc/train.hip: gemm_tn_kernel) */

@@ -605,3 +605,28 @@ def test_conv_nearest_upsample_parity_class_backward_data_vs_autograd(case):
     got = run_program("fp16", dy, emit)
     assert got.shape == ref.shape
     assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
+
+
+@pytest.mark.parametrize("N,H,W,Cx,Cout", [(2, 8, 64, 40, 24), (1, 16, 32, 136, 128), (3, 8, 16, 8, 200), (1, 4, 128, 64, 64)])
+def test_conv3x3_backward_weights_parity_class_form(N, H, W, Cx, Cout):
+    """eod_conv3x3_wgrad(ups = 2) + eod_wgrad_reduce(ksize 4) + eod_wgrad_up4_map: the weight gradient of a 3x3 conv over the nearest-2x
+    upsampling of X from the 16 class / tap correlations of the stride-2 views of dY (4/9 of the MACs of the nine-tap form) vs torch"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    x = synth_input(f"wcx{N}{H}{W}{Cx}", (N, Cx, H, W), 15).half()
+    dy = synth_input(f"wcy{N}{H}{W}{Cout}", (N, Cout, 2 * H, 2 * W), 16, scale=0.5).half()
+    ref = torch.nn.grad.conv2d_weight(F.interpolate(x.float(), scale_factor=2, mode="nearest"), (Cout, Cx, 3, 3), dy.float(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    st = current_stream_ptr(torch.device(DEV))
+    for S in (1, 3):
+        partial = torch.full((S, 16, Cout, Cx), 7.0, dtype=torch.float32, device=DEV)
+        t16 = torch.zeros((Cout, Cx, 16), dtype=torch.float32, device=DEV)
+        dw = torch.zeros((Cout, Cx, 3, 3), dtype=torch.float32, device=DEV)
+        _lib.check(L.eod_conv3x3_wgrad(dyd.data_ptr(), xd.data_ptr(), _lib.EOD_F16, N, H, W, Cx, 2 * H, 2 * W, Cout, Cout, 2, partial.data_ptr(), Cx, S, st),
+                   "conv3x3_wgrad")
+        _lib.check(L.eod_wgrad_reduce(partial.data_ptr(), S, 4, Cout, Cx, Cx, 0, Cx, 1.0, t16.data_ptr(), st), "wgrad_reduce")
+        _lib.check(L.eod_wgrad_up4_map(t16.data_ptr(), Cout, Cx, dw.data_ptr(), st), "wgrad_up4_map")
+        torch.cuda.synchronize()
+        assert rel_l2(dw.cpu(), ref) < 2e-3, (S, rel_l2(dw.cpu(), ref))
