@@ -1114,8 +1114,13 @@ __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row
 // dY[2i+p][2j+q] with X rows i - 1 + p + a, the two column taps b being X row offsets q + b:
 //   dW'_pq[a][b][co][ci] = sum_{n,i,j} G_pq[i][j][co] * X[i-1+p+a][j-1+q+b][ci]        (16 tap products per stored position, not 36)
 // strips walk the STORED (H x W) map; partial[split][((2p+q)*2 + a)*2 + b][co][ci]; eod_wgrad_up4_map folds the 16 back into the 9.
-template <int WS, bool CLS = false>
+// MODE 2 (p.ups == 3): STRIDE-2 conv (Downsample.op).  dW[ky][kx] = sum dY[oh][ow] X[2oh+ky-1][2ow+kx-1]: strips walk dY, the X row is
+// gathered at pixel stride 2 in one of two column phases per workgroup -- odd columns 2(w0+j)-1 serve kx = 0 and kx = 2 (row offsets 0
+// and 1), even columns 2(w0+j) serve kx = 1 -- so the workgroup index enumerates (ky, phase) and the planes land in the ordinary
+// partial[split][ky*3+kx] layout (no transposed copies, no GEMM path).
+template <int WS, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
+    constexpr bool CLS = MODE == 1, S2 = MODE == 2;
     constexpr int RPS = 64 / WS, RPITCH = WS + 16;                    // image rows per strip, staged-row pitch of an image row
     constexpr int A_ROWS = 64, X_ROWS = ((RPS - 1) * RPITCH + WS + 2 + 3) / 4 * 4, ROWB = 256, XG = X_ROWS / 4;
     constexpr int A_BYTES = A_ROWS * ROWB, X_BYTES = X_ROWS * ROWB, STAGE = A_BYTES + X_BYTES;  // 16 KiB + 17 KiB
@@ -1127,14 +1132,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
     int b = blockIdx.x;
     const int tile_ci = b % p.tiles_ci; b /= p.tiles_ci;
     const int tile_co = b % p.tiles_co; b /= p.tiles_co;
-    constexpr int NKY = CLS ? 8 : 3, NKX = CLS ? 2 : 3;
+    constexpr int NKY = CLS ? 8 : S2 ? 6 : 3, NKX = (CLS || S2) ? 2 : 3;
     const int kyi = b % NKY;
     const int split = b / NKY;
     const int cp = CLS ? kyi >> 2 : 0, cq = CLS ? (kyi >> 1) & 1 : 0;   // class (p, q)
-    const int ky = CLS ? cp + (kyi & 1) : kyi;                          // X row of the strip's image row h: h + ky - 1
+    const int ky = CLS ? cp + (kyi & 1) : S2 ? kyi >> 1 : kyi;          // X row of the strip's image row h: h + ky - 1
+    const int phase = S2 ? kyi & 1 : 0;                                 // stride 2: 0 = odd columns (kx 0 / 2), 1 = even columns (kx 1)
     const int co0 = tile_co * 128, ci0 = tile_ci * 128;
     const int s_begin = split * p.strips_per, s_end = min(p.strips_total, s_begin + p.strips_per);
-    const int Heff = (!CLS && p.ups) ? 2 * p.H : p.H, Weff = (!CLS && p.ups) ? 2 * p.W : p.W;
+    const int Heff = (MODE == 0 && p.ups) ? 2 * p.H : p.H, Weff = (MODE == 0 && p.ups) ? 2 * p.W : p.W;
     const int Hs = CLS ? p.H : p.Ho, Ws = CLS ? p.W : p.Wo;             // the map the strips walk
 
     // ---- DMA slots: one instruction = 4 tile rows x 16 chunks; this lane: row (4*grp + lane/16), LDS slot lane%16 ----
@@ -1172,11 +1178,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
                 const int row = grp * 4 + drow;
                 const int chunk = dslot ^ wg_swz(row);
                 const int r = row / RPITCH, rr = row - r * RPITCH;
-                const int hh = h + r + ky - 1, ww = w0 - 1 + rr;
+                const int hh = S2 ? 2 * (h + r) + ky - 1 : h + r + ky - 1;
+                const int ww = S2 ? 2 * (w0 + rr) - 1 + phase : w0 - 1 + rr;
                 const int c = ci0 + chunk * 8;
                 const bool ok = r < RPS && rr < WS + 2 && (unsigned)hh < (unsigned)Heff && (unsigned)ww < (unsigned)Weff && c < p.Cx;
                 int hs = hh, ws = ww;
-                if (!CLS && p.ups) {
+                if (MODE == 0 && p.ups) {
                     hs >>= 1;
                     ws >>= 1;
                 }
@@ -1262,7 +1269,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradP p) {
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int kx = 0; kx < NKX; ++kx) {
-        float* base = p.partial + (CLS ? ((long long)split * 16 + kyi * 2 + kx) : ((long long)split * 9 + ky * 3 + kx)) * p.Cout * p.ldp;
+        if (S2 && phase == 1 && kx == 1) break;  // the even phase carries one tap
+        const int plane = CLS ? kyi * 2 + kx : S2 ? ky * 3 + (phase ? 1 : 2 * kx) : ky * 3 + kx;
+        float* base = p.partial + ((long long)split * (CLS ? 16 : 9) + plane) * p.Cout * p.ldp;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1282,13 +1291,15 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
     EOD_REQUIRE(dy && x && partial && N > 0 && H > 0 && W > 0 && Cx > 0 && Ho > 0 && Wo > 0 && Cy > 0 && Cout > 0 && S > 0 && ldp >= Cx,
                 "conv3x3_wgrad: bad args");
     EOD_REQUIRE(dtype == EOD_F16, "conv3x3_wgrad: fp16 only (the transposed LDS read is a 16-bit instruction)");
-    EOD_REQUIRE(ups >= 0 && ups <= 2, "conv3x3_wgrad: ups %d", ups);
+    EOD_REQUIRE(ups >= 0 && ups <= 3, "conv3x3_wgrad: ups %d", ups);
     const bool cls = ups == 2;  // parity-class form: strips walk the stored (H x W) map, 16 tap planes per split
+    const bool s2 = ups == 3;   // stride-2 conv: X is (H x W) = (2 Ho x 2 Wo), gathered at pixel stride 2
     const int Hs = cls ? H : Ho, Ws = cls ? W : Wo;
     const int ws = Ws % 64 == 0 ? 64 : Ws;
     EOD_REQUIRE((ws == 64 || ws == 32 || ws == 16) && (Hs * Ws) % 64 == 0 && Cx % 8 == 0 && Cy % 8 == 0 && Cout <= Cy,
                 "conv3x3_wgrad: needs a map width %% 64 == 0 (or 32 / 16 with H*W %% 64 == 0) and channel counts that are multiples of 8");
-    EOD_REQUIRE(Ho == (ups ? 2 * H : H) && Wo == (ups ? 2 * W : W), "conv3x3_wgrad: stride-1 / pad-1 geometry expected");
+    EOD_REQUIRE(s2 ? (H == 2 * Ho && W == 2 * Wo) : (Ho == (ups ? 2 * H : H) && Wo == (ups ? 2 * W : W)),
+                "conv3x3_wgrad: stride-1 / pad-1 geometry (or, ups = 3, a stride-2 conv of an even map) expected");
     EOD_REQUIRE(eod_aligned16(dy) && eod_aligned16(x), "conv3x3_wgrad: 16-byte alignment");
     EOD_REQUIRE((long long)N * Ho * Wo * Cy * 2 < 0x7fffffffLL && (long long)N * H * W * Cx * 2 < 0x7fffffffLL, "conv3x3_wgrad: tensors exceed the 2 GiB buffer window");
     WgradP p;
@@ -1299,18 +1310,20 @@ extern "C" int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N
     p.strips_w = 0;
     p.strips_total = N * (Hs * Ws / 64);
     p.strips_per = (p.strips_total + S - 1) / S;
-    const long long grid = (long long)p.tiles_co * p.tiles_ci * (cls ? 8 : 3) * S;
+    const long long grid = (long long)p.tiles_co * p.tiles_ci * (cls ? 8 : s2 ? 6 : 3) * S;
     EOD_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_wgrad: grid too large");
     const int rps = 64 / ws, xrows = ((rps - 1) * (ws + 16) + ws + 2 + 3) / 4 * 4;
     const size_t lds = 2 * (size_t)(64 * 256 + xrows * 256);
+    const int mode = cls ? 1 : s2 ? 2 : 0;
     void (*kern)(const WgradP) =
-        cls ? (ws == 64 ? conv3x3_wgrad_kernel<64, true> : ws == 32 ? conv3x3_wgrad_kernel<32, true> : conv3x3_wgrad_kernel<16, true>)
-            : (ws == 64 ? conv3x3_wgrad_kernel<64, false> : ws == 32 ? conv3x3_wgrad_kernel<32, false> : conv3x3_wgrad_kernel<16, false>);
-    static bool attr_done[2][3] = {{false, false, false}, {false, false, false}};
+        mode == 1 ? (ws == 64 ? conv3x3_wgrad_kernel<64, 1> : ws == 32 ? conv3x3_wgrad_kernel<32, 1> : conv3x3_wgrad_kernel<16, 1>)
+      : mode == 2 ? (ws == 64 ? conv3x3_wgrad_kernel<64, 2> : ws == 32 ? conv3x3_wgrad_kernel<32, 2> : conv3x3_wgrad_kernel<16, 2>)
+                  : (ws == 64 ? conv3x3_wgrad_kernel<64, 0> : ws == 32 ? conv3x3_wgrad_kernel<32, 0> : conv3x3_wgrad_kernel<16, 0>);
+    static bool attr_done[3][3] = {{false, false, false}, {false, false, false}, {false, false, false}};
     const int vi = ws == 64 ? 0 : ws == 32 ? 1 : 2;
-    if (!attr_done[cls][vi]) {
+    if (!attr_done[mode][vi]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done[cls][vi] = true;
+        attr_done[mode][vi] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
     EOD_CHECK_LAUNCH("conv3x3_wgrad");

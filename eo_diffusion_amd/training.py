@@ -652,12 +652,12 @@ class UNetTrainer:
                 self._call(L.eod_wgrad_up4_map, ptr(t16), cout, cin_total, ptr(dW))
                 ci0 += cs_real
                 continue
-            tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * ks
+            tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * (6 if rec.stride == 2 else ks)
             S = max(1, min(strips, (int(os.environ.get("EOD_WGRAD_WGS", "512")) + tiles - 1) // tiles))
             partial = bp.empty((S * ks * ks * cout * ldp,), torch.float32)
-            if ks == 3:
-                self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, int(bool(rec.upsample)),
-                           ptr(partial), ldp, S)
+            if ks == 3:  # (ups 3 = stride-2 conv: X gathered at pixel stride 2)
+                self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout,
+                           3 if rec.stride == 2 else int(bool(rec.upsample)), ptr(partial), ldp, S)
             else:
                 self._call(L.eod_conv1x1_wgrad, ptr(dy.t), ptr(xs.t), dt, npix, cs, dy.C, cout, ptr(partial), ldp, S)
             self._call(L.eod_wgrad_reduce, ptr(partial), S, ks, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(dW))
@@ -689,8 +689,9 @@ class UNetTrainer:
         ld = S * Kper
         shift_dy = None
         # dedicated backward-weights kernel (no transposed copies) where it applies; the GEMM path otherwise
-        geom = ((s1 and (Wo % 64 == 0 or (Wo in (16, 32) and (Ho * Wo) % 64 == 0)))
-                or (ks == 1 and stride == 1 and not rec.upsample))
+        strip_ok = Wo % 64 == 0 or (Wo in (16, 32) and (Ho * Wo) % 64 == 0)
+        s2 = (ks == 3 and stride == 2 and not rec.upsample and all(x.H == 2 * Ho and x.W == 2 * Wo for x in rec.srcs))  # even maps
+        geom = ((s1 or s2) and strip_ok) or (ks == 1 and stride == 1 and not rec.upsample)
         direct = (geom and self.prog.precision == "fp16"
                   and dy.C % 8 == 0 and all(x.C % 8 == 0 for x in rec.srcs)
                   and dy.t.numel() * es < 2**31 and all(x.t.numel() * es < 2**31 for x in rec.srcs)

@@ -352,6 +352,8 @@ int eod_conv3x3_wgrad(const void* dy, const void* x, int dtype, int N, int H, in
  * planes partial[S][((2p+q)*2 + a)*2 + b][Cout][ldp] from the stride-2 views of dY (4/9 of the MACs of ups = 1);
  * eod_wgrad_reduce(ksize = 4) sums the splits into [Cout][Cin][16], eod_wgrad_up4_map folds those into dW_oihw [Cout][Cin][3][3] */
 int eod_wgrad_up4_map(const float* t16, int Cout, int Cin, float* dw_oihw, void* stream);
+/* ups = 3: the same kernel for a STRIDE-2 3x3 conv (Downsample.op, unet_openai.py:262) of an even map: X is [N][H = 2 Ho][W = 2 Wo][Cx],
+ * gathered at pixel stride 2 (two column phases per row tap); ordinary 9-plane partial tiles -> eod_wgrad_reduce(ksize 3) */
 /* the same for a 1x1 / stride-1 conv (skip connections, attention projections; F.conv2d / conv1d backward-weights behind
  * unet_openai.py:345,409,413): dW[co][ci] = sum_pix dY[pix][co] X[pix][ci] over npix = N*H*W pixel-major rows, split over S
  * pixel ranges into partial[S][1][Cout][ldp] (fp16, channels % 8 == 0; csrc/train.hip: gemm_tn_kernel) */

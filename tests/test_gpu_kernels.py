@@ -630,3 +630,27 @@ def test_conv3x3_backward_weights_parity_class_form(N, H, W, Cx, Cout):
         _lib.check(L.eod_wgrad_up4_map(t16.data_ptr(), Cout, Cx, dw.data_ptr(), st), "wgrad_up4_map")
         torch.cuda.synchronize()
         assert rel_l2(dw.cpu(), ref) < 2e-3, (S, rel_l2(dw.cpu(), ref))
+
+
+@pytest.mark.parametrize("N,Ho,Wo,Cx,Cout", [(2, 8, 64, 40, 24), (1, 16, 32, 136, 128), (3, 8, 16, 8, 200), (1, 4, 128, 64, 64)])
+def test_conv3x3_backward_weights_stride2(N, Ho, Wo, Cx, Cout):
+    """eod_conv3x3_wgrad(ups = 3): weight gradient of a stride-2 / pad-1 3x3 conv (Downsample.op) straight from the NHWC tensors -- X
+    gathered at pixel stride 2 in two column phases -- vs torch's conv2d weight gradient"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    H, W = 2 * Ho, 2 * Wo
+    x = synth_input(f"w2x{N}{H}{W}{Cx}", (N, Cx, H, W), 17).half()
+    dy = synth_input(f"w2y{N}{Ho}{Wo}{Cout}", (N, Cout, Ho, Wo), 18, scale=0.5).half()
+    ref = torch.nn.grad.conv2d_weight(x.float(), (Cout, Cx, 3, 3), dy.float(), stride=2, padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    st = current_stream_ptr(torch.device(DEV))
+    for S in (1, 3):
+        partial = torch.full((S, 9, Cout, Cx), 7.0, dtype=torch.float32, device=DEV)
+        dw = torch.zeros((Cout, Cx, 3, 3), dtype=torch.float32, device=DEV)
+        _lib.check(L.eod_conv3x3_wgrad(dyd.data_ptr(), xd.data_ptr(), _lib.EOD_F16, N, H, W, Cx, Ho, Wo, Cout, Cout, 3, partial.data_ptr(), Cx, S, st),
+                   "conv3x3_wgrad")
+        _lib.check(L.eod_wgrad_reduce(partial.data_ptr(), S, 3, Cout, Cx, Cx, 0, Cx, 1.0, dw.data_ptr(), st), "wgrad_reduce")
+        torch.cuda.synchronize()
+        assert rel_l2(dw.cpu(), ref) < 2e-3, (S, rel_l2(dw.cpu(), ref))
