@@ -113,7 +113,8 @@ template <> struct Mma<float> {
 // sets, pinned order; 246-256 VGPRs): -1..-3 %; rewriting the patch piece before instead of after a step's MFMAs: +-0; an 8-wave
 // 16x16-pixel tile with a 3-stage weight ring (half the weight DMA per MFMA) on 16x16x32: +-1 %; a pixel permutation inside the
 // 16-row MFMA blocks that makes the patch reads bank-conflict free (PMC: SQ_LDS_BANK_CONFLICT 26 % -> 1 % of LDS_IDX_ACTIVE):
-// fp16 +-0 (LDS is not the limiter), fp32x3 -13 % (57-62 spilled VGPRs).  PMC of the split kernel (tools/pmc_stall.txt): waves are
+// fp16 +-0 (LDS is not the limiter), fp32x3 -13 % (57-62 spilled VGPRs); with the registers the column-keyed swizzle freed (213
+// VGPRs), reading the NEXT tap's patch fragments at the end of a tap, across the wait + barrier: +-0.5 %.  PMC of the split kernel (tools/pmc_stall.txt): waves are
 // 32 % issuing, 44 % stalled on issue (the matrix pipe shared by two waves), 24 % parked at s_waitcnt / s_barrier.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define EOD_SPLIT_ASCALE 16.0f
