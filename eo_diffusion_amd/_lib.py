@@ -72,6 +72,7 @@ SYMBOLS = {
     "eod_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
     "eod_pack_conv_weight": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "eod_pack_conv_weight_tapmajor": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "eod_pack_conv_weight_tapmajor_split": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "eod_conv_tapmajor_ldk": (i32, [i32, i32]),
     # training path (csrc/train.hip)
     "eod_pack_conv_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -1789,7 +1789,8 @@ static int conv_bm(const eod_conv_desc* d, bool halo, int force) { return (!halo
 // 1 if this conv can run as the split-fp16 product (fp32 storage, weights packed by eod_pack_conv_weight_split): whole chunk
 // pairs (8 channels) per source; every kernel variant has it except the thin-input (tap-major) first conv
 static bool conv_split_ok(const eod_conv_desc* d, int Ho, int Wo, int force) {
-    return d->dtype == EOD_F32 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && !d->w_tapmajor && d->upsample != 2 && force != 7;
+    // (thin-input first conv: the K axis is [tap][C0] flattened and padded to whole K-steps, so its 8-k pairs always exist)
+    return d->dtype == EOD_F32 && (d->w_tapmajor || (d->C0 % 8 == 0 && d->C1 % 8 == 0)) && d->upsample != 2 && force != 7;
 }
 // zero-insertion upsampling through the four parity-class launches (see eod_conv2d_igemm); EOD_CONV_PARITY=0 keeps the single
 // full-grid launch that multiplies the inserted zeros (tuning / A-B only)

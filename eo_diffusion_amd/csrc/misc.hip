@@ -148,6 +148,27 @@ __global__ void pack_conv_w_tapmajor_kernel(const float* __restrict__ w, T* __re
     }
 }
 
+// the same in the split-fp16 format of the fp32x3 product (every 8 consecutive k = [8 x fp16 hi | 8 x fp16 lo] of s*w, per-tensor s)
+__global__ void pack_conv_w_tapmajor_split_kernel(const float* __restrict__ w, half_t* __restrict__ dst, const float* __restrict__ scale,
+                                                  int Cout, int Cin, int cin_pad, int ldk) {
+    const float s = scale[0];
+    const long long groups = (long long)Cout * (ldk / 8);
+    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
+        const int kg = (int)(gi % (ldk / 8)), co = (int)(gi / (ldk / 8));
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kg * 8 + j, tap = k / cin_pad, ci = k - tap * cin_pad;
+            const float v = (tap < 9 && ci < Cin) ? w[((long long)co * Cin + ci) * 9 + tap] * s : 0.0f;
+            hi[j] = (half_t)v;
+            lo[j] = (half_t)(v - (float)hi[j]);
+        }
+        half8* o = reinterpret_cast<half8*>(dst + gi * 16);
+        o[0] = hi;
+        o[1] = lo;
+    }
+}
+
 extern "C" int eod_conv_tapmajor_ldk(int C0, int dtype);
 extern "C" int eod_pack_conv_weight_tapmajor(const float* w, void* dst, int dtype, int Cout, int Cin, int cin_pad, void* stream) {
     EOD_REQUIRE(w && dst && Cout > 0 && Cin > 0 && cin_pad >= Cin, "pack_conv_weight_tapmajor: bad args");
@@ -160,6 +181,17 @@ extern "C" int eod_pack_conv_weight_tapmajor(const float* w, void* dst, int dtyp
     else
         hipLaunchKernelGGL(pack_conv_w_tapmajor_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)dst, Cout, Cin, cin_pad, ldk);
     EOD_CHECK_LAUNCH("pack_conv_weight_tapmajor");
+    return EOD_OK;
+}
+
+extern "C" int eod_pack_conv_weight_tapmajor_split(const float* w, void* dst, float* scale, int Cout, int Cin, int cin_pad, void* stream) {
+    EOD_REQUIRE(w && dst && scale && Cout > 0 && Cin > 0 && cin_pad >= Cin && eod_aligned16(dst), "pack_conv_weight_tapmajor_split: bad args");
+    const int ldk = eod_conv_tapmajor_ldk(cin_pad, EOD_F32);
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cout * Cin * 9, scale);
+    const long long groups = (long long)Cout * (ldk / 8);
+    const unsigned blocks = (unsigned)((groups + 255) / 256 > 4096 ? 4096 : (groups + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_w_tapmajor_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, scale, Cout, Cin, cin_pad, ldk);
+    EOD_CHECK_LAUNCH("pack_conv_weight_tapmajor_split");
     return EOD_OK;
 }
 

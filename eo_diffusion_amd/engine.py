@@ -152,6 +152,11 @@ class Program:
         cout, cin = w.shape[0], w.shape[1]
         assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3
         ldk = self.L.eod_conv_tapmajor_ldk(cin_pad, self.dt)
+        if self.split and os.environ.get("EOD_FIRST_X3", "1") != "0":  # fp32x3 program: split-fp16 pairs + device scale (conv() sets w_split)
+            dst, scale = self.empty((cout, ldk), torch.float32), self.empty((2,), torch.float32)
+            check(self.L.eod_pack_conv_weight_tapmajor_split(ptr(w), ptr(dst), ptr(scale), cout, cin, cin_pad,
+                                                             current_stream_ptr(self.device)), "pack_conv_weight_tapmajor_split")
+            return ("split", dst, scale)
         dst = self.empty((cout, ldk))
         check(self.L.eod_pack_conv_weight_tapmajor(ptr(w), ptr(dst), self.dt, cout, cin, cin_pad,
                                                    current_stream_ptr(self.device)), "pack_conv_weight_tapmajor")
@@ -233,7 +238,9 @@ class Program:
         d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
         d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
         d.w_tapmajor = int(w_tapmajor)
-        if isinstance(w_packed, _LazyConvW):  # fp32x3: split-fp16 product where the library has it for this geometry
+        if isinstance(w_packed, tuple) and w_packed[0] == "split":  # pre-split weights (thin-input first conv of an fp32x3 program)
+            d.w, d.w_split, d.w_scale = ptr(w_packed[1]), 1, ptr(w_packed[2])
+        elif isinstance(w_packed, _LazyConvW):  # fp32x3: split-fp16 product where the library has it for this geometry
             if self.L.eod_conv_split_ok(C.byref(d)):
                 wt, wscale = w_packed.split()
                 d.w, d.w_split, d.w_scale = ptr(wt), 1, ptr(wscale)

@@ -85,7 +85,8 @@ typedef struct {
                             K-steps instead of 9 mostly-zero ones.  Needs C1 == 0, no upsample, C0 in {1,2,4} 16-byte chunks */
     int32_t w_split;     /* 1: "fp32x3" product -- fp32 storage, every product as three fp16 MFMAs on split operands (hi + lo):
                             w is the output of eod_pack_conv_weight_split, w_scale its scale pair.  Only where
-                            eod_conv_split_ok(d) == 1 (fp32, C0 and C1 multiples of 8, not w_tapmajor); rel. error ~2^-22 per product */
+                            eod_conv_split_ok(d) == 1 (fp32, C0 and C1 multiples of 8 -- or w_tapmajor with eod_pack_conv_weight_tapmajor_split);
+                            rel. error ~2^-22 per product */
     const float* w_scale; /* device pointer to {s, 1/(16 s)} written by eod_pack_conv_weight_split (w_split only) */
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
@@ -145,6 +146,8 @@ int eod_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int Cout, in
 int eod_pack_conv_weight_split(const float* w_oihw, void* dst, float* scale, int Cout, int Cin, int ksize, int cin_pad, void* stream);
 /* thin-input variant: OIHW fp32 -> [Cout][ldk], k = tap*cin_pad + c, zero padded (see eod_conv_desc.w_tapmajor) */
 int eod_pack_conv_weight_tapmajor(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int cin_pad, void* stream);
+/* the same in the split-fp16 pair format (fp32 storage, eod_conv_desc.w_tapmajor together with w_split); scale as above */
+int eod_pack_conv_weight_tapmajor_split(const float* w_oihw, void* dst, float* scale, int Cout, int Cin, int cin_pad, void* stream);
 int eod_conv_tapmajor_ldk(int C0, int dtype);
 /* generic strided 2-D cast-copy: dst[r][c] = (dtype) src[row_map[r]*ld_src + c]; row_map may be NULL
  * (identity); a negative row_map entry yields a zero row (K padding of attention heads) */
