@@ -1844,17 +1844,21 @@ extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
 }
 
 // 1 if eod_conv2d_igemm can apply GroupNorm(+SiLU) to the conv INPUT on the fly (gn_scale_shift) for this geometry.
-// The fused form re-normalises the halo patch once per N-tile (Cout / 128 times), so it only pays while the conv has
-// few N-tiles; measured on MI355X: worth it for Cout <= 256, the separate apply pass wins beyond.
+// The fused form re-normalises the halo patch once per N-tile (Cout / 128 times), so in fp16 storage it only pays while the conv has
+// few N-tiles (measured on MI355X: Cout <= 256, the separate apply pass wins beyond); in fp32 storage (split product) it pays at
+// every width the UNet has.
 extern "C" int eod_conv_gn_fusable(const eod_conv_desc* d) {
     if (!d || d->upsample) return 0;
     const int Ho = (d->H + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (d->W + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
-    static int max_cout = -1;
-    if (max_cout < 0) {
+    static int env_cout = -2;
+    if (env_cout == -2) {
         const char* e = getenv("EOD_GN_FUSE_MAX_COUT");
-        max_cout = e ? atoi(e) : 256;
+        env_cout = e ? atoi(e) : -1;
     }
+    // measured (same-box A/B of bench.py): fp32 storage with the split product pays for the fusion at every width (a separate pass
+    // moves 8 bytes per element; 384 / 512-wide layers: step -0.2 ms), fp16 storage up to 256 output channels
+    const int max_cout = env_cout >= 0 ? env_cout : (d->w_split ? 512 : 256);
     if (d->Cout > max_cout) return 0;
     return conv_uses_halo(d, Ho, Wo, igemm_forced_cfg()) ? 1 : 0;
 }

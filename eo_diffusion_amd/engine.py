@@ -215,6 +215,7 @@ class Program:
             probe.C0, probe.C1, probe.Cout = x.C, (x2.C if x2 is not None else 0), cout
             probe.ksize, probe.stride, probe.pad, probe.upsample, probe.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
             probe.out_nchw_f32 = int(out_nchw_f32)
+            probe.w_split = int(self.split and isinstance(w_packed, _LazyConvW))  # (the fusion threshold depends on the product form)
             if not self.L.eod_conv_gn_fusable(C.byref(probe)):
                 x = self.gn_apply([x] + ([x2] if x2 is not None else []), gn[0], silu=gn[1])
                 x2, gn = None, None
