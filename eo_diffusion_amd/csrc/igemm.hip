@@ -1608,6 +1608,235 @@ template <typename T, bool SPLIT, bool BWD = false> static int launch_up4(IgemmP
     return EOD_OK;
 }
 
+// =============================================================================================
+// conv_head_kernel: the UNet's output head, GroupNorm -> SiLU -> 3x3 conv to <= 16 channels, NCHW fp32 output (unet_openai.py:738-743).
+// 2 x 128 x 9 x Cout MACs per pixel against 512 bytes of input: HBM-bound, and in the halo kernel's frame (one barrier per tap for a
+// 12-MFMA step) bound by synchronisation instead (0.41 ms for 537 MB of input).  Here a tile's tap loop has NO barrier: the weights
+// of a whole chunk (9 taps x 16 output rows) live in REGISTERS, loaded from L2 one chunk ahead; the patch ring is three deep (chunk cc
+// is read, cc+1 is normalised / split by the waves that fetched it, cc+2 is in flight), so there is ONE barrier per chunk.
+// Workgroup = 8 x 16 pixel tile, 4 waves x 32 pixels; MFMA 16x16x32 with the WEIGHTS as the A operand: D[row = channel][col = pixel],
+// so a lane of the first quarter holds the <= 4 output channels of one pixel and a plane row of 16 pixels is one 64-byte store.
+// =============================================================================================
+#define HEAD_MAX_C 384  // input channels of the head (the whole scale / shift table sits in LDS)
+template <typename T, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
+    static_assert(SPLIT ? sizeof(T) == 4 : sizeof(T) == 2, "fp16 storage or split fp32");
+    constexpr int NW = 4, BM = 128, MS = 16;
+    constexpr int PH = 10, PW = 18, PR = PH * PW, LAH = ((PR + 7) / 8 + NW - 1) / NW, PG = LAH * NW;  // 180 rows in 24 groups of 8 (the last one
+    // is padding: every wave issues exactly LAH = 6 pieces per chunk, which keeps the counted vmcnt waits exact for the compiler too)
+    constexpr int ES = sizeof(T), EPC = 16 / ES, BKB = 128, BK = BKB / ES;
+    constexpr int ABUF = PG * 1024;
+    constexpr int NSUB = SPLIT ? 1 : 2;  // 32-k MFMA sub-steps per chunk row (fp16: 64 channels)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sA = smem;              // [3][ABUF]
+    char* const sS = smem + 3 * ABUF;   // [HEAD_MAX_C][2] scale / shift of every input channel of this image
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n;
+    map_tile(p, tile_m, tile_n);
+    const TileGeom g = make_geom<true, BM>(p, tile_m);
+
+    const int srow = lane >> 3, sslot = lane & 7;
+    unsigned ppix[LAH];
+    unsigned pck = 0, pvalid = 0;
+#pragma unroll
+    for (int i = 0; i < LAH; ++i) {
+        const int prow = (wave + NW * i) * 8 + srow;
+        const int py = prow / PW, px = prow - py * PW;
+        const int hi = g.ty0 - 1 + py, wi = g.tx0 - 1 + px;
+        const bool ok = prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        if (ok) pvalid |= 1u << i;
+        ppix[i] = (unsigned)(hi * p.W + wi);
+        pck |= (unsigned)(sslot ^ ((px >> 1) & 7)) << (3 * i);
+    }
+    auto pchunk_of = [&](int i) { return (int)((pck >> (3 * i)) & 7u); };
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gn_ss) + (long long)g.n_first * p.C0 * 2, 0, p.C0 * 8, 0x00020000);
+    const int KC = p.kc0;
+
+    auto issue_chunk = [&](int cc) {  // this wave's patch pieces of chunk cc into ring slot cc % 3
+        char* abuf = sA + (cc % 3) * ABUF;
+        const int kin = cc * BK;
+        const bool ktail = kin + BK > p.C0;
+#pragma unroll
+        for (int i = 0; i < LAH; ++i) {
+            const int pc = pchunk_of(i);
+            unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(p.C0 * ES) + pc * 16 : EOD_OOB;
+            if (ktail) v = (kin + pc * EPC < p.C0) ? v : EOD_OOB;  // (also every piece of a chunk past the last one)
+            blds16(rsA, v, (unsigned)(kin * ES), abuf + (wave + NW * i) * 1024);
+        }
+    };
+    auto transform_chunk = [&](int cc) {  // x -> silu(x * scale + shift) [-> fp16 pair image], this wave's pieces, in place
+        char* abuf = sA + (cc % 3) * ABUF;
+        const int kin = cc * BK;
+        const char* ssbuf = sS + kin * 8;
+        const bool ktail = kin + BK > p.C0;
+#pragma unroll
+        for (int i = 0; i < LAH; ++i) {
+            if ((wave + NW * i) * 8 >= PR) continue;  // the padding group
+            const int pc = pchunk_of(i);
+            const bool ok = ((pvalid >> i) & 1u) && (!ktail || (kin + pc * EPC < p.C0));
+            char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
+            const i32x4 raw = *reinterpret_cast<const i32x4*>(ptr);
+            const float* sp = reinterpret_cast<const float*>(ssbuf) + pc * EPC * 2;
+            if constexpr (SPLIT) {
+                const f32x4 f = __builtin_bit_cast(f32x4, raw);
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const float sc[4] = {q0[0], q0[2], q1[0], q1[2]}, sh[4] = {q0[1], q0[3], q1[1], q1[3]};
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = f[e] * sc[e] + sh[e];
+                    if (p.gn_silu) v = silu_f<true>(v);
+                    o[e] = ok ? v * EOD_SPLIT_ASCALE : 0.0f;  // conv zero padding / masked channel tail stay zero
+                }
+                *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(o, (pc & 1) != 0);
+            } else {
+                const half8 h = __builtin_bit_cast(half8, raw);
+                half8 o;
+                f32x4 q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = (float)h[e] * q[e >> 1][(e & 1) * 2] + q[e >> 1][(e & 1) * 2 + 1];
+                    if (p.gn_silu) v = silu_f<true>(v);
+                    o[e] = (half_t)v;
+                }
+                if (ok) *reinterpret_cast<i32x4*>(ptr) = __builtin_bit_cast(i32x4, o);
+            }
+        }
+    };
+    // weights of one chunk in registers: [tap][sub-step / (hi, lo)]; lane = (output row lr, k-quarter lh).  Packed [tap][Cout][Cin]
+    // rows; split storage: 32-byte [8 x hi | 8 x lo] pairs, quarter lh takes pair {0, 3, 1, 2}[lh] like the patch reads.
+    const int lr = lane & 15, lh = lane >> 4;
+    const int c0 = SPLIT ? 2 * ((0x2130 >> (4 * lh)) & 3) : lh, c1 = SPLIT ? c0 + 1 : 4 + lh;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.b), 0, 9 * p.Cout * p.Cin * ES, 0x00020000);
+    const unsigned wrow = lr < p.Cout ? (unsigned)(lr * p.Cin * ES) : EOD_OOB;  // rows past Cout: zeros
+    const int tapbytes = p.Cout * p.Cin * ES;
+    auto load_weights = [&](int cc, i32x4 (&w)[9][2]) {
+        const int kin = cc * BK;
+        const unsigned v0 = (kin + c0 * EPC < p.C0) ? wrow + c0 * 16 : EOD_OOB;  // (a split pair lies wholly inside or outside: C0 % 8 == 0)
+        const unsigned v1 = (kin + c1 * EPC < p.C0) ? wrow + c1 * 16 : EOD_OOB;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            w[t][0] = __builtin_amdgcn_raw_buffer_load_b128(rsW, v0, (unsigned)(t * tapbytes + kin * ES), 0);
+            w[t][1] = __builtin_amdgcn_raw_buffer_load_b128(rsW, v1, (unsigned)(t * tapbytes + kin * ES), 0);
+        }
+    };
+
+    // fragment addresses of the patch (see conv3x3_halo_kernel): this wave's tile rows 2*wave + i, column lr + dx
+    int abase[2][3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int pxc = lr + dx;
+        const int key = (pxc >> 1) & 7;
+        const int rowb = ((wave * 2) * PW + pxc) * BKB;
+        abase[0][dx] = rowb + ((c0 ^ key) << 4);
+        abase[1][dx] = rowb + ((c1 ^ key) << 4);
+    }
+    f32x4 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.0f;
+
+    // VMEM per iteration: the LAH pieces of chunk cc + 2 and the 18 weight loads of chunk cc + 1 -- exactly that in every iteration
+    // (past the last chunk all of it out of range: zeros into a ring slot nobody reads), in whichever order the scheduler puts them
+    // (it sinks the weight loads below the tap loop and reloads each register after its last use: no second register set).  The
+    // rewrite of chunk cc + 1 needs ITS pieces, issued one iteration earlier: vmcnt(LAH + 18) keeps this iteration's issues in flight.
+    // Issues and waits are unconditional and the wait is the builtin: the compiler's own wait insertion is path-insensitive, and a
+    // conditional issue or an inline-asm wait makes it guard every MFMA of the tap loop with a vmcnt of its own (seen in the ISA).
+    constexpr int KEEP = LAH + 18;
+    static_assert(KEEP < 64, "vmcnt is 6 bits");
+    auto wait_keep_pieces = [&]() { __builtin_amdgcn_s_waitcnt(0x0f70 | (KEEP & 15) | ((KEEP >> 4) << 14)); };
+    i32x4 wcur[9][2], wnxt[9][2];
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < HEAD_MAX_C / 128; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void*)(sS + j * 1024), 16, (unsigned)(lane * 16 + j * 1024), 0, 0, 0);
+    }
+    issue_chunk(0);
+    load_weights(0, wcur);
+    issue_chunk(1);
+    wait_keep_pieces();
+    __builtin_amdgcn_s_barrier();  // wave 0's table is visible
+    transform_chunk(0);
+    for (int cc = 0; cc < KC; ++cc) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my in-place rewrites of chunk cc are in LDS
+        __builtin_amdgcn_s_barrier();        // chunk cc is complete for every wave, and ring slot (cc + 2) % 3 is no longer read
+        load_weights(cc + 1, wnxt);
+        issue_chunk(cc + 2);
+        const char* abuf = sA + (cc % 3) * ABUF;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const i32x4 a0 = *reinterpret_cast<const i32x4*>(abuf + abase[0][dx] + (i + dy) * PW * BKB);
+                const i32x4 a1 = *reinterpret_cast<const i32x4*>(abuf + abase[1][dx] + (i + dy) * PW * BKB);
+                if constexpr (SPLIT) {  // a0 = hi, a1 = lo of the pixels; wcur[t][0] = hi, [1] = lo of the weights; smallest terms first
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][0]), __builtin_bit_cast(half8, a1), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][1]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][0]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
+                } else {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][0]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][1]), __builtin_bit_cast(half8, a1), acc[i], 0, 0, 0);
+                }
+            }
+        }
+        wait_keep_pieces();
+        if (cc + 1 < KC) transform_chunk(cc + 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            wcur[t][0] = wnxt[t][0];
+            wcur[t][1] = wnxt[t][1];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // the out-of-range pieces of the last two iterations: nothing in flight at exit
+    // ---- store: rows of D = output channels 4 lh + r, column = pixel lr of tile row 2 wave + i: 64-byte runs per plane row ----
+    {
+        const float alpha = SPLIT ? p.alpha * p.w_scale[1] : p.alpha;
+        float* yb = reinterpret_cast<float*>(p.y) + (long long)g.n_first * p.Cout * p.HoWo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 4 * lh + r;
+            if (co >= p.Cout) continue;
+            const float bv = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                yb[(long long)co * p.HoWo + (long long)(g.ty0 + wave * 2 + i) * p.Wo + g.tx0 + lr] = acc[i][r] * alpha + bv;
+        }
+    }
+}
+
+template <typename T, bool SPLIT> static int launch_head(IgemmP& p, hipStream_t st) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    const size_t lds = 3 * (size_t)(24 * 1024) + HEAD_MAX_C * 8;
+    auto kern = conv_head_kernel<T, SPLIT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    p.kc0 = (p.C0 + BK - 1) / BK;
+    p.kc1 = 0;
+    p.tiles_n = 1;
+    p.tw_log2 = 4;
+    p.th = 8;
+    p.tiles_pw = p.Wo / 16;
+    p.tiles_pi = p.tiles_pw * (p.Ho / 8);
+    p.tiles_m = p.tiles_pi * p.N;
+    if (p.tiles_m <= 0) {
+        eod_set_error("conv_head: bad grid");
+        return EOD_EINVAL;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.tiles_m), dim3(256), lds, st, p);
+    EOD_CHECK_LAUNCH("conv_head");
+    return EOD_OK;
+}
+
 // split-K second pass: y[m][c] = alpha * sum_z ws[z][m][c] + bias[c] + cbias[n(m)][c] + res[m][c]   (fixed z order)
 template <typename T>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long M, int Cout, int HoWo, float alpha,
@@ -1835,6 +2064,17 @@ static int conv_up4_bwd(const eod_conv_desc* d, void* stream) {
     p.M = (long long)d->N * d->Ho * d->Wo; p.Ncols = d->Cout; p.taps = 9; p.alpha = d->alpha; p.nb1 = 1; p.tapmajor_log2 = -1;
     return launch_up4<half_t, false, true>(p, (hipStream_t)stream);
 }
+// the UNet's output head on conv_head_kernel (EOD_HEAD=0: the 32-column halo instance, A/B)
+static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EOD_HEAD");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    const bool store_ok = d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
+    return on && halo_ok && d->out_nchw_f32 && d->Cout <= 16 && d->gn_scale_shift && d->C1 == 0 && !d->x2 && !d->upsample && !d->res && !d->cbias &&
+           !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C && halo_mfma_shape() == 16;
+}
 extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
     if (!d) return 0;
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
@@ -1983,6 +2223,11 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         return d->dtype == EOD_F16 ? launch_up4<half_t, false>(p, st) : launch_up4<float, true>(p, st);
     }
     const bool m16 = halo_mfma_shape() == 16;
+    if (conv_head_ok(d, halo_ok)) {  // output head: GroupNorm + SiLU fused, <= 16 channels, NCHW fp32 (conv_head_kernel)
+        p.gn_ss = d->gn_scale_shift;
+        p.gn_silu = d->gn_silu;
+        return d->dtype == EOD_F16 ? launch_head<half_t, false>(p, st) : launch_head<float, true>(p, st);
+    }
     if (halo_ok && d->w_split) {
         // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)
         if (d->gn_scale_shift) {

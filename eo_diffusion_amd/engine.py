@@ -477,10 +477,12 @@ class Program:
                 geo = d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and d.Wo % 16 == 0 and d.Ho % 8 == 0
                 halo = geo and d.Cout > 64 and not d.out_nchw_f32 and not d.w_tapmajor  # mirrors conv_uses_halo() in csrc/igemm.hip
                 head = geo and d.Cout <= 32 and d.out_nchw_f32 and not d.upsample  # 32-column instance (HBM-bound head conv)
+                headk = head and bool(d.gn_scale_shift) and d.Cout <= 16 and d.C1 == 0 and cin <= 384 and self.precision != "fp32" \
+                    and os.environ.get("EOD_HEAD", "1") != "0"  # mirrors conv_head_ok()
                 up4 = d.upsample == 3  # parity-class form of the nearest-2x conv: the algorithm's 9 taps are executed as 4 (pre-summed)
                 out.append(dict(kind="conv", flops=fl, bytes=by, exec_flops=fl * (4.0 / 9.0 if up4 else 1.0),
                                 kernel="conv_up4_halo_kernel" if up4 else "conv3x3_halo_kernel" if halo else
-                                       "conv3x3_halo_kernel<BN=32>" if head else "igemm_kernel",
+                                       "conv_head_kernel" if headk else "conv3x3_halo_kernel<BN=32>" if head else "igemm_kernel",
                                 label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u4' if up4 else 'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"))
             elif k == OP_GEMM:
                 d = op.u.gemm

@@ -315,11 +315,13 @@ def test_first_conv_tapmajor(prec, dims):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
-@pytest.mark.parametrize("dims", [(2, 128, 16, 16, 3), (1, 64, 8, 32, 13), (2, 96, 16, 16, 3)])
+@pytest.mark.parametrize("dims", [(2, 128, 16, 16, 3), (1, 64, 8, 32, 13), (2, 96, 16, 16, 3), (3, 128, 40, 48, 3), (1, 160, 24, 32, 16),
+                                  (1, 32, 8, 16, 1), (1, 416, 8, 16, 3)])
 @pytest.mark.parametrize("fused_gn", [True, False])
 def test_head_conv_nchw_f32(prec, dims, fused_gn):
-    """output head (unet_openai.py:739-742): [GroupNorm + SiLU ->] 3x3 conv to a few channels written as NCHW fp32
-    (32-column instance of the halo-patch kernel, GroupNorm fused into the patch staging)"""
+    """output head (unet_openai.py:739-742): [GroupNorm + SiLU ->] 3x3 conv to a few channels written as NCHW fp32: conv_head_kernel
+    for the fused form (weights in registers, three-deep patch ring; single and many chunks, channel tails, multi-image, up to 16
+    output channels), the 32-column instance of the halo-patch kernel otherwise (no GroupNorm, > 384 input channels, exact fp32)"""
     from eo_diffusion_amd.engine import Act
     N, C, H, W, Cout = dims
     x = synth_input(f"hx{dims}", (N, C, H, W), 43, scale=1.5) + 0.2

@@ -25,6 +25,8 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, upsample)
     "sk_768": (16, 64, 64, 768, 384, 1, 1, False),
     "dn_128": (16, 256, 256, 128, 128, 3, 2, False),
     "dn_256": (16, 128, 128, 256, 256, 3, 2, False),
+    "head_128": (16, 256, 256, 128, 3, 3, 1, False),   # output head: NCHW fp32 output (use with --gn: conv_head_kernel)
+    "head_192": (16, 128, 128, 192, 3, 3, 1, False),
 }
 
 def main():
@@ -49,7 +51,10 @@ def main():
         if ups and a.up4 and prog.conv_up4_ok(x, Cout):  # the parity-class form of the nearest-2x conv (4/9 of the MACs; flops below = algorithmic)
             w = prog.pack_conv_up4(torch.randn((Cout, Cin, k, k), device=dev) * 0.02)
             ups = "up4"
-        y, _ = prog.conv(x, w, b, Cout, ksize=k, stride=stride, pad=k // 2, upsample=ups, gn=gn)
+        y, _i = prog.conv(x, w, b, Cout, ksize=k, stride=stride, pad=k // 2, upsample=ups, gn=gn, out_nchw_f32=name.startswith("head"))
+        if y is None:  # head: the caller binds the NCHW fp32 output
+            out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=dev)
+            prog.ops[_i].u.conv.y = out.data_ptr()
         prog.finalize()
         for _ in range(3): prog.run()
         torch.cuda.synchronize()
@@ -57,7 +62,7 @@ def main():
         for _ in range(a.iters): prog.run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.iters
-        fl = 2.0 * N * y.H * y.W * Cout * Cin * k * k
+        fl = 2.0 * N * (y.H * y.W if y is not None else H * W) * Cout * Cin * k * k
         print(f"{name:8s} {a.prec}{' gn' if gn else ''} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
 
 if __name__ == "__main__":
