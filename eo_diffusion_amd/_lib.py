@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                 ("Cout", i32), ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32), ("pad_tl", i32),
                 ("Ho", i32), ("Wo", i32), ("out_nchw_f32", i32), ("alpha", f32), ("stats", vp), ("stats_slots", i32),
                 ("gn_silu", i32), ("gn_scale_shift", vp), ("workspace", vp), ("workspace_bytes", i64),
-                ("w_tapmajor", i32), ("w_split", i32), ("w_scale", vp)]
+                ("w_tapmajor", i32), ("w_split", i32), ("w_scale", vp),
+                ("skip_x", vp), ("skip_x2", vp), ("skip_w", vp), ("skip_C0", i32), ("skip_C1", i32)]
 
 
 class GemmDesc(C.Structure):
@@ -113,10 +114,12 @@ SYMBOLS = {
     "eod_conv_stats_slots": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_gn_fusable": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_split_ok": (i32, [C.POINTER(ConvDesc)]),
+    "eod_conv_skip_ok": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_up4_ok": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_up4_weights": (i32, [vp, vp, i32, i32, vp]),
     "eod_conv_up4_bwd_ok": (i32, [C.POINTER(ConvDesc)]),
     "eod_pack_conv_weight_split": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eod_pack_conv_weight_split_pair": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eod_conv_workspace_size": (i64, [C.POINTER(ConvDesc)]),
     "eod_gn_apply": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
     "eod_attention_fwd": (i32, [C.POINTER(AttnDesc), vp]),

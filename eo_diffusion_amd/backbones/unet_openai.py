@@ -324,16 +324,24 @@ class ResBlock(TimestepBlock):
             ss2 = prog.gn_stats([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), eps=gn2.eps, film=emb_ptr_off, film_stride=ctx.J)
         else:
             ss2 = prog.gn_stats([h1], prog.f32(gn2.weight), prog.f32(gn2.bias), eps=gn2.eps)
+        live_dropout = self.training and self.dropout > 0
         if isinstance(self.skip_connection, nn.Identity):
             if len(srcs) != 1:
                 raise _lib.EodError("identity skip over a virtual concat is not supported")
             skip = srcs[0]
+        elif self.skip_connection.kernel_size[0] == 1 and not live_dropout and prog.conv_skip_ok(h1, cout, srcs):
+            # the 1x1 skip_connection rides in conv2's accumulators (its K loop continues over the block input's channels): the skip
+            # tensor is never written or read back
+            sc = self.skip_connection
+            out, _ = prog.conv(h1, prog.pack_conv(conv2.weight), prog.f32(conv2.bias), cout, stats=True, gn=(ss2, True),
+                               skip=(srcs, sc.weight, sc.bias))
+            return out
         else:
             sc = self.skip_connection
             k = sc.kernel_size[0]
             skip, _ = prog.conv(srcs[0], prog.pack_conv(sc.weight), prog.f32(sc.bias), cout,
                                 x2=srcs[1] if len(srcs) > 1 else None, ksize=k, stride=1, pad=k // 2)
-        if self.training and self.dropout > 0:
+        if live_dropout:
             # train-mode forward without autograd (the reference samples previews from modules left in train mode): nn.Dropout of
             # out_layers[2] (unet_openai.py:339) is live.  GroupNorm+SiLU is materialised, then y = x * keep / (1 - p) with the
             # Philox mask of eod_dropout keyed by (seed, layer, forward counter) -- a fresh mask every forward

@@ -76,6 +76,12 @@ struct IgemmP {
     // walks only the taps that meet stored (even) input positions for that class: taplist holds them, 4 bits each, `taps` of them.
     int Hd, Wd, HWd, par, par_y, par_x;
     unsigned taplist;
+    // fused 1x1 skip connection of a ResBlock (halo kernel, SKIP instances): after the 3x3 K loop the same accumulators take
+    // sum_c sx[pixel][c] * b2[co][c] over the block input (one or two sources = the virtual concat), see eod_conv_desc.skip_x
+    const char* sx0;
+    const char* sx1;
+    const char* b2;  // packed [Cout][SC0 + SC1] (the 1x1 weight; split mode: same scale as `b`)
+    int SC0, SC1, skc0, skc1;
 };
 
 template <typename T> struct Mma;
@@ -885,8 +891,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // MS = MFMA shape of the fp16 products: 32 = v_mfma_f32_32x32x16_f16 (2x2 tiles per wave), 16 = v_mfma_f32_16x16x32_f16 (4x4 tiles).
 // Same flops, same LDS bytes and reads per K-step; under the chip's power limit the 16x16x32 form sustains ~1.14x the issued
 // FLOP/s (tools/probe/mfma_shape.hip: 1.76 vs 1.54 PFLOP/s for this wave tile with every operand re-read from LDS).
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32>
+// SKIP = true (16x16x32 instances): the ResBlock's 1x1 skip_connection conv (unet_openai.py:352, 385: `skip_connection(x) + h`) rides in
+// the same accumulators.  After the last 3x3 tap the operand ring is reused as a plain two-stage GEMM ring (128 pixel rows x 128 B of the
+// block input | 128 x 128 B of the 1x1 weight per K-step) and the K loop continues over the input's channels: the skip tensor is never
+// written to or read back from HBM (2 x M x Cout elements per block), and its MFMA work runs at this kernel's rate instead of in an
+// HBM-bound launch of its own.
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel(const IgemmP p) {
+    static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M * WAVES_N == 4), "fused skip conv: 16x16x32 instances of the 8x16 tile");
     static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 product is a mode of fp32 storage");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only");
     constexpr bool XF = GN || SPLIT;  // the staged patch pieces are rewritten in place by the wave that DMA'd them
@@ -1295,6 +1307,111 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
             for (int dx = 0; dx < 3; ++dx) {
                 acur[0][dx] += flip;
                 acur[1][dx] += flip;
+            }
+        }
+    }
+    if constexpr (SKIP) {
+        // ---- 1x1 skip conv over the block input: GEMM-layout ring in the same LDS, K-step = 32 / 64 channels of one source ----
+        constexpr int LA = BM / 8 / NW;                    // 8-row pieces of the pixel tile per wave (4)
+        constexpr int STG_A = BM * BKB, STG = STG_A + BSTAGE;
+        static_assert(2 * STG <= 2 * ABUF + BSTAGES * BSTAGE && LA == LB, "the skip phase reuses the operand ring");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();  // every wave is done with the 3x3 loop's buffers
+        const int SC = p.SC0 + p.SC1;
+        const __amdgpu_buffer_rsrc_t rsX0 = make_rsrc(p.sx0 + (long long)g.n_first * p.H * p.W * p.SC0 * ES);
+        const __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(p.sx1 ? p.sx1 + (long long)g.n_first * p.H * p.W * p.SC1 * ES : p.sx0);
+        const __amdgpu_buffer_rsrc_t rsW2 = make_rsrc(p.b2 + (long long)n0 * SC * ES);
+        // row r of the tile = pixel (ty0 + r / 16, tx0 + r % 16) -- always inside the image; rows use the (row >> 1) & 7 swizzle, which
+        // for this lane's pieces is bchunk0 (the weight rows' value)
+        unsigned xpix[LA], wv[LA];
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int row = (wave + NW * i) * 8 + srow;
+            xpix[i] = (unsigned)((g.ty0 + (row >> 4)) * p.W + g.tx0 + (row & 15));
+            wv[i] = (n0 + row < p.Ncols) ? (unsigned)(row * SC * ES) + bchunk0 * 16 : EOD_OOB;
+        }
+        auto issue_skip = [&](int kt, char* stg) {
+            const int src = kt >= p.skc0 ? 1 : 0;
+            const int kin = (src ? kt - p.skc0 : kt) * BK, cw = src ? p.SC1 : p.SC0;
+            const bool ktail = kin + BK > cw;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                unsigned v = xpix[i] * (unsigned)(cw * ES) + bchunk0 * 16;
+                if (ktail) v = (kin + bchunk0 * EPC < cw) ? v : EOD_OOB;
+                if (src)
+                    blds16(rsX1, v, (unsigned)(kin * ES), stg + (wave + NW * i) * 1024);
+                else
+                    blds16(rsX0, v, (unsigned)(kin * ES), stg + (wave + NW * i) * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                unsigned v = wv[i];
+                if (ktail) v = (kin + (SPLIT ? (bchunk0 >> 1) * 8 : bchunk0 * EPC) < cw) ? v : EOD_OOB;
+                blds16(rsW2, v, (unsigned)(((src ? p.SC0 : 0) + kin) * ES), stg + STG_A + (wave + NW * i) * 1024);
+            }
+        };
+        const int KS = p.skc0 + p.skc1;
+        const int a_rd = (wm * WM + lr) * BKB;
+        const int b_rd2 = STG_A + (wn * WN + lr) * BKB;
+        if (KS > 0) issue_skip(0, smem);
+        for (int kt = 0; kt < KS; ++kt) {
+            char* stg = smem + (kt & 1) * STG;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (SPLIT) {  // this wave's pixel pieces have landed: fp32 chunk pairs -> [8 x hi | 8 x lo] (x 16) in place
+#pragma unroll
+                for (int i = 0; i < LA; ++i) {
+                    char* ptr = stg + (wave + NW * i) * 1024 + lane * 16;
+                    f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+                    *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (bchunk0 & 1) != 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < KS) issue_skip(kt + 1, smem + ((kt + 1) & 1) * STG);
+            if constexpr (SPLIT) {
+                const int ch = 2 * ((0x2130 >> (4 * lh)) & 3);
+                const int ohi = (ch ^ bsw) * 16, olo = ((ch + 1) ^ bsw) * 16;
+                i32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) al[i] = *reinterpret_cast<const i32x4*>(stg + a_rd + i * MS * BKB + olo);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bh[j] = *reinterpret_cast<const i32x4*>(stg + b_rd2 + j * MS * BKB + ohi);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const i32x4*>(stg + a_rd + i * MS * BKB + ohi);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(stg + b_rd2 + j * MS * BKB + olo);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int o = ((4 * s2 + lh) ^ bsw) * 16;
+                    i32x4 fa16[TM], fb16[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa16[i] = *reinterpret_cast<const i32x4*>(stg + a_rd + i * MS * BKB + o);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb16[j] = *reinterpret_cast<const i32x4*>(stg + b_rd2 + j * MS * BKB + o);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa16[i]), __builtin_bit_cast(half8, fb16[j]), acc[i][j], 0, 0, 0);
+                }
             }
         }
     }
@@ -1932,7 +2049,7 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int NW = WAVES_M * WAVES_N, BM = 32 * NW, TH = BM / 16;
@@ -1941,7 +2058,11 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128 + (GN ? 2048 : 0);
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP>;
+    if constexpr (SKIP) {
+        p.skc0 = (p.SC0 + BK - 1) / BK;
+        p.skc1 = (p.SC1 + BK - 1) / BK;
+    }
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2075,6 +2196,23 @@ static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
     return on && halo_ok && d->out_nchw_f32 && d->Cout <= 16 && d->gn_scale_shift && d->C1 == 0 && !d->x2 && !d->upsample && !d->res && !d->cbias &&
            !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C && halo_mfma_shape() == 16;
 }
+// ResBlock 1x1 skip conv fused behind the 3x3 K loop (conv3x3_halo_kernel<SKIP>; EOD_SKIP_FUSE=0: off, A/B)
+static bool conv_skip_geom_ok(const eod_conv_desc* d) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EOD_SKIP_FUSE");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (!on || !d || d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->upsample || d->pad_tl || d->C1 != 0 || d->x2 || d->res ||
+        d->out_nchw_f32 || d->w_tapmajor || d->Cout <= 64 || d->Cout % 8 || d->C0 % 8 || halo_mfma_shape() != 16)
+        return false;
+    if (d->skip_C0 <= 0 || d->skip_C0 % 8 || d->skip_C1 < 0 || d->skip_C1 % 8) return false;
+    const int Ho = d->H, Wo = d->W;
+    const int force = igemm_forced_cfg();
+    if (!conv_uses_halo(d, Ho, Wo, force) || halo_big(d, Ho, force)) return false;
+    return d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
+}
+extern "C" int eod_conv_skip_ok(const eod_conv_desc* d) { return conv_skip_geom_ok(d) ? 1 : 0; }
 extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
     if (!d) return 0;
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
@@ -2227,6 +2365,28 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.gn_ss = d->gn_scale_shift;
         p.gn_silu = d->gn_silu;
         return d->dtype == EOD_F16 ? launch_head<half_t, false>(p, st) : launch_head<float, true>(p, st);
+    }
+    if (d->skip_x) {  // ResBlock 1x1 skip conv fused behind the 3x3 K loop
+        EOD_REQUIRE(conv_skip_geom_ok(d) && halo_ok && d->skip_w, "conv: skip_x needs a geometry for which eod_conv_skip_ok(d) == 1, and skip_w");
+        EOD_REQUIRE((d->skip_C1 > 0) == (d->skip_x2 != nullptr), "conv: skip_x2 / skip_C1 mismatch");
+        EOD_REQUIRE(eod_aligned16(d->skip_x) && eod_aligned16(d->skip_x2) && eod_aligned16(d->skip_w), "conv: 16-byte alignment (skip operands)");
+        {
+            const int es = d->dtype == EOD_F16 ? 2 : 4;
+            const long long smax = d->skip_C0 > d->skip_C1 ? d->skip_C0 : d->skip_C1;
+            EOD_REQUIRE((long long)d->H * d->W * smax * es < 0x7fffffffLL && (long long)d->Cout * (d->skip_C0 + d->skip_C1) * es < 0x7fffffffLL,
+                        "conv: skip operand exceeds the 2 GiB window");
+        }
+        p.sx0 = (const char*)d->skip_x;
+        p.sx1 = (const char*)d->skip_x2;
+        p.b2 = (const char*)d->skip_w;
+        p.SC0 = d->skip_C0;
+        p.SC1 = d->skip_C1;
+        p.gn_ss = d->gn_scale_shift;
+        p.gn_silu = d->gn_silu;
+        if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st)
+                                                 : launch_halo<float, 128, 2, 2, false, 2, false, true, 16, true>(p, st);
+        return d->gn_scale_shift ? launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16, true>(p, st)
+                                 : launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16, true>(p, st);
     }
     if (halo_ok && d->w_split) {
         // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)

@@ -40,10 +40,12 @@ extern "C" int eod_pack_conv_weight(const float* w, void* dst, int dtype, int Co
 // max|w|*s lies in (2^12, 2^13].  scale[0] = s, scale[1] = 1 / (s * 16) (what the conv epilogue multiplies by: weight scale and the
 // activation scale of 16).  Two launches, no host round trip: the scale is read from device memory by the pack kernel and by the conv.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restrict__ w, long long n, float* __restrict__ scale) {
+__global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restrict__ w, long long n, float* __restrict__ scale,
+                                                            const float* __restrict__ w2 = nullptr, long long n2 = 0) {
     __shared__ float red[16];
     float m = 0.0f;
     for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    for (long long i = threadIdx.x; i < n2; i += blockDim.x) m = fmaxf(m, fabsf(w2[i]));  // (a second tensor sharing the scale)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -93,6 +95,23 @@ extern "C" int eod_pack_conv_weight_split(const float* w, void* dst, float* scal
     const unsigned blocks = (unsigned)((groups + 255) / 256 > 4096 ? 4096 : (groups + 255) / 256);
     hipLaunchKernelGGL(pack_conv_w_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, scale, Cout, Cin, taps, cin_pad);
     EOD_CHECK_LAUNCH("pack_conv_weight_split");
+    return EOD_OK;
+}
+
+extern "C" int eod_pack_conv_weight_split_pair(const float* w, void* dst, const float* w2, void* dst2, float* scale, int Cout, int Cin,
+                                               int ksize, int cin_pad, int Cin2, void* stream) {
+    EOD_REQUIRE(w && dst && w2 && dst2 && scale && Cout > 0 && Cin > 0 && Cin2 > 0 && cin_pad >= Cin && cin_pad % 8 == 0 && Cin2 % 8 == 0 &&
+                    (ksize == 1 || ksize == 3),
+                "pack_conv_weight_split_pair: bad args (cin_pad and Cin2 must be multiples of 8)");
+    EOD_REQUIRE(eod_aligned16(dst) && eod_aligned16(dst2), "pack_conv_weight_split_pair: dst must be 16-byte aligned");
+    const int taps = ksize * ksize;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, st, w, (long long)Cout * Cin * taps, scale, w2, (long long)Cout * Cin2);
+    const long long g1 = (long long)taps * Cout * (cin_pad / 8), g2 = (long long)Cout * (Cin2 / 8);
+    const unsigned b1 = (unsigned)((g1 + 255) / 256 > 4096 ? 4096 : (g1 + 255) / 256), b2 = (unsigned)((g2 + 255) / 256 > 4096 ? 4096 : (g2 + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_w_split_kernel, dim3(b1), dim3(256), 0, st, w, (half_t*)dst, scale, Cout, Cin, taps, cin_pad);
+    hipLaunchKernelGGL(pack_conv_w_split_kernel, dim3(b2), dim3(256), 0, st, w2, (half_t*)dst2, scale, Cout, Cin2, 1, Cin2);
+    EOD_CHECK_LAUNCH("pack_conv_weight_split_pair");
     return EOD_OK;
 }
 

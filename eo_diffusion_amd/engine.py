@@ -73,6 +73,22 @@ class _LazyConvW:
             self._split = (dst, scale)
         return self._split
 
+    def split_pair(self, weight2):
+        """this 3x3 weight and a 1x1 weight [Cout][Cin2] that feeds the same accumulator (the ResBlock's fused skip conv): both in the
+        split format under ONE scale -> (dst, scale, dst2)"""
+        prog = self.prog
+        w, w2 = prog.f32(self.weight), prog.f32(weight2)
+        cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+        cin2 = w2.shape[1]
+        assert w2.shape[0] == cout and w2.numel() == cout * cin2, "skip weight must be [Cout][Cin2][1][1]"
+        cin_pad = self.cin_pad or cin
+        dst = prog.empty((k * k, cout, cin_pad), torch.float32)
+        dst2 = prog.empty((1, cout, cin2), torch.float32)
+        scale = prog.empty((2,), torch.float32)
+        check(prog.L.eod_pack_conv_weight_split_pair(ptr(w), ptr(dst), ptr(w2), ptr(dst2), ptr(scale), cout, cin, k, cin_pad, cin2,
+                                                     current_stream_ptr(prog.device)), "pack_conv_weight_split_pair")
+        return dst, scale, dst2
+
 
 class Program:
     def __init__(self, device, precision):
@@ -205,10 +221,24 @@ class Program:
         d.ksize, d.stride, d.pad, d.upsample, d.pad_tl, d.Ho, d.Wo = 3, 1, 1, 4, 0, dy.H // 2, dy.W // 2
         return bool(self.L.eod_conv_up4_bwd_ok(C.byref(d)))
 
+    def conv_skip_ok(self, x, cout, srcs):
+        """True if the library can run `conv3x3(x) + conv1x1(cat(srcs))` (a ResBlock's out_layers conv + skip_connection,
+        unet_openai.py:385) as ONE launch for this geometry (eod_conv_desc.skip_x)"""
+        if len(srcs) > 2 or any((s.N, s.H, s.W) != (x.N, x.H, x.W) for s in srcs) or self.precision == "fp32":
+            return False
+        d = ConvDesc()
+        d.dtype, d.N, d.H, d.W, d.C0, d.C1, d.Cout = self.dt, x.N, x.H, x.W, x.C, 0, cout
+        d.ksize, d.stride, d.pad, d.Ho, d.Wo = 3, 1, 1, x.H, x.W
+        d.w_split = int(self.split)
+        d.skip_C0, d.skip_C1 = srcs[0].C, (srcs[1].C if len(srcs) > 1 else 0)
+        return bool(self.L.eod_conv_skip_ok(C.byref(d)))
+
     def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
-             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None, w_tapmajor=False):
+             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None, w_tapmajor=False, skip=None):
         """gn = (scale_shift tensor from gn_stats(), silu): GroupNorm(+SiLU) of the conv INPUT.  Fused into the conv's
-        patch staging when the library can (eod_conv_gn_fusable), otherwise applied by a separate pass first."""
+        patch staging when the library can (eod_conv_gn_fusable), otherwise applied by a separate pass first.
+        skip = (srcs, weight, bias): add conv1x1(cat(srcs)) with that OI11 weight / bias in the same launch (only where
+        conv_skip_ok(x, cout, srcs); w_packed must be pack_conv(weight3x3) of this program)."""
         if gn is not None:
             probe = ConvDesc()
             probe.dtype, probe.N, probe.H, probe.W = self.dt, x.N, x.H, x.W
@@ -239,7 +269,23 @@ class Program:
         d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
         d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
         d.w_tapmajor = int(w_tapmajor)
-        if isinstance(w_packed, tuple) and w_packed[0] == "split":  # pre-split weights (thin-input first conv of an fp32x3 program)
+        if skip is not None:
+            ssrc, sw, sb = skip
+            assert res is None and x2 is None and self.conv_skip_ok(x, cout, ssrc), "fused skip conv: ask conv_skip_ok first"
+            d.skip_x, d.skip_C0 = ptr(ssrc[0].t), ssrc[0].C
+            if len(ssrc) > 1:
+                d.skip_x2, d.skip_C1 = ptr(ssrc[1].t), ssrc[1].C
+            op._skip_c = d.skip_C0 + d.skip_C1
+            if self.split:
+                wt, wscale, wt2 = w_packed.split_pair(sw)
+                d.w, d.w_split, d.w_scale, d.skip_w = ptr(wt), 1, ptr(wscale), ptr(wt2)
+            else:
+                d.w, d.skip_w = ptr(w_packed), ptr(self._pack_conv_plain(sw))
+            if sb is not None:  # both biases land in the one epilogue add
+                bsum = self.empty((cout,), torch.float32)
+                check(self.L.eod_add(ptr(bias), ptr(self.f32(sb)), ptr(bsum), _lib.EOD_F32, cout, current_stream_ptr(self.device)), "add (bias)")
+                d.bias = ptr(bsum)
+        elif isinstance(w_packed, tuple) and w_packed[0] == "split":  # pre-split weights (thin-input first conv of an fp32x3 program)
             d.w, d.w_split, d.w_scale = ptr(w_packed[1]), 1, ptr(w_packed[2])
         elif isinstance(w_packed, _LazyConvW):  # fp32x3: split-fp16 product where the library has it for this geometry
             if self.L.eod_conv_split_ok(C.byref(d)):
@@ -471,8 +517,9 @@ class Program:
                 cin = d.C0 + d.C1
                 m = d.N * d.Ho * d.Wo
                 cin_alg = getattr(op, "_cin_alg", cin)
-                fl = 2.0 * m * d.Cout * cin_alg * d.ksize * d.ksize
-                by = es * (d.N * d.H * d.W * cin + d.ksize * d.ksize * d.Cout * cin + (0 if d.out_nchw_f32 else m * d.Cout)) \
+                sc = getattr(op, "_skip_c", 0)  # fused 1x1 skip conv over `sc` more input channels (center tap only)
+                fl = 2.0 * m * d.Cout * (cin_alg * d.ksize * d.ksize + sc)
+                by = es * (d.N * d.H * d.W * (cin + sc) + d.ksize * d.ksize * d.Cout * cin + d.Cout * sc + (0 if d.out_nchw_f32 else m * d.Cout)) \
                     + (4 * m * d.Cout if d.out_nchw_f32 else 0) + (es * m * d.Cout if d.res else 0)
                 geo = d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and d.Wo % 16 == 0 and d.Ho % 8 == 0
                 halo = geo and d.Cout > 64 and not d.out_nchw_f32 and not d.w_tapmajor  # mirrors conv_uses_halo() in csrc/igemm.hip
@@ -483,7 +530,8 @@ class Program:
                 out.append(dict(kind="conv", flops=fl, bytes=by, exec_flops=fl * (4.0 / 9.0 if up4 else 1.0),
                                 kernel="conv_up4_halo_kernel" if up4 else "conv3x3_halo_kernel" if halo else
                                        "conv_head_kernel" if headk else "conv3x3_halo_kernel<BN=32>" if head else "igemm_kernel",
-                                label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u4' if up4 else 'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"))
+                                label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u4' if up4 else 'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"
+                                      + (f" +skip1x1 {sc}" if sc else "")))
             elif k == OP_GEMM:
                 d = op.u.gemm
                 nb = d.nb0 * d.nb1

@@ -88,6 +88,16 @@ typedef struct {
                             eod_conv_split_ok(d) == 1 (fp32, C0 and C1 multiples of 8 -- or w_tapmajor with eod_pack_conv_weight_tapmajor_split);
                             rel. error ~2^-22 per product */
     const float* w_scale; /* device pointer to {s, 1/(16 s)} written by eod_pack_conv_weight_split (w_split only) */
+    /* ResBlock skip connection fused into out_layers' conv (unet_openai.py:352, 385: `return self.skip_connection(x) + h`): y gets
+     * sum_c skip_w[co][c] * X(n, ho, wo, c) on top of the 3x3 conv, X = the block input (skip_x | skip_x2 as a virtual concat) at the
+     * output resolution.  The skip tensor is never written: same accumulators, the K loop simply continues over X's channels.
+     * skip_w = the 1x1 weight packed like `w` (eod_pack_conv_weight, ksize 1: [Cout][skip_C0 + skip_C1]; w_split: BOTH weights packed
+     * by eod_pack_conv_weight_split_pair -- one common scale); the caller adds the skip conv's bias into `bias`.  Only where
+     * eod_conv_skip_ok(d) == 1 (3x3 / stride 1 / halo-tile geometry, Cout > 64, C1 == 0, no `res`); NULL = off. */
+    const void* skip_x;
+    const void* skip_x2;
+    const void* skip_w;
+    int32_t skip_C0, skip_C1;
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
@@ -95,6 +105,7 @@ int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 int eod_conv_stats_slots(const eod_conv_desc* d);
 int eod_conv_gn_fusable(const eod_conv_desc* d);
 int eod_conv_split_ok(const eod_conv_desc* d);
+int eod_conv_skip_ok(const eod_conv_desc* d);
 /* upsample = 3 (Upsample.conv, unet_openai.py:236-241, in 4/9 of the MACs): output pixel (2i+p, 2j+q) of the 3x3 conv over the nearest-2x
  * image reads only stored rows {i-1+p, i+p} and columns {j-1+q, j+q}, so each parity class (p, q) is a 2x2-tap conv of the STORED map with
  * summed taps (rows: p = 0 -> [w0 | w1+w2], p = 1 -> [w0+w1 | w2]; columns alike).  w is then ONE packed tensor (eod_pack_conv_weight /
@@ -144,6 +155,10 @@ int eod_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int Cout, in
  * channels as [8 x fp16 hi | 8 x fp16 lo] of s*w, s = 2^k per tensor chosen on the device; scale (device, 2 floats) receives
  * {s, 1/(16 s)}.  cin_pad % 8 == 0.  No host synchronisation. */
 int eod_pack_conv_weight_split(const float* w_oihw, void* dst, float* scale, int Cout, int Cin, int ksize, int cin_pad, void* stream);
+/* two weights that feed ONE accumulator (eod_conv_desc.skip_w: out_layers' 3x3 conv + the 1x1 skip_connection, unet_openai.py:341,352):
+ * both packed as above with one common scale s taken over the two tensors.  w2 is [Cout][Cin2] (1x1), dst2 [Cout][Cin2] at 4 bytes. */
+int eod_pack_conv_weight_split_pair(const float* w_oihw, void* dst, const float* w2_oi, void* dst2, float* scale, int Cout, int Cin,
+                                    int ksize, int cin_pad, int Cin2, void* stream);
 /* thin-input variant: OIHW fp32 -> [Cout][ldk], k = tap*cin_pad + c, zero padded (see eod_conv_desc.w_tapmajor) */
 int eod_pack_conv_weight_tapmajor(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int cin_pad, void* stream);
 /* the same in the split-fp16 pair format (fp32 storage, eod_conv_desc.w_tapmajor together with w_split); scale as above */

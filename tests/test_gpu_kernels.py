@@ -62,6 +62,51 @@ def test_conv_vs_torch(prec, case):
 
 @pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
 @pytest.mark.parametrize("gn", [False, True])
+@pytest.mark.parametrize("case", [
+    # N, C (3x3 input), H, W, Cout, skip channels (one source, or two = virtual concat)
+    (2, 128, 8, 16, 128, (64,)),          # one K-step of skip (fp16), two (fp32 storage)
+    (1, 128, 16, 32, 128, (256, 128)),    # the A0 up-path block: conv2 128->128 + skip over cat(256, 128)
+    (2, 96, 16, 16, 192, (40,)),          # channel tails in both phases (96 % 64, 40 % 32), N tail (192 % 128)
+    (1, 256, 24, 16, 256, (72, 200)),     # two N tiles; tails in both skip sources
+    (3, 160, 8, 16, 136, (320,)),         # one patch per image, Cout % 128 = 8
+])
+def test_conv3x3_with_fused_1x1_skip_vs_torch(prec, gn, case):
+    """eod_conv_desc.skip_x (conv3x3_halo_kernel<SKIP>): y = conv3x3([GroupNorm+SiLU](h)) + conv1x1(cat(x...)) + both biases, the ResBlock
+    tail `skip_connection(x) + h` (unet_openai.py:352, 385) in one launch, vs the two F.conv2d of the reference; fp32x3: the two
+    weights share one split scale (eod_pack_conv_weight_split_pair) -- the skip weight is 8x the 3x3 one here to exercise that"""
+    from eo_diffusion_amd.engine import Act
+    N, C, H, W, Cout, scs = case
+    h = synth_input(f"skh{case}", (N, C, H, W), 47, scale=1.3) + 0.1
+    xs = [synth_input(f"skx{case}{i}", (N, c, H, W), 47) for i, c in enumerate(scs)]
+    w3 = synth_input(f"skw3{case}", (Cout, C, 3, 3), 47, scale=1.0 / math.sqrt(C * 9))
+    w1 = synth_input(f"skw1{case}", (Cout, sum(scs), 1, 1), 47, scale=8.0 / math.sqrt(C * 9))
+    b3 = synth_input(f"skb3{case}", (Cout,), 47, scale=0.1)
+    b1 = synth_input(f"skb1{case}", (Cout,), 47, scale=0.1)
+    gam = 1.0 + 0.2 * synth_input("skg", (C,), 47)
+    bet = 0.1 * synth_input("ske", (C,), 47)
+    prog = Program(DEV, prec)
+    to_act = lambda t: Act(prog.own(t.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), t.shape[0], H, W, t.shape[1])
+    ah, axs = to_act(h), [to_act(t) for t in xs]
+    if not prog.conv_skip_ok(ah, Cout, axs):
+        pytest.skip("fused skip conv not available in this configuration (EOD_SKIP_FUSE=0 / EOD_MFMA_SHAPE=32)")
+    g = (prog.gn_stats([ah], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True) if gn else None
+    y, _ = prog.conv(ah, prog.pack_conv(w3.to(DEV)), prog.f32(b3.to(DEV)), Cout, gn=g, stats=True, skip=(axs, w1.to(DEV), b1.to(DEV)))
+    prog.run()
+    torch.cuda.synchronize()
+    got = y.t.float().permute(0, 3, 1, 2).cpu()
+    hin = F.silu(F.group_norm(h, 32, gam, bet, eps=1e-5)) if gn else h
+    if prec == "fp16":  # the oracle sees the stored (fp16-rounded) operands of the skip path
+        xs = [t.half().float() for t in xs]
+    ref = F.conv2d(hin, w3, b3, padding=1) + F.conv2d(torch.cat(xs, 1), w1, b1)
+    assert rel_l2(got, ref) < TOL[prec]
+    if y.stats is not None:  # the epilogue's GroupNorm partial sums cover the fused result
+        st, slots = y.stats
+        tot = st.sum(1).cpu()  # [N][Cout][2]
+        assert torch.allclose(tot[..., 0], got.sum((2, 3)), rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
+@pytest.mark.parametrize("gn", [False, True])
 @pytest.mark.parametrize("case", [(2, 128, 8, 16, 128), (1, 96, 16, 32, 192), (3, 64, 24, 16, 256), (1, 640, 16, 16, 160)])
 def test_conv_nearest_upsample_parity_class_form_vs_torch(prec, gn, case):
     """upsample='up4' (conv_up4_halo_kernel): the 3x3 conv over the nearest-2x image as four 2x2-tap parity classes with pre-summed
