@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeodiff.so")
+# (EOD_LIBRARY: another build of the same library, for same-box A/B measurements of a kernel change -- tools only)
+LIB_PATH = os.environ.get("EOD_LIBRARY") or os.path.join(_HERE, "lib", "libeodiff.so")
 
 EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,

@@ -144,7 +144,8 @@ __device__ __forceinline__ i32x4 split_pair_exchange(const f32x4& f, bool odd_ch
     int hi[2], lo[2];
     split4(f, hi, lo);
     const int s0 = odd_chunk ? hi[0] : lo[0], s1 = odd_chunk ? hi[1] : lo[1];
-    const int r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+    // lane ^ 1 through DPP quad_perm [1, 0, 3, 2] (a VALU move; __shfl_xor would go through the LDS crossbar: ds_bpermute + wait)
+    const int r0 = __builtin_amdgcn_mov_dpp(s0, 0xB1, 0xF, 0xF, true), r1 = __builtin_amdgcn_mov_dpp(s1, 0xB1, 0xF, 0xF, true);
     return odd_chunk ? i32x4{r0, r1, lo[0], lo[1]} : i32x4{hi[0], hi[1], r0, r1};
 }
 
