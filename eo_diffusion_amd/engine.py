@@ -281,10 +281,9 @@ class Program:
                 d.w, d.w_split, d.w_scale, d.skip_w = ptr(wt), 1, ptr(wscale), ptr(wt2)
             else:
                 d.w, d.skip_w = ptr(w_packed), ptr(self._pack_conv_plain(sw))
-            if sb is not None:  # both biases land in the one epilogue add
-                bsum = self.empty((cout,), torch.float32)
-                check(self.L.eod_add(ptr(bias), ptr(self.f32(sb)), ptr(bsum), _lib.EOD_F32, cout, current_stream_ptr(self.device)), "add (bias)")
-                d.bias = ptr(bsum)
+            if sb is not None:  # the skip conv's bias: the per-sample bias slot with stride 0 (both vectors stay live parameters)
+                assert cbias is None, "fused skip conv: the per-sample bias slot carries the skip bias"
+                d.cbias, d.cbias_stride = ptr(self.f32(sb)), 0
         elif isinstance(w_packed, tuple) and w_packed[0] == "split":  # pre-split weights (thin-input first conv of an fp32x3 program)
             d.w, d.w_split, d.w_scale = ptr(w_packed[1]), 1, ptr(w_packed[2])
         elif isinstance(w_packed, _LazyConvW):  # fp32x3: split-fp16 product where the library has it for this geometry

@@ -92,7 +92,7 @@ typedef struct {
      * sum_c skip_w[co][c] * X(n, ho, wo, c) on top of the 3x3 conv, X = the block input (skip_x | skip_x2 as a virtual concat) at the
      * output resolution.  The skip tensor is never written: same accumulators, the K loop simply continues over X's channels.
      * skip_w = the 1x1 weight packed like `w` (eod_pack_conv_weight, ksize 1: [Cout][skip_C0 + skip_C1]; w_split: BOTH weights packed
-     * by eod_pack_conv_weight_split_pair -- one common scale); the caller adds the skip conv's bias into `bias`.  Only where
+     * by eod_pack_conv_weight_split_pair -- one common scale); the skip conv's bias can go through cbias with cbias_stride = 0.  Only where
      * eod_conv_skip_ok(d) == 1 (3x3 / stride 1 / halo-tile geometry, Cout > 64, C1 == 0, no `res`); NULL = off. */
     const void* skip_x;
     const void* skip_x2;
