@@ -279,6 +279,8 @@ class Program:
             if self.split:
                 wt, wscale, wt2 = w_packed.split_pair(sw)
                 d.w, d.w_split, d.w_scale, d.skip_w = ptr(wt), 1, ptr(wscale), ptr(wt2)
+            elif isinstance(sw, tuple) and sw[0] == "packed":  # [1][Cout][skip channels] that the caller (re)packs itself (training step)
+                d.w, d.skip_w = ptr(w_packed), ptr(sw[1])
             else:
                 d.w, d.skip_w = ptr(w_packed), ptr(self._pack_conv_plain(sw))
             if sb is not None:  # the skip conv's bias: the per-sample bias slot with stride 0 (both vectors stay live parameters)

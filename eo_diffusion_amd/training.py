@@ -218,7 +218,9 @@ class UNetTrainer:
         return cur[:numel]
 
     # ------------------------------------------------------------------ forward emission (training form)
-    def _conv_fwd(self, srcs, conv, *, ksize=3, stride=1, upsample=False, res=None, emb=None, stats=True, src_needs_grad=True):
+    def _conv_fwd(self, srcs, conv, *, ksize=3, stride=1, upsample=False, res=None, emb=None, stats=True, src_needs_grad=True, skip=None):
+        """skip = (block inputs, the 1x1 skip_connection conv): its product rides in this conv's accumulators (eod_conv_desc.skip_x); the
+        backward is unchanged -- the skip conv gets a record of its own whose output is a placeholder that only ever carries dY"""
         prog = self.prog
         fwd_ups = upsample
         if (upsample and len(srcs) == 1 and res is None and emb is None and ksize == 3 and stride == 1
@@ -239,8 +241,17 @@ class UNetTrainer:
         if emb is not None:
             kw = dict(cbias=emb[0], cbias_stride=emb[1])
         up4_wc = fwd_ups if isinstance(fwd_ups, torch.Tensor) else None
+        if skip is not None:
+            ssrcs, sconv = skip
+            assert res is None and len(srcs) == 1
+            sw = prog.empty((1, conv.out_channels, sum(a.C for a in ssrcs)))
+            self._add_pack_job(0, sconv, sw)
+            res = Act(None, srcs[0].N, srcs[0].H, srcs[0].W, conv.out_channels)  # placeholder of skip_connection(x): never materialised
+            self.recs.append(_ConvRec(ssrcs, sconv, res, ksize=1))
+            kw["skip"] = (ssrcs, ("packed", sw), sconv.bias)
         y, _ = prog.conv(srcs[0], w, prog.f32(conv.bias), conv.out_channels, x2=srcs[1] if len(srcs) > 1 else None,
-                         ksize=ksize, stride=stride, pad=ksize // 2, upsample=("up4" if up4_wc is not None else fwd_ups), res=res, stats=stats, **kw)
+                         ksize=ksize, stride=stride, pad=ksize // 2, upsample=("up4" if up4_wc is not None else fwd_ups),
+                         res=None if skip is not None else res, stats=stats, **kw)
         rec = _ConvRec(srcs, conv, y, ksize=ksize, stride=stride, upsample=upsample, res=res, emb=emb, src_needs_grad=src_needs_grad)
         rec.up4_wc = up4_wc  # fp32 class-kernel tensor of the parity-class form (its backward-data can use it too)
         self.recs.append(rec)
@@ -345,6 +356,8 @@ class UNetTrainer:
             skip = srcs[0]
         else:
             k = blk.skip_connection.kernel_size[0]
+            if k == 1 and self.prog.conv_skip_ok(a2, conv2.out_channels, srcs):
+                return self._conv_fwd([a2], conv2, skip=(srcs, blk.skip_connection))  # `skip_connection(x) + h` in conv2's launch
             skip = self._conv_fwd(srcs, blk.skip_connection, ksize=k, stats=False)
         return self._conv_fwd([a2], conv2, res=skip)
 
