@@ -287,6 +287,9 @@ def time_sampling(args, m, dev, rank, world, use_dist, dist, timing=True):
                 "kernel_share_of_step": tsec / (dt / args.steps)}
         if prec in PEAK_NOTE:
             roof["peak_note"] = PEAK_NOTE[prec]
+        nskip = sum(1 for s, _ in conv if "+skip1x1" in s["label"])
+        if nskip:  # ResBlocks whose 1x1 skip conv runs inside out_layers' conv: those launches carry its FLOPs too
+            roof["launches_with_fused_1x1_skip"] = nskip
         if up4:
             # the sibling kernel of the convs behind a nearest-2x upsampling: the algorithm's nine taps are executed as four pre-summed
             # ones per output parity class, so its ALGORITHMIC rate (the reference's flop count) exceeds what its MFMAs execute
