@@ -898,13 +898,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // written to or read back from HBM (2 x M x Cout elements per block), and its MFMA work runs at this kernel's rate instead of in an
 // HBM-bound launch of its own.
 template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel(const IgemmP p) {
-    static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M * WAVES_N == 4), "fused skip conv: 16x16x32 instances of the 8x16 tile");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void conv3x3_halo_kernel(const IgemmP p) {
+    static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M == 2), "fused skip conv: 16x16x32 instances of the 8x16 tile");
     static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 product is a mode of fp32 storage");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only");
     constexpr bool XF = GN || SPLIT;  // the staged patch pieces are rewritten in place by the wave that DMA'd them
     constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
-    constexpr int BM = 32 * NW, TH = BM / 16, TW = 16;
+    // WAVES_N = 4 (BN = 256): the 8x16 pixel tile with EIGHT waves, 2 x 4, each still 64 x 64 -- one workgroup covers the two N-tiles of a
+    // 256-column conv, so the patch is fetched from HBM and normalised / split ONCE for both (one 8-wave workgroup per CU instead of two
+    // 4-wave ones: the same waves per SIMD)
+    constexpr int BM = WAVES_N == 4 ? 64 * WAVES_M : 32 * NW, TH = BM / 16, TW = 16;
     constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2, PR = PH * PW;  // 180 (60) patch rows
     constexpr int PG = (PR + 7) / 8;                                             // 23 (8) DMA groups of 8 rows
     constexpr int LAH = (PG + NW - 1) / NW;                                      // patch pieces per wave
@@ -1315,7 +1318,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         // ---- 1x1 skip conv over the block input: GEMM-layout ring in the same LDS, K-step = 32 / 64 channels of one source ----
         constexpr int LA = BM / 8 / NW;                    // 8-row pieces of the pixel tile per wave (4)
         constexpr int STG_A = BM * BKB, STG = STG_A + BSTAGE;
-        static_assert(2 * STG <= 2 * ABUF + BSTAGES * BSTAGE && LA == LB, "the skip phase reuses the operand ring");
+        static_assert(2 * STG <= 2 * ABUF + BSTAGES * BSTAGE, "the skip phase reuses the operand ring");
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();  // every wave is done with the 3x3 loop's buffers
         const int SC = p.SC0 + p.SC1;
@@ -1324,11 +1327,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv3x3_halo_kernel
         const __amdgpu_buffer_rsrc_t rsW2 = make_rsrc(p.b2 + (long long)n0 * SC * ES);
         // row r of the tile = pixel (ty0 + r / 16, tx0 + r % 16) -- always inside the image; rows use the (row >> 1) & 7 swizzle, which
         // for this lane's pieces is bchunk0 (the weight rows' value)
-        unsigned xpix[LA], wv[LA];
+        unsigned xpix[LA], wv[LB];
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int row = (wave + NW * i) * 8 + srow;
             xpix[i] = (unsigned)((g.ty0 + (row >> 4)) * p.W + g.tx0 + (row & 15));
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int row = (wave + NW * i) * 8 + srow;
             wv[i] = (n0 + row < p.Ncols) ? (unsigned)(row * SC * ES) + bchunk0 * 16 : EOD_OOB;
         }
         auto issue_skip = [&](int kt, char* stg) {
@@ -2053,7 +2060,7 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
 template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
-    constexpr int NW = WAVES_M * WAVES_N, BM = 32 * NW, TH = BM / 16;
+    constexpr int NW = WAVES_M * WAVES_N, BM = WAVES_N == 4 ? 64 * WAVES_M : 32 * NW, TH = BM / 16;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int PR = UPS ? (TH / 2 + 2) * 10 : (TH + 2) * 18, PG = (PR + 7) / 8;
     const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128 + (GN ? 2048 : 0);
@@ -2196,6 +2203,15 @@ static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
     const bool store_ok = d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
     return on && halo_ok && d->out_nchw_f32 && d->Cout <= 16 && d->gn_scale_shift && d->C1 == 0 && !d->x2 && !d->upsample && !d->res && !d->cbias &&
            !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C && halo_mfma_shape() == 16;
+}
+// 256-column convs in fp32 storage on the 8-wave instance that shares one patch between the two N-tiles (EOD_HALO_BN256=0: off, A/B)
+static bool halo_bn256(const eod_conv_desc* d) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EOD_HALO_BN256");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return on && d->Cout % 256 == 0 && !d->upsample && halo_mfma_shape() == 16;
 }
 // ResBlock 1x1 skip conv fused behind the 3x3 K loop (conv3x3_halo_kernel<SKIP>; EOD_SKIP_FUSE=0: off, A/B)
 static bool conv_skip_geom_ok(const eod_conv_desc* d) {
@@ -2384,6 +2400,9 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.SC1 = d->skip_C1;
         p.gn_ss = d->gn_scale_shift;
         p.gn_silu = d->gn_silu;
+        if (d->w_split && halo_bn256(d))
+            return d->gn_scale_shift ? launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(p, st)
+                                     : launch_halo<float, 256, 2, 4, false, 2, false, true, 16, true>(p, st);
         if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st)
                                                  : launch_halo<float, 128, 2, 2, false, 2, false, true, 16, true>(p, st);
         return d->gn_scale_shift ? launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16, true>(p, st)
@@ -2396,6 +2415,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
             if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, true, true>(p, st);
+            if (m16 && halo_bn256(d)) return launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(p, st);
             return m16 ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true, true>(p, st);
         }
         if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, false, true>(p, st);
