@@ -2206,7 +2206,7 @@ static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
     return on && halo_ok && d->out_nchw_f32 && d->Cout <= 16 && d->gn_scale_shift && d->C1 == 0 && !d->x2 && !d->upsample && !d->res && !d->cbias &&
            !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C && halo_mfma_shape() == 16;
 }
-// 256-column convs in fp32 storage on the 8-wave instance that shares one patch between the two N-tiles (EOD_HALO_BN256=0: off, A/B)
+// 256-column convs with a fused GroupNorm on the 8-wave instance that shares one patch between the two N-tiles (EOD_HALO_BN256=0: off, A/B)
 static bool halo_bn256(const eod_conv_desc* d) {
     static int on = -1;
     if (on < 0) {
@@ -2407,6 +2407,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
                                      : launch_halo<float, 256, 2, 4, false, 2, false, true, 16, true>(p, st);
         if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st)
                                                  : launch_halo<float, 128, 2, 2, false, 2, false, true, 16, true>(p, st);
+        if (d->gn_scale_shift && halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16, true>(p, st);
         return d->gn_scale_shift ? launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16, true>(p, st)
                                  : launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16, true>(p, st);
     }
@@ -2430,6 +2431,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
             if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, true, false, 16>(p, st);
+            if (halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16>(p, st);
             return launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16>(p, st);
         }
         if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, false, false, 16>(p, st);
