@@ -105,6 +105,55 @@ def test_conv3x3_with_fused_1x1_skip_vs_torch(prec, gn, case):
         assert torch.allclose(tot[..., 0], got.sum((2, 3)), rtol=2e-3, atol=2e-2)
 
 
+def _random_halo_cases(n, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n):
+        N = rnd.choice([1, 2, 3])
+        H, W = 8 * rnd.choice([1, 2, 3, 5]), 16 * rnd.choice([1, 2, 3])
+        C = 8 * rnd.choice([4, 8, 12, 16, 20, 33, 48])
+        Cout = rnd.choice([128, 256, 512, 136, 384, 200, 256])
+        nsrc = rnd.choice([0, 1, 2])
+        scs = tuple(8 * rnd.choice([1, 4, 5, 8, 16, 23, 40]) for _ in range(nsrc))
+        out.append((N, C, H, W, Cout, scs, rnd.random() < 0.7))
+    return out
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
+@pytest.mark.parametrize("case", _random_halo_cases(14, 20260101))
+def test_halo_conv_random_shapes_vs_torch(prec, case):
+    """seeded random geometries through every instance of the halo kernel's fast paths: 4-wave / 8-wave (256-column) tiles, GroupNorm
+    fused or not, with or without the fused 1x1 skip conv over one or two sources, channel and column tails, several images"""
+    from eo_diffusion_amd.engine import Act
+    N, C, H, W, Cout, scs, gn = case
+    h = synth_input(f"rh{case}", (N, C, H, W), 53, scale=1.2) - 0.1
+    xs = [synth_input(f"rx{case}{i}", (N, c, H, W), 53) for i, c in enumerate(scs)]
+    w3 = synth_input(f"rw3{case}", (Cout, C, 3, 3), 53, scale=1.0 / math.sqrt(C * 9))
+    b3 = synth_input(f"rb3{case}", (Cout,), 53, scale=0.1)
+    gam = 1.0 + 0.2 * synth_input("rg", (C,), 53)
+    bet = 0.1 * synth_input("re", (C,), 53)
+    prog = Program(DEV, prec)
+    to_act = lambda t: Act(prog.own(t.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), t.shape[0], H, W, t.shape[1])
+    ah, axs = to_act(h), [to_act(t) for t in xs]
+    gn = gn and C % 32 == 0
+    g = (prog.gn_stats([ah], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True) if gn else None
+    hin = F.silu(F.group_norm(h, 32, gam, bet, eps=1e-5)) if gn else h
+    ref = F.conv2d(hin if prec != "fp16" or gn else h.half().float(), w3, b3, padding=1)
+    skip = None
+    if xs and prog.conv_skip_ok(ah, Cout, axs):
+        w1 = synth_input(f"rw1{case}", (Cout, sum(scs), 1, 1), 53, scale=1.0 / math.sqrt(sum(scs)))
+        b1 = synth_input(f"rb1{case}", (Cout,), 53, scale=0.1)
+        skip = (axs, w1.to(DEV), b1.to(DEV))
+        ref = ref + F.conv2d(torch.cat([t.half().float() if prec == "fp16" else t for t in xs], 1), w1, b1)
+    y, _ = prog.conv(ah, prog.pack_conv(w3.to(DEV)), prog.f32(b3.to(DEV)), Cout, gn=g, stats=True, skip=skip)
+    prog.run()
+    torch.cuda.synchronize()
+    got = y.t.float().permute(0, 3, 1, 2).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < TOL[prec]
+
+
 @pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
 @pytest.mark.parametrize("gn", [False, True])
 @pytest.mark.parametrize("case", [(2, 128, 8, 16, 128), (1, 96, 16, 32, 192), (3, 64, 24, 16, 256), (1, 640, 16, 16, 160)])
