@@ -69,6 +69,44 @@ def test_library_exports_every_declared_symbol():
     assert L.eod_version() >= 100
 
 
+def test_conv_geometry_queries_are_pure_host_predicates():
+    """the eod_conv_*_ok queries decide on the host which kernel form a conv descriptor gets (no device call): the rules of
+    include/eodiff.h for the fused 1x1 skip conv, the parity-class upsample form and the fused input GroupNorm"""
+    import ctypes as C
+    from eo_diffusion_amd import _lib
+    L = _lib.lib()
+
+    def desc(**kw):
+        d = _lib.ConvDesc()
+        d.dtype, d.N, d.H, d.W, d.C0, d.C1, d.Cout = _lib.EOD_F32, 2, 32, 32, 128, 0, 128
+        d.ksize, d.stride, d.pad, d.Ho, d.Wo, d.w_split = 3, 1, 1, 32, 32, 1
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    ok = lambda fn, **kw: bool(fn(C.byref(desc(**kw))))
+    # fused skip conv: 3x3 / stride 1 on maps that tile into 8 x 16 patches, > 64 output channels, whole 8-channel groups
+    assert ok(L.eod_conv_skip_ok, skip_C0=256, skip_C1=128)
+    assert ok(L.eod_conv_skip_ok, skip_C0=64, dtype=_lib.EOD_F16, w_split=0)
+    assert not ok(L.eod_conv_skip_ok, skip_C0=0)
+    assert not ok(L.eod_conv_skip_ok, skip_C0=60)                       # not a multiple of 8
+    assert not ok(L.eod_conv_skip_ok, skip_C0=64, w_split=0)            # exact fp32 keeps the separate launch
+    assert not ok(L.eod_conv_skip_ok, skip_C0=64, W=24, Wo=24)          # 24 columns do not tile
+    assert not ok(L.eod_conv_skip_ok, skip_C0=64, Cout=64)
+    assert not ok(L.eod_conv_skip_ok, skip_C0=64, stride=2, Ho=16, Wo=16)
+    assert not ok(L.eod_conv_skip_ok, skip_C0=64, C1=32)                # the 3x3 input is a single source
+    # parity-class upsample form: stored map tiles into 8 x 16 patches, fp16 or split fp32
+    assert ok(L.eod_conv_up4_ok, upsample=3, Ho=64, Wo=64)
+    assert not ok(L.eod_conv_up4_ok, upsample=3, Ho=64, Wo=64, w_split=0)
+    assert not ok(L.eod_conv_up4_ok, upsample=1, Ho=64, Wo=64)
+    assert not ok(L.eod_conv_up4_ok, upsample=3, H=20, Ho=40, Wo=64)
+    # fused input GroupNorm: every width in split fp32, up to 256 output channels in fp16 storage
+    assert ok(L.eod_conv_gn_fusable, Cout=512)
+    assert ok(L.eod_conv_gn_fusable, Cout=256, dtype=_lib.EOD_F16, w_split=0)
+    assert not ok(L.eod_conv_gn_fusable, Cout=512, dtype=_lib.EOD_F16, w_split=0)
+    assert not ok(L.eod_conv_gn_fusable, stride=2, Ho=16, Wo=16)
+
+
 def test_product_fails_loudly_without_gpu():
     from eo_diffusion_amd import _lib
     from eo_diffusion_amd.backbones.unet_openai import ResBlock, UNetModel, normalization
