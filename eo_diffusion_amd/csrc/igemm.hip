@@ -908,7 +908,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     // 256-column conv, so the patch is fetched from HBM and normalised / split ONCE for both (one 8-wave workgroup per CU instead of two
     // 4-wave ones: the same waves per SIMD): +3.5 ... 10 % on the 256- and 512-column convs.  (The mirror image for 128-column convs -- a
     // 16 x 16 pixel tile, 4 x 2 waves, halo 1.27x instead of 1.41x and one weight tile per 256 pixels -- measured -1 ... +2 %, and the
-    // same 2 x 4 form of conv_up4_halo_kernel +0.4 %: neither is used.)
+    // same 2 x 4 form of conv_up4_halo_kernel +0.4 %: neither is used; a three-stage weight ring on this instance: -2 %.)
     constexpr int BM = WAVES_N == 4 ? 64 * WAVES_M : 32 * NW, TH = BM / 16, TW = 16;
     constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2, PR = PH * PW;  // 180 (60) patch rows
     constexpr int PG = (PR + 7) / 8;                                             // 23 (8) DMA groups of 8 rows
