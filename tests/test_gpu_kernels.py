@@ -121,7 +121,8 @@ def _random_halo_cases(n, seed):
 
 
 @pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
-@pytest.mark.parametrize("case", _random_halo_cases(14, 20260101))
+@pytest.mark.parametrize("case", _random_halo_cases(int(os.environ.get("EOD_TEST_RANDOM_CASES", "14")),
+                                                    int(os.environ.get("EOD_TEST_RANDOM_SEED", "20260101"))))  # (soak runs: more cases / other seeds)
 def test_halo_conv_random_shapes_vs_torch(prec, case):
     """seeded random geometries through every instance of the halo kernel's fast paths: 4-wave / 8-wave (256-column) tiles, GroupNorm
     fused or not, with or without the fused 1x1 skip conv over one or two sources, channel and column tails, several images"""
