@@ -2113,11 +2113,23 @@ template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipSt
     return launch_cfg<T, CONV, 128, 128, 2, 2, 2>(p, batch, st);
 }
 
+static bool igemm_bn256() {  // EOD_HALO_BN256=0 switches the 8-wave 256-column forms off everywhere (A/B)
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EOD_HALO_BN256");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return on != 0;
+}
 // fp32 conv as the split-fp16 product on the generic kernel (1x1, stride 2, ragged maps)
 static int launch_conv_split(IgemmP& p, int batch, hipStream_t st) {
     if (halo_mfma_shape() == 16) {
         if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true, 16>(p, batch, st);
         if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true, 16>(p, batch, st);
+        // 256 columns per 8-wave workgroup: the pixel rows of a K-step are fetched and split once for two N-tiles (these launches are
+        // bound by that in-place split: four pieces per wave against 48 MFMAs) -- the qkv / proj 1x1 convs of the attention blocks
+        if (p.Ncols % 256 == 0 && batch == 1 && ((p.M + 127) / 128) * (p.Ncols / 256) >= 256 && igemm_bn256())
+            return launch_cfg<float, true, 128, 256, 2, 4, 2, true, 16>(p, batch, st);
         return launch_cfg<float, true, 128, 128, 2, 2, 2, true, 16>(p, batch, st);
     }
     if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true>(p, batch, st);
@@ -2213,7 +2225,10 @@ static bool halo_bn256(const eod_conv_desc* d) {
         const char* e = getenv("EOD_HALO_BN256");
         on = (e && atoi(e) == 0) ? 0 : 1;
     }
-    return on && d->Cout % 256 == 0 && !d->upsample && halo_mfma_shape() == 16;
+    // only where it still fills the chip: one 8-wave workgroup occupies a CU, so fewer than 256 of them leave CUs idle (32 x 32 maps at
+    // batch 8: 128 workgroups, measured -20 %; the choice never changes a result: same K order, same MFMAs)
+    const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * (d->Cout / 256);
+    return on && d->Cout % 256 == 0 && !d->upsample && wgs >= 256 && halo_mfma_shape() == 16;
 }
 // ResBlock 1x1 skip conv fused behind the 3x3 K loop (conv3x3_halo_kernel<SKIP>; EOD_SKIP_FUSE=0: off, A/B)
 static bool conv_skip_geom_ok(const eod_conv_desc* d) {

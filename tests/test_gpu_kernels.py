@@ -33,6 +33,9 @@ CONV_CASES = [
     (1, 640, 32, 32, 256, 3, 1, 1, False),      # halo-patch kernel, 10 channel chunks
     (2, 128, 8, 8, 128, 3, 1, 1, True),         # upsample halo-patch kernel (6x10 input patch), 16x16 output
     (1, 96, 16, 24, 192, 3, 1, 1, True),        # upsample halo, K tail, N tail, non-square
+    (2, 96, 16, 16, 256, 1, 1, 0, False),       # 1x1 to 256 columns (fp32x3: the 8-wave 256-column form of the generic kernel), K tail
+    (1, 256, 24, 16, 768, 1, 1, 0, False),      # qkv-shaped 1x1: three 256-column tiles
+    (2, 128, 16, 32, 512, 3, 2, 1, False),      # stride 2 to 512 columns
 ]
 
 

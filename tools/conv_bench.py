@@ -36,10 +36,12 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--gn", action="store_true")
     ap.add_argument("--up4", action="store_true", help="upsample shapes through conv_up4_halo_kernel")
+    ap.add_argument("--batch", type=int, default=0, help="override the batch size of the shapes (default 16)")
     a = ap.parse_args()
     dev = "cuda:0"
     for name in a.shapes.split(","):
         N, H, W, Cin, Cout, k, stride, ups = SHAPES[name]
+        N = a.batch or N
         prog = Program(dev, a.prec)
         x = prog.act(N, H, W, Cin)
         x.t.normal_()
