@@ -82,6 +82,7 @@ struct IgemmP {
     const char* sx1;
     const char* b2;  // packed [Cout][SC0 + SC1] (the 1x1 weight; split mode: same scale as `b`)
     int SC0, SC1, skc0, skc1;
+    int n_base;  // halo kernel: first output column of this launch (a conv of 384 columns runs as a 256-column and a 128-column launch)
 };
 
 template <typename T> struct Mma;
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     int tile_m, tile_n;
     map_tile(p, tile_m, tile_n);
-    const int n0 = tile_n * BN;
+    const int n0 = p.n_base + tile_n * BN;
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode: ty0, tx0, n_first
 
     // ---- patch pieces of this wave: group gi = wave + 4*i, patch row = gi*8 + (lane>>3), slot = lane&7 ----
@@ -2081,7 +2082,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     p.kc0 = (p.C0 + BK - 1) / BK;
     p.kc1 = (p.C1 + BK - 1) / BK;
     p.KT = (p.kc0 + p.kc1) * 9;
-    p.tiles_n = (p.Ncols + BN - 1) / BN;
+    p.tiles_n = (p.Ncols - p.n_base + BN - 1) / BN;
     p.tw_log2 = 4;  // TH x 16 pixel patches
     p.th = TH;
     p.tiles_pw = p.Wo / 16;
@@ -2229,6 +2230,17 @@ static bool halo_bn256(const eod_conv_desc* d) {
     // batch 8: 128 workgroups, measured -20 %; the choice never changes a result: same K order, same MFMAs)
     const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * (d->Cout / 256);
     return on && d->Cout % 256 == 0 && !d->upsample && wgs >= 256 && halo_mfma_shape() == 16;
+}
+// 384, 640, ... columns: all but the last 128 on the 8-wave form, as a launch of its own (EOD_HALO_SPLIT_N=0: off)
+static bool halo_bn256_plus128(const eod_conv_desc* d) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EOD_HALO_SPLIT_N");
+        const char* f = getenv("EOD_HALO_BN256");
+        on = ((e && atoi(e) == 0) || (f && atoi(f) == 0)) ? 0 : 1;
+    }
+    const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * ((d->Cout - 128) / 256);
+    return on && d->Cout > 256 && d->Cout % 256 == 128 && !d->upsample && wgs >= 256 && halo_mfma_shape() == 16;
 }
 // ResBlock 1x1 skip conv fused behind the 3x3 K loop (conv3x3_halo_kernel<SKIP>; EOD_SKIP_FUSE=0: off, A/B)
 static bool conv_skip_geom_ok(const eod_conv_desc* d) {
@@ -2420,6 +2432,14 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         if (d->w_split && halo_bn256(d))
             return d->gn_scale_shift ? launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(p, st)
                                      : launch_halo<float, 256, 2, 4, false, 2, false, true, 16, true>(p, st);
+        if (d->w_split && d->gn_scale_shift && halo_bn256_plus128(d)) {  // 256 columns on the 8-wave form, the last 128 on the 4-wave one
+            IgemmP q = p;
+            q.Ncols = d->Cout - 128;
+            const int rc = launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(q, st);
+            if (rc != EOD_OK) return rc;
+            p.n_base = d->Cout - 128;
+            return launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st);
+        }
         if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st)
                                                  : launch_halo<float, 128, 2, 2, false, 2, false, true, 16, true>(p, st);
         if (d->gn_scale_shift && halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16, true>(p, st);
@@ -2434,6 +2454,14 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
             p.gn_silu = d->gn_silu;
             if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, true, true>(p, st);
             if (m16 && halo_bn256(d)) return launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(p, st);
+            if (m16 && halo_bn256_plus128(d)) {
+                IgemmP q = p;
+                q.Ncols = d->Cout - 128;
+                const int rc = launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(q, st);
+                if (rc != EOD_OK) return rc;
+                p.n_base = d->Cout - 128;
+                return launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st);
+            }
             return m16 ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true, true>(p, st);
         }
         if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, false, true>(p, st);

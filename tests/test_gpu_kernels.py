@@ -72,6 +72,8 @@ def test_conv_vs_torch(prec, case):
     (2, 96, 16, 16, 192, (40,)),          # channel tails in both phases (96 % 64, 40 % 32), N tail (192 % 128)
     (1, 256, 24, 16, 256, (72, 200)),     # two N tiles; tails in both skip sources
     (3, 160, 8, 16, 136, (320,)),         # one patch per image, Cout % 128 = 8
+    (8, 64, 64, 64, 384, (72,)),          # enough tiles for the two-launch form of 384 columns (256 on 8 waves + 128 on 4)
+    (8, 96, 32, 64, 512, (40, 24)),       # ... and for the 8-wave 256-column form (2 x 256)
 ])
 def test_conv3x3_with_fused_1x1_skip_vs_torch(prec, gn, case):
     """eod_conv_desc.skip_x (conv3x3_halo_kernel<SKIP>): y = conv3x3([GroupNorm+SiLU](h)) + conv1x1(cat(x...)) + both biases, the ResBlock
