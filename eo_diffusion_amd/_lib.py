@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("EOD_LIBRARY") or os.path.join(_HERE, "lib", "libeodif
 
 EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
- OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT, OP_DROPOUT) = range(1, 15)
+ OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT, OP_DROPOUT, OP_ACT_BOUND) = range(1, 16)
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -23,15 +23,15 @@ class ConvDesc(C.Structure):
                 ("Cout", i32), ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32), ("pad_tl", i32),
                 ("Ho", i32), ("Wo", i32), ("out_nchw_f32", i32), ("alpha", f32), ("stats", vp), ("stats_slots", i32),
                 ("gn_silu", i32), ("gn_scale_shift", vp), ("workspace", vp), ("workspace_bytes", i64),
-                ("w_tapmajor", i32), ("w_split", i32), ("w_scale", vp),
-                ("skip_x", vp), ("skip_x2", vp), ("skip_w", vp), ("skip_C0", i32), ("skip_C1", i32)]
+                ("w_tapmajor", i32), ("w_split", i32), ("w_scale", vp), ("a_bound", vp),
+                ("skip_x", vp), ("skip_x2", vp), ("skip_w", vp), ("skip_C0", i32), ("skip_C1", i32), ("skip_bound", vp)]
 
 
 class GemmDesc(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("bias", vp), ("res", vp), ("c", vp), ("lda", i64), ("ldb", i64), ("ldc", i64),
                 ("sa0", i64), ("sa1", i64), ("sb0", i64), ("sb1", i64), ("sc0", i64), ("sc1", i64), ("dtype", i32),
                 ("M", i32), ("N", i32), ("K", i32), ("nb0", i32), ("nb1", i32), ("bias_mode", i32), ("c_f32", i32),
-                ("alpha", f32), ("x3", i32)]
+                ("alpha", f32), ("x3", i32), ("a_bound", vp), ("b_bound", vp)]
 
 
 class TembDesc(C.Structure):
@@ -54,7 +54,7 @@ PACK_CHUNK = 4096
 
 
 class SmallDesc(C.Structure):
-    _fields_ = [("p", vp * 6), ("l", i64 * 4), ("i", i32 * 10), ("f", f32 * 2)]
+    _fields_ = [("p", vp * 8), ("l", i64 * 4), ("i", i32 * 10), ("f", f32 * 2)]
 
 
 class _OpU(C.Union):
@@ -96,7 +96,7 @@ SYMBOLS = {
     "eod_dropout": (i32, [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "eod_rowdot": (i32, [vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
     "eod_scale_f32": (i32, [vp, i64, f32, vp]),
-    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "eod_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
     "eod_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i32, i64, i32, vp]),
@@ -111,7 +111,8 @@ SYMBOLS = {
     "eod_nchw_to_nhwc": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "eod_nhwc_to_nchw": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "eod_gn_partial": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
-    "eod_gn_finalize": (i32, [vp, i32, i32, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, i64, vp, vp]),
+    "eod_gn_finalize": (i32, [vp, i32, i32, vp, i32, i32, i32, i64, i32, f32, vp, vp, vp, i64, vp, vp, vp, vp]),
+    "eod_act_bound": (i32, [vp, i32, i32, i64, vp, i32, i32, vp, i32, i32, vp, i32, vp]),
     "eod_conv_stats_slots": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_gn_fusable": (i32, [C.POINTER(ConvDesc)]),
     "eod_conv_split_ok": (i32, [C.POINTER(ConvDesc)]),

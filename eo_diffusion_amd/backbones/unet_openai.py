@@ -393,7 +393,7 @@ def _qkv_attention_standalone(mod, qkv):
     prog.ops[i_in].u.small.p[0] = xin.data_ptr()
     qo, ko, vo, hs = (0, Cc, 2 * Cc, d) if mod.new_order else (0, d, 2 * d, 3 * d)
     a = prog.act(bs, 1, length, Cc)
-    prog.attention_nat(a0.t, a.t, bs, length, Cc, nh, d, qo, ko, vo, hs)
+    prog.attention_nat(a0.t, a.t, bs, length, Cc, nh, d, qo, ko, vo, hs, qkv_bound=prog.bound_of([a0]))
     out = th.empty((bs, Cc, 1, length), dtype=th.float32, device=qkv.device)
     i_out = prog.to_nchw(a)
     prog.ops[i_out].u.small.p[1] = out.data_ptr()
@@ -476,10 +476,13 @@ class AttentionBlock(_Emitter):
             qo, ko, vo, hs = (0, Cc, 2 * Cc, d_nat) if self.attention.new_order else (0, d_nat, 2 * d_nat, 3 * d_nat)
             xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps)
             if prog.split:
+                # (stats=True: the epilogue's sums of squares give the bound table q / k / v are scaled by -- no pass over qkv)
                 qkv, _ = prog.conv(xn, prog.pack_conv(self.qkv.weight.view(3 * Cc, Cc, 1, 1)), prog.f32(self.qkv.bias), 3 * Cc,
-                                   ksize=1, stride=1, pad=0)
+                                   ksize=1, stride=1, pad=0, stats=True)
                 a = prog.act(N, x.H, x.W, Cc)
-                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs)
+                qkv_bound = prog.bound_of([qkv])
+                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs, qkv_bound=qkv_bound)
+                a.bound = qkv_bound  # a = convex combinations of v: |a| <= max|v| <= the bound of qkv
                 out, _ = prog.conv(a, prog.pack_conv(self.proj_out.weight.view(Cc, Cc, 1, 1)), prog.f32(self.proj_out.bias), Cc,
                                    ksize=1, stride=1, pad=0, res=x, stats=True)
                 return out
@@ -505,15 +508,29 @@ class AttentionBlock(_Emitter):
         bproj = prog.f32(self.proj_out.bias)
 
         xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps)
+        # fp32x3 (wide or odd head dims): the split-fp16 GEMMs scale each operand by ITS image's bound table (engine.gemm), so the
+        # projections whose rows stack every image along M run as 1x1 convs (per-image scale inside the conv kernel), and the batched
+        # GEMMs take the tables of qk (from the conv epilogue's statistics), xn (the GroupNorm finalize), vT (one max|x| pass).
+        x3 = prog.split and Cc % 8 == 0
+        qk_bound = vT_bound = None
         # q|k projection: [N*T][2*Cq]
-        qk = prog.empty((N * T, 2 * Cq))
-        prog.gemm(xn.t, wqk, qk, N * T, 2 * Cq, Cc, Cc, Cc, 2 * Cq, bias=bqk, bias_mode=1)
+        if x3:
+            w0 = th.cat([w2d.detach(), w2d.new_zeros(1, Cc)])  # index -1 -> a zero row (head padding), like bq0
+            w_qk = prog.own(w0[th.tensor(qk_rows, device=w0.device)].contiguous().view(2 * Cq, Cc, 1, 1))
+            qk_act, _ = prog.conv(xn, prog.pack_conv(w_qk), bqk, 2 * Cq, ksize=1, stride=1, pad=0, stats=True)
+            qk = qk_act.t.view(N * T, 2 * Cq)
+            qk_bound = prog.bound_of([qk_act])
+        else:
+            qk = prog.empty((N * T, 2 * Cq))
+            prog.gemm(xn.t, wqk, qk, N * T, 2 * Cq, Cc, Cc, Cc, 2 * Cq, bias=bqk, bias_mode=1)
         # v projection, produced TRANSPOSED ([N][C][ldt], keys contiguous) by swapping the GEMM operands:
         # vT[n][c][t] = sum_k Wv[c][k] * xn[n][t][k] + bv[c]
         ldt = round_up(T, prog.epc)
         vT = prog.empty((N, Cc, ldt), zero=True)
         prog.gemm(wv, xn.t, vT, Cc, T, Cc, Cc, Cc, ldt, bias=bv, bias_mode=2, nb0=N, sa=(0, 0), sb=(T * Cc, 0),
-                  sc=(Cc * ldt, 0))
+                  sc=(Cc * ldt, 0), a_bound=prog.weight_bound(wv, N) if x3 else None, b_bound=xn.bound if x3 else None)
+        if x3:
+            vT_bound = prog.bound_of_tensor(vT, N)
         a = prog.empty((N * T, Cc))
         fused = prog.precision == "fp16" and dpad <= 64 and d % 4 == 0 and os.environ.get("EOD_ATTN", "nat") != "gemm"
         if fused:
@@ -524,12 +541,18 @@ class AttentionBlock(_Emitter):
             # -> alpha = 1/sqrt(d); fp32 scores [N*nh][T][ldt], row softmax, then a = P.V
             S = prog.empty((N * nh, T, ldt), th.float32)
             prog.gemm(qk, qk, S, T, T, dpad, 2 * Cq, 2 * Cq, ldt, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
-                      sa=(T * 2 * Cq, dpad), sb=(T * 2 * Cq, dpad), sc=(nh * T * ldt, T * ldt), b_off=Cq)
+                      sa=(T * 2 * Cq, dpad), sb=(T * 2 * Cq, dpad), sc=(nh * T * ldt, T * ldt), b_off=Cq, a_bound=qk_bound, b_bound=qk_bound)
             P = prog.empty((N * nh, T, ldt))
             prog.softmax_rows(S, ldt, P, ldt, N * nh * T, T)
-            # a[n][t][h*d + j] = sum_s P[n,h][t][s] * vT[n][h*d + j][s]
+            # a[n][t][h*d + j] = sum_s P[n,h][t][s] * vT[n][h*d + j][s]     (P in [0, 1]: no table needed)
             prog.gemm(P, vT, a, T, d, ldt, ldt, ldt, Cc, nb0=N, nb1=nh, sa=(nh * T * ldt, T * ldt),
-                      sb=(Cc * ldt, d * ldt), sc=(T * Cc, d))
+                      sb=(Cc * ldt, d * ldt), sc=(T * Cc, d), a_bound=None, b_bound=vT_bound)
+        if x3:
+            a_act = Act(a.view(N, x.H, x.W, Cc), N, x.H, x.W, Cc)
+            a_act.bound = vT_bound  # rows of a = convex combinations of v rows
+            out, _ = prog.conv(a_act, prog.pack_conv(self.proj_out.weight.view(Cc, Cc, 1, 1)), bproj, Cc, ksize=1, stride=1, pad=0, res=x,
+                               stats=True)
+            return out
         out = prog.act(N, x.H, x.W, Cc)
         prog.gemm(a, wproj, out.t, N * T, Cc, Cc, Cc, Cc, Cc, bias=bproj, bias_mode=1, res=x.t)
         return out

@@ -2,8 +2,10 @@
 //     out[n, t, h*d + j] = sum_s softmax_s(q_t . k_s / sqrt(d)) v[s, j]          (QKVAttention(Legacy), unet_openai.py:465-515)
 // The reference materialises the T x T weights per head in fp32 (:476-480, 508-514); here they never leave the registers, and both
 // contractions run as three fp16 MFMAs per product on operands split into hi + lo halves (see the fp32x3 note in igemm.hip):
-//     S^T = K Q^T      : q, k (x16 each) split when they are staged; S = Kl.Qh + Kh.Ql + Kh.Qh
-//     O^T += V^T P^T   : P in [0, 1] split from the fp32 accumulator registers, v (x16) split when staged
+//     S^T = K Q^T      : q, k (x s each) split when they are staged; S = Kl.Qh + Kh.Ql + Kh.Qh
+//     O^T += V^T P^T   : P in [0, 1] split from the fp32 accumulator registers, v (x s) split when staged
+// s = the power-of-two operand scale of the IMAGE, derived from the bound table of the qkv tensor (common.h: |s x| < 2^15 for every
+// element, whatever the magnitude of q / k / v; no table: s = 16, the caller guarantees |x| < 4094).
 // Structure = attn_fwd_nat_kernel (attn_bwd.hip): a workgroup owns 128 queries (one wave = 32, lane & 31 = query) and walks 64-key
 // tiles; online softmax per lane in fp32; P^T is fed to the second product straight from the accumulators (permuted key order),
 // V^T comes from transposed LDS reads of the row-major V tile.  Differences forced by the 4-byte storage:
@@ -19,7 +21,7 @@
 typedef __fp16 fp16x4c __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 constexpr int AX_ROWB = 128;       // LDS row = 64 halves (head dim padded with zeros)
-constexpr float AX_SCALE = 16.0f;  // power-of-two operand scale: keeps the low halves' absolute resolution at 2^-29
+constexpr int AX_KMIN = -48;       // smallest operand scale 2^-48 (|q|, |k|, |v| up to 2^63: beyond that q.k overflows fp32 itself); keeps 1/s^2 normal
 
 __device__ __forceinline__ int ax_swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int ax_off(int row, int c) { return row * AX_ROWB + ((c ^ ax_swz(row)) << 4); }
@@ -59,7 +61,8 @@ struct AttnX3P {
     float* out;
     float* lse;
     int N, T, C, heads, d, q_off, k_off, v_off, hs;
-    float scale_log2;  // log2(e) / sqrt(d) / AX_SCALE^2
+    float scale_log2;  // log2(e) / sqrt(d)
+    const float* ab;   // bound table [N][EOD_AB] of qkv, or NULL
 };
 
 template <int DS, int DT>
@@ -76,6 +79,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
     const int q0 = blockIdx.x * 128;
     const long long ld = 3LL * p.C;
     const float* base = p.qkv + (long long)n * p.T * ld;
+    // operand scale of this image (wave-uniform), 1 / s, and the exponent's factor log2(e) / sqrt(d) / s^2 (exact: powers of two)
+    AbScale asc = {16.0f, 1.0f};
+    if (p.ab) asc = ab_scale_of(ab_wave_bound(p.ab, n), AX_KMIN);
+    const float AX_SCALE = asc.s, rscale = asc.inv * 0.0625f;
+    const float scale_log2 = p.scale_log2 * rscale * rscale;
 
     // ---- this lane's query row, split once: fragment ks = channels 16 ks + 8 lh .. + 7 ----
     half8 qh[DS], ql[DS];
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
                 mloc = fmaxf(mloc, s[mt][r]);  // raw scores: the (positive) scale is applied inside the exponent's fma below -- one rounding
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc * p.scale_log2);
+        const float m_new = fmaxf(m_run, mloc * scale_log2);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // raw v_exp_f32 (1 ulp; arguments <= 0, underflow to 0 is the intent)
         m_run = m_new;
         float lsum = 0.0f;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[mt][r], p.scale_log2, -m_new));
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[mt][r], scale_log2, -m_new));
                 s[mt][r] = e;
                 lsum += e;
             }
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
     for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
     if (nfull < nkt) tile(nkt - 1, std::true_type{});
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / (l_tot * AX_SCALE);
+    const float inv = rscale / l_tot;
     const int q = q0 + wave * 32 + lr;
     if (q < p.T) {
         if (p.lse && lh == 0) p.lse[((long long)n * p.heads + h) * p.T + q] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
@@ -246,13 +254,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
 }
 
 int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int d, int q_off, int k_off, int v_off,
-                             int head_stride, hipStream_t st) {
+                             int head_stride, const float* qkv_bound, hipStream_t st) {
     EOD_REQUIRE(q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && head_stride % 4 == 0 && eod_aligned16(qkv) && eod_aligned16(out) && C % 4 == 0,
                 "attention_fwd_nat (fp32): alignment of the head slices");
     AttnX3P p;
     p.qkv = qkv; p.out = out; p.lse = lse;
     p.N = N; p.T = T; p.C = C; p.heads = heads; p.d = d; p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.hs = head_stride;
-    p.scale_log2 = 1.4426950408889634f / sqrtf((float)d) / (AX_SCALE * AX_SCALE);
+    p.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
+    p.ab = qkv_bound;
     const dim3 grid((T + 127) / 128, N * heads);
     const size_t lds = (size_t)256 * AX_ROWB;
     const int ds = (d + 15) / 16;

@@ -56,6 +56,51 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
     return p;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ACTIVATION BOUND TABLES of the split-fp16 ("fp32x3") products.  An fp32 activation enters the fp16 matrix pipe as
+// hi + lo = fp16(s x) + fp16(s x - hi); s must keep |s x| inside the fp16 range for EVERY element of the tensor, whatever its
+// magnitude (the reference multiplies in IEEE fp32: unet_openai.py:352,262-264,227,609,414-422).  s is a power of two per IMAGE
+// (per image, not per batch: a sample's bits must not depend on what else is in the batch), derived ON THE DEVICE from a bound
+// table ab[N][EOD_AB]: EOD_AB non-negative floats per image whose maximum B_n bounds max|x| over the image (as the splitting
+// consumer sees it, i.e. behind a fused GroupNorm + SiLU when there is one).  Producers: eod_gn_finalize (raw and normalised
+// bounds of the tensors it takes statistics of, from the per-channel partial sums of squares: sqrt(sum over a slot's pixels of x^2)
+// >= max|x| over those pixels) and eod_act_bound (the same from conv-epilogue statistics, or a direct |x| maximum of a tensor).
+// Consumer rule: s = 2^k with B s in [2^14, 2^15)  ->  |s x| < 2^15 (no fp16 overflow).  B overestimates the true maximum by at most
+// sqrt(pixels per slot) (conv epilogues: 64 pixels -> 8x; eod_gn_partial: HW / 256 pixels), so max|s x| >= 2^9 in the worst case and
+// `lo` resolves 2^-25 absolute on the s x scale = 2^-34 of the image's largest element: a tensor of ANY magnitude gets the 2^-22
+// relative product accuracy of the fp32x3 note in igemm.hip (elements 2^12 and more below the image maximum keep an absolute error
+// of 2^-34 of that maximum -- invisible in any norm of the result).  Sums of squares overflow above sqrt(FLT_MAX) = 1.8e19: there B
+// is inf, s falls back to 2^-113 (finite results, no accuracy claim) -- the magnitude at which the GroupNorm variance of the
+// reference itself is inf; the direct |x| maximum of eod_act_bound has no such limit.
+// k is clamped to [EOD_AB_KMIN, EOD_AB_KMAX] so that s, 16/s and their products with the weight scale stay normal fp32 numbers.
+// ---------------------------------------------------------------------------------------------------------------------------
+#define EOD_AB 32
+#define EOD_AB_KMIN (-113)  // B = inf / NaN / 2^127: s = 2^-113 keeps every finite fp32 value inside the fp16 range
+#define EOD_AB_KMAX 60      // images whose largest element is below 2^-46 keep s = 2^60 (graceful: |s x| < 2^14)
+struct AbScale {
+    float s, inv;  // operand scale, and 16 / s (what the epilogue multiplies by on top of the weights' 1 / (16 s_w))
+};
+__device__ __forceinline__ AbScale ab_scale_of(float B, int kmin = EOD_AB_KMIN) {
+    const unsigned eb = (__float_as_uint(B) >> 23) & 0xffu;  // biased exponent of the (non-negative) bound; 255 = inf / NaN
+    int k = 141 - (int)eb;                                   // 14 - floor(log2 B)
+    k = k < kmin ? kmin : (k > EOD_AB_KMAX ? EOD_AB_KMAX : k);
+    AbScale r;
+    r.s = __uint_as_float((unsigned)(k + 127) << 23);
+    r.inv = __uint_as_float((unsigned)(4 - k + 127) << 23);
+    return r;
+}
+// maximum of image n's EOD_AB table entries, wave-uniform (every lane of the wave must call); NaN entries count as +inf
+__device__ __forceinline__ float ab_wave_bound(const float* __restrict__ ab, long long n) {
+    float b = 0.0f;
+    if ((threadIdx.x & 63) < EOD_AB) {
+        b = ab[n * EOD_AB + (threadIdx.x & 63)];
+        b = (b == b) ? b : __uint_as_float(0x7f800000u);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o));
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b)));
+}
+
 // SiLU (nn.SiLU, unet_openai.py:314,330,338): precise form for the fp32 parity mode, fast form
 // (v_exp_f32 + v_rcp_f32) for the fp16 mode where the result is rounded to 11 bits anyway.
 template <bool FAST> __device__ __forceinline__ float silu_f(float v) {

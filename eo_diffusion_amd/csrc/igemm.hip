@@ -83,6 +83,13 @@ struct IgemmP {
     const char* b2;  // packed [Cout][SC0 + SC1] (the 1x1 weight; split mode: same scale as `b`)
     int SC0, SC1, skc0, skc1;
     int n_base;  // halo kernel: first output column of this launch (a conv of 384 columns runs as a 256-column and a 128-column launch)
+    // split-fp16 products: bound tables (common.h) of the activation operands -> a power-of-two operand scale per image, derived in
+    // the kernel.  conv: a_bound [N][32] of the conv input, skip_bound of the fused skip conv's input; gemm (x3): a_bound / b_bound
+    // [nb0][32] of the two operands.  NULL = fixed scale 16 (the caller guarantees |x| < 4094).
+    const float* a_bound;
+    const float* skip_bound;
+    const float* b_bound;
+    int ab_tab_off;  // generic kernel: byte offset in LDS of the per-image {s, 16/s} table of a tile that straddles images
 };
 
 template <typename T> struct Mma;
@@ -109,8 +116,12 @@ template <> struct Mma<float> {
 // Scaling (exact powers of two, undone by alpha in the epilogue):
 //   * weights: per tensor, s = 2^k with max|w|*s in (2^12, 2^13] (pack time, device side) -> lo_w is a normal fp16 for every weight
 //     within 2^-17 of the largest one;
-//   * activations: A_SCALE = 16 -> lo_a is exact to 2^-29 absolute; |x| must stay below 65504/16 = 4094 (GroupNorm'd inputs always
-//     do; beyond that the result is inf/NaN -- loud --, and the exact "fp32" mode remains available).
+//   * activations: per IMAGE, s_a = 2^k derived in the kernel from the bound table of the tensor (common.h: eod_gn_finalize /
+//     eod_act_bound write an upper bound B of max|x| per image; B s_a in [2^14, 2^15)), so every element of a tensor of any magnitude
+//     stays inside the fp16 range and lo_a resolves 2^-34 of the image's largest element or better.  This holds for EVERY consumer,
+//     including the ones whose input is not behind a GroupNorm: the first conv on x_t, the (fused) 1x1 skip convs over the raw block
+//     input, Downsample / Upsample convs, proj_out, q / k / v.  Without a table (NULL) the scale is the fixed 16 of round 2 and the
+//     caller guarantees |x| < 65504/16 = 4094.
 // LDS image: operands stay 4 bytes per element.  Each pair of 16-byte chunks (8 consecutive k) is rewritten IN PLACE as
 // [8 x hi | 8 x lo]: weights are packed that way in HBM, activation patches are converted once per staged element by the wave
 // that DMA'd them (lanes l and l^1 hold the two chunks of a pair and swap halves through DPP).  A K-step of 128 bytes = 32 k =
@@ -124,7 +135,7 @@ template <> struct Mma<float> {
 // VGPRs), reading the NEXT tap's patch fragments at the end of a tap, across the wait + barrier: +-0.5 %.  PMC of the split kernel (tools/pmc_stall.txt): waves are
 // 32 % issuing, 44 % stalled on issue (the matrix pipe shared by two waves), 24 % parked at s_waitcnt / s_barrier.
 // ---------------------------------------------------------------------------------------------------------------------------
-#define EOD_SPLIT_ASCALE 16.0f
+#define EOD_SPLIT_ASCALE 16.0f  // operand scale without a bound table
 __device__ __forceinline__ void mma_f16(const i32x4& a, const i32x4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
@@ -246,10 +257,12 @@ template <int MS> struct AccLayout {
     static __device__ __forceinline__ int col(int lane) { return MS == 32 ? (lane & 31) : (lane & 15); }
 };
 
+// rowtab (generic split kernel, tiles that straddle images): LDS table of {s, 16/s} per image of the tile; a row's values are
+// multiplied by ITS image's 16/s on top of p.alpha
 template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, bool OUTF32, int MS = 32>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& g,
                                                typename AccLayout<MS>::vec (&acc)[BM / WAVES_M / MS][BN / WAVES_N / MS], char* smem, int wave,
-                                               int lane, int n0) {
+                                               int lane, int n0, const float* rowtab = nullptr, int rowtab_n = 0) {
     constexpr int ES = sizeof(T);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / MS, TN = WN / MS, R = AccLayout<MS>::R;
@@ -294,10 +307,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                 int nrel, ho, wo;
                 if (!decode_row<BM>(p, g, row, nrel, ho, wo)) continue;
                 const int n = g.n_first + nrel;
+                const float ralpha = rowtab ? p.alpha * rowtab[2 * min(nrel, rowtab_n - 1) + 1] : p.alpha;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (!cok[j]) continue;
-                    float v = acc[i][j][r] * p.alpha + bcol[j];
+                    float v = acc[i][j][r] * ralpha + bcol[j];
                     if (cb_per_row) v += p.cbias[(long long)n * p.cbias_stride + col[j]];
                     reinterpret_cast<float*>(p.y)[((long long)n * p.Cout + col[j]) * p.HoWo + (long long)ho * p.Wo + wo] = v;
                 }
@@ -363,7 +377,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
             float cb[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) cb[j] = 0.0f;
+            float ralpha = p.alpha;
             if constexpr (CONV) {
+                if (rowtab) {
+                    int nrel, ho, wo;
+                    decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo);
+                    ralpha = p.alpha * rowtab[2 * min(nrel, rowtab_n - 1) + 1];
+                }
                 if (cb_per_row) {
                     int nrel, ho, wo;
                     decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo);
@@ -382,7 +402,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                 }
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * MS + lr] = acc[i][j][r] * p.alpha + bcol[j] + cb[j];
+            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * MS + lr] = acc[i][j][r] * ralpha + bcol[j] + cb[j];
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
     __builtin_amdgcn_wave_barrier();
@@ -499,11 +519,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     if constexpr (CONV) {
         if (p.splitk > 1) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;
     }
+    // split-fp16 product: operand scales of the activation operand(s) from their bound tables (common.h).  conv: one scale per image;
+    // a tile normally lies inside one image (always in patch mode) -> wave-uniform as0; a tile that straddles images (maps smaller
+    // than or not a multiple of the 128-row tile) keeps a table of its images' scales in LDS: rows are scaled and un-scaled one by one.
+    AbScale as0 = {EOD_SPLIT_ASCALE, 1.0f}, bs0 = {EOD_SPLIT_ASCALE, 1.0f};
+    const float* rowtab = nullptr;
+    int rowtab_n = 0;
     if constexpr (SPLIT) {
         if constexpr (CONV) {
-            if (p.splitk <= 1) pe.alpha = p.alpha * p.w_scale[1];  // (split-K: raw partial tiles, the reduce pass rescales)
-        } else {
-            pe.alpha = p.alpha * (1.0f / (EOD_SPLIT_ASCALE * EOD_SPLIT_ASCALE));  // GEMM: both operands are activations, split in LDS
+            if (p.a_bound) {
+                if (p.tw_log2 >= 0 || g.rem_first + BM <= p.HWd) {
+                    as0 = ab_scale_of(ab_wave_bound(p.a_bound, n_first));
+                } else {
+                    float* tab = reinterpret_cast<float*>(smem + p.ab_tab_off);
+                    rowtab_n = min(p.N - n_first, (g.rem_first + BM - 1) / p.HWd + 1);
+                    for (int j = wave; j < rowtab_n; j += NW) {
+                        const AbScale a = ab_scale_of(ab_wave_bound(p.a_bound, n_first + j));
+                        if (lane == 0) {
+                            tab[2 * j] = a.s;
+                            tab[2 * j + 1] = a.inv;
+                        }
+                    }
+                    __syncthreads();  // (nothing is in flight yet)
+                    rowtab = tab;
+                }
+            }
+            // split-K: the partial tiles are stored already un-scaled (exact: powers of two), the reduce pass only sums them
+            pe.alpha = p.alpha * p.w_scale[1] * (rowtab ? 1.0f : as0.inv);
+        } else {  // GEMM: both operands are activations, split in LDS; image = outer batch index
+            const int b0 = (int)blockIdx.y / p.nb1;
+            if (p.a_bound) as0 = ab_scale_of(ab_wave_bound(p.a_bound, b0));
+            if (p.b_bound) bs0 = ab_scale_of(ab_wave_bound(p.b_bound, b0));
+            pe.alpha = p.alpha * (as0.inv * 0.0625f) * (bs0.inv * 0.0625f);
         }
     }
     const long long offA = g.offA, offB = g.offB;
@@ -516,6 +563,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     unsigned a_v0[LA], a_v1[LA], a_mask[LA];
     int a_bh[LA], a_bw[LA], a_nh[LA];   // upsample only
     int a_chunk[LA];
+    float a_s[LA];                      // split mode: operand scale of this lane's row (its image's)
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int row = (wave + NW * i) * 8 + srow;
@@ -523,9 +571,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
         a_v0[i] = a_v1[i] = 0;
         a_mask[i] = 0;
         a_bh[i] = a_bw[i] = a_nh[i] = 0;
+        a_s[i] = as0.s;
         if constexpr (CONV) {
             int nrel, ho, wo;
             const bool ok = decode_row<BM>(p, g, row, nrel, ho, wo);
+            if constexpr (SPLIT) {
+                if (rowtab) a_s[i] = rowtab[2 * min(nrel, rowtab_n - 1)];
+            }
             const int bh = ho * p.stride - p.pad - p.pad_tl, bw = wo * p.stride - p.pad - p.pad_tl;
             a_bh[i] = bh;
             a_bw[i] = bw;
@@ -731,7 +783,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                 char* ptr = sa + (wave + NW * i) * 1024 + lane * 16;
                 f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+                for (int e = 0; e < 4; ++e) f[e] *= a_s[i];
                 *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (a_chunk[i] & 1) != 0);
             }
             if constexpr (!CONV) {  // GEMM (attention with wide heads): the B operand is an fp32 activation too
@@ -740,7 +792,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
                     char* ptr = sa + STAGE_A + (wave + NW * i) * 1024 + lane * 16;
                     f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+                    for (int e = 0; e < 4; ++e) f[e] *= bs0.s;
                     *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (b_chunk[i] & 1) != 0);
                 }
             }
@@ -860,7 +912,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     __builtin_amdgcn_s_barrier();        // ... and so are everybody else's: the ring can be reused by the epilogue
 
     if constexpr (sizeof(T) == 4) {
-        igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0);
+        igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, rowtab, rowtab_n);
     } else {
         if (CONV ? p.splitk > 1 : p.c_f32 != 0)
             igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0);
@@ -932,6 +984,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     map_tile(p, tile_m, tile_n);
     const int n0 = p.n_base + tile_n * BN;
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode: ty0, tx0, n_first
+    // split-fp16 product: power-of-two operand scale of this tile's image from the bound table(s) (wave-uniform, common.h); the fused
+    // skip conv shares the accumulators, so the launch runs on the smaller of the two tensors' scales
+    AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};
+    if constexpr (SPLIT) {
+        if (p.a_bound) asc = ab_scale_of(ab_wave_bound(p.a_bound, g.n_first));
+        if constexpr (SKIP) {
+            if (p.skip_bound) {
+                const AbScale k = ab_scale_of(ab_wave_bound(p.skip_bound, g.n_first));
+                if (k.s < asc.s) asc = k;
+            }
+        }
+    }
 
     // ---- patch pieces of this wave: group gi = wave + 4*i, patch row = gi*8 + (lane>>3), slot = lane&7 ----
     const int srow = lane >> 3, sslot = lane & 7;
@@ -1050,7 +1114,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
             // fp32 chunk -> its half of the pair's [8 x hi | 8 x lo] image (zeros stay zeros); both lanes of a pair take part
             f32x4 f = __builtin_bit_cast(f32x4, outv);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+            for (int e = 0; e < 4; ++e) f[e] *= asc.s;
             *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pc & 1) != 0);
         } else {
             if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
@@ -1374,7 +1438,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
                     char* ptr = stg + (wave + NW * i) * 1024 + lane * 16;
                     f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+                    for (int e = 0; e < 4; ++e) f[e] *= asc.s;
                     *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (bchunk0 & 1) != 0);
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1430,7 +1494,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
     if constexpr (SPLIT) {
         IgemmP pe = p;
-        pe.alpha = p.alpha * p.w_scale[1];  // undo the weight and activation scales (exact powers of two)
+        pe.alpha = p.alpha * p.w_scale[1] * asc.inv;  // undo the weight and activation scales (exact powers of two)
         igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0);
     } else {
         igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0);
@@ -1482,6 +1546,10 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     const int cls = BWD ? 0 : tile_nn / tpc, n0 = (tile_nn - cls * tpc) * BN;
     const int par_y = cls >> 1, par_x = cls & 1;        // (forward: the workgroup's class; backward: classes rotate inside the K loop)
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode on the STORED map: ty0, tx0, n_first
+    AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};             // split-fp16 product: operand scale of this tile's image (see conv3x3_halo_kernel)
+    if constexpr (SPLIT) {
+        if (p.a_bound) asc = ab_scale_of(ab_wave_bound(p.a_bound, g.n_first));
+    }
 
     const int srow = lane >> 3, sslot = lane & 7;
     unsigned ppix[LAH];
@@ -1534,7 +1602,7 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
         f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] *= EOD_SPLIT_ASCALE;
+        for (int e = 0; e < 4; ++e) f[e] *= asc.s;
         *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk_of(i) & 1) != 0);
     };
     // tap slot of K-step s (a = s >> 1, b = s & 1) of the 3x3 frame: forward (par_y + a, par_x + b); backward (1 - p + a, 1 - q + b)
@@ -1702,7 +1770,7 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         pe.tiles_per_image = p.tiles_pi * 4;  // statistics slots: (tile of the stored map, class)
         ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
     }
-    if constexpr (SPLIT) pe.alpha = p.alpha * p.w_scale[1];
+    if constexpr (SPLIT) pe.alpha = p.alpha * p.w_scale[1] * asc.inv;
     igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0);
 }
 
@@ -1764,6 +1832,10 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
     int tile_m, tile_n;
     map_tile(p, tile_m, tile_n);
     const TileGeom g = make_geom<true, BM>(p, tile_m);
+    AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};  // split-fp16 product: operand scale of this tile's image (see conv3x3_halo_kernel)
+    if constexpr (SPLIT) {
+        if (p.a_bound) asc = ab_scale_of(ab_wave_bound(p.a_bound, g.n_first));
+    }
 
     const int srow = lane >> 3, sslot = lane & 7;
     unsigned ppix[LAH];
@@ -1817,7 +1889,7 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
                 for (int e = 0; e < 4; ++e) {
                     float v = f[e] * sc[e] + sh[e];
                     if (p.gn_silu) v = silu_f<true>(v);
-                    o[e] = ok ? v * EOD_SPLIT_ASCALE : 0.0f;  // conv zero padding / masked channel tail stay zero
+                    o[e] = ok ? v * asc.s : 0.0f;  // conv zero padding / masked channel tail stay zero
                 }
                 *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(o, (pc & 1) != 0);
             } else {
@@ -1925,7 +1997,7 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
     __builtin_amdgcn_s_waitcnt(0x0f70);  // the out-of-range pieces of the last two iterations: nothing in flight at exit
     // ---- store: rows of D = output channels 4 lh + r, column = pixel lr of tile row 2 wave + i: 64-byte runs per plane row ----
     {
-        const float alpha = SPLIT ? p.alpha * p.w_scale[1] : p.alpha;
+        const float alpha = SPLIT ? p.alpha * p.w_scale[1] * asc.inv : p.alpha;
         float* yb = reinterpret_cast<float*>(p.y) + (long long)g.n_first * p.Cout * p.HoWo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2015,7 +2087,12 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, NW = WAVES_M * WAVES_N;
     const size_t ring = STAGES * (size_t)(BM + BN) * 128;
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
-    const size_t lds = ring > epi ? ring : epi;
+    size_t lds = ring > epi ? ring : epi;
+    if (SPLIT && CONV) {  // per-image operand scales of a tile that straddles images: at most BM + 1 images of {s, 16/s}
+        lds = (lds + 15) & ~(size_t)15;
+        p.ab_tab_off = (int)lds;
+        lds += (BM + 2) * 2 * sizeof(float);
+    }
     auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES, SPLIT, MS>;
     static bool attr_done = false;  // >64 KiB dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_done) {
@@ -2402,6 +2479,8 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     EOD_REQUIRE(!d->w_split || (conv_split_ok(d, Ho, Wo, p.force_cfg) && d->w_scale),
                 "conv: w_split needs a geometry for which eod_conv_split_ok(d) == 1 and the w_scale of eod_pack_conv_weight_split");
     p.w_scale = d->w_split ? d->w_scale : nullptr;
+    p.a_bound = d->w_split ? d->a_bound : nullptr;
+    p.skip_bound = (d->w_split && d->skip_x) ? d->skip_bound : nullptr;
     if (d->upsample == 3) {
         EOD_REQUIRE(conv_up4_ok(d), "conv: upsample = 3 (parity-class form of the nearest-2x conv) needs a geometry for which eod_conv_up4_ok(d) == 1");
         return d->dtype == EOD_F16 ? launch_up4<half_t, false>(p, st) : launch_up4<float, true>(p, st);
@@ -2521,7 +2600,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         if (d->dtype == EOD_F16)
             hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y, (const float*)nullptr);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, d->w_split ? d->w_scale : (const float*)nullptr);
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, (const float*)nullptr);  // (split-fp16 partial tiles arrive un-scaled)
         EOD_CHECK_LAUNCH("splitk_reduce");
         return EOD_OK;
     }
@@ -2585,6 +2664,8 @@ extern "C" int eod_gemm_nt(const eod_gemm_desc* d, void* stream) {
     const int batch = d->nb0 * d->nb1;
     if (d->x3) {  // fp32 operands, every product as three fp16 MFMAs on operands split in LDS (the fp32x3 mode's attention GEMMs)
         EOD_REQUIRE(d->dtype == EOD_F32 && d->K % 8 == 0 && halo_mfma_shape() == 16, "gemm: x3 needs fp32 operands and K %% 8 == 0");
+        p.a_bound = d->a_bound;
+        p.b_bound = d->b_bound;
         if (p.Ncols <= 32) return launch_cfg<float, false, 128, 32, 4, 1, 2, true, 16>(p, batch, st);
         if (p.Ncols <= 64) return launch_cfg<float, false, 128, 64, 4, 1, 2, true, 16>(p, batch, st);
         return launch_cfg<float, false, 128, 128, 2, 2, 2, true, 16>(p, batch, st);

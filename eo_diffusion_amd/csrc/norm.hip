@@ -87,11 +87,18 @@ extern "C" int eod_gn_partial(const void* x, int dtype, int N, int HW, int C, fl
 //     y = x*scale + shift,  scale = rstd*gamma,  shift = beta - mean*rstd*gamma
 // FiLM (use_scale_shift_norm, unet_openai.py:377-381): y' = y*(1+s) + t with film[n] = [s(0..C) | t(0..C)].
 // ---------------------------------------------------------------------------------------------
+// Bound tables (common.h, EOD_AB = 32 entries per image; groups <= 32): entry g of image n receives
+//   ab_raw : sqrt(max over the group's (slot, channel) partial sums of squares)  >= max|x| over the group's channels
+//   ab_norm: max_c|scale_c| * that + max_c|shift_c|                                >= max|x*scale + shift| (and of its SiLU)
+// for the consumers that split the raw tensor (skip / resampling convs) and the normalised one (the conv behind the GroupNorm).
 __global__ void gn_finalize_kernel(const float* __restrict__ part0, int P0, int C0, const float* __restrict__ part1, int P1,
                                    int C1, long long HW, int groups, float eps, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, const float* __restrict__ film, long long film_stride,
-                                   float* __restrict__ ss) {
+                                   float* __restrict__ ss, float* __restrict__ ab_raw, float* __restrict__ ab_norm) {
     __shared__ double rs[256], rq[256];
+    __shared__ float rm[256];
+    float qmax = 0.0f;  // largest partial sum of squares of the group (a NaN sum is dropped by fmaxf, but it also poisons q and with it
+                        // every scale / shift below: NaN in, NaN out)
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int Ctot = C0 + C1;
     const int cpg = Ctot / groups;
@@ -117,6 +124,7 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part0, int P0, int 
             for (int u = 0; u < 4; ++u) {
                 s += (double)v[u].x;
                 q += (double)v[u].y;
+                qmax = fmaxf(qmax, v[u].y);
             }
         }
         for (; i < total; i += 256) {
@@ -124,17 +132,20 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part0, int P0, int 
             const float2 v = base[(long long)p * Cs + first + (i - p * nc)];
             s += (double)v.x;
             q += (double)v.y;
+            qmax = fmaxf(qmax, v.y);
         }
     };
     if (n0c > 0) accumulate(part0, P0, C0, a0, n0c);
     if (n1c > 0) accumulate(part1, P1, C1, max(c0, C0) - C0, n1c);  // (first channel inside source 1)
     rs[tid] = s;
     rq[tid] = q;
+    rm[tid] = qmax;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) {
             rs[tid] += rs[tid + o];
             rq[tid] += rq[tid + o];
+            rm[tid] = fmaxf(rm[tid], rm[tid + o]);
         }
         __syncthreads();
     }
@@ -144,6 +155,8 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part0, int P0, int 
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float meanf = (float)mean;
+    const float xmax = sqrtf(rm[0]);  // (a sum of squares that overflowed gives inf: the consumers then fall back to the smallest scale)
+    float scmax = 0.0f, shmax = 0.0f;
     for (int c = c0 + tid; c < c0 + cpg; c += 256) {
         float sc = rstd * gamma[c];
         float sh = beta[c] - meanf * sc;
@@ -155,18 +168,117 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part0, int P0, int 
         }
         ss[((long long)n * Ctot + c) * 2 + 0] = sc;
         ss[((long long)n * Ctot + c) * 2 + 1] = sh;
+        scmax = fmaxf(scmax, fabsf(sc));
+        shmax = fmaxf(shmax, fabsf(sh));
+    }
+    if (ab_raw || ab_norm) {
+        __syncthreads();  // (rm[0] has been read by everybody)
+        rm[tid] = scmax;
+        reinterpret_cast<float*>(rs)[tid] = shmax;
+        __syncthreads();
+        if (tid == 0) {
+            const int nt = cpg < 256 ? cpg : 256;
+            for (int i = 1; i < nt; ++i) {
+                scmax = fmaxf(scmax, rm[i]);
+                shmax = fmaxf(shmax, reinterpret_cast<float*>(rs)[i]);
+            }
+            if (ab_raw) ab_raw[(long long)n * EOD_AB + g] = xmax;
+            if (ab_norm) ab_norm[(long long)n * EOD_AB + g] = scmax * xmax + shmax;
+        }
+        // entries [groups, EOD_AB) of the tables are never written: the caller zero-fills them once (groups < 32 only)
     }
 }
 
 extern "C" int eod_gn_finalize(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW,
                                int groups, float eps, const float* gamma, const float* beta, const float* film,
-                               int64_t film_stride, float* scale_shift, void* stream) {
+                               int64_t film_stride, float* scale_shift, float* ab_raw, float* ab_norm, void* stream) {
     EOD_REQUIRE(part0 && gamma && beta && scale_shift, "gn_finalize: null pointer");
     EOD_REQUIRE(N > 0 && P0 > 0 && C0 > 0 && C1 >= 0 && (C1 == 0 || (part1 && P1 > 0)) && groups > 0 && (C0 + C1) % groups == 0,
                 "gn_finalize: C0=%d C1=%d groups=%d", C0, C1, groups);
+    EOD_REQUIRE((!ab_raw && !ab_norm) || groups <= EOD_AB, "gn_finalize: bound tables hold %d entries per image, got %d groups", EOD_AB, groups);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, part0, P0, C0, part1, P1, C1,
-                       (long long)HW, groups, eps, gamma, beta, film, (long long)film_stride, scale_shift);
+                       (long long)HW, groups, eps, gamma, beta, film, (long long)film_stride, scale_shift, ab_raw, ab_norm);
     EOD_CHECK_LAUNCH("gn_finalize");
+    return EOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// eod_act_bound: the bound table ab[N][EOD_AB] (common.h) of a tensor that no GroupNorm takes statistics of right before its
+// split-fp16 consumer (the inputs of Downsample.op / Upsample.conv unet_openai.py:262-264,227, the image in front of the first conv
+// :609, q / k / v of the attention :476-480).  grid (EOD_AB, N): block (j, n) covers the j-th 1/32 of image n's data.
+//   parts mode : from the {sum, sumsq} slots a conv epilogue / eod_gn_partial wrote ([N][P][C][2], one or two concat sources):
+//                entry = sqrt(max sumsq) -- an upper bound of max|x| that costs no pass over the tensor
+//   direct mode: entry = max|x| over the image's elements, exact for every finite fp32 value (NaN / inf -> inf)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bound_parts_kernel(const float* __restrict__ part0, long long L0, const float* __restrict__ part1,
+                                                              long long L1, float* __restrict__ ab) {
+    __shared__ float red[4];
+    const int j = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    float m = 0.0f;
+    auto scan = [&](const float* __restrict__ part, long long L) {  // L = P * C {sum, sumsq} pairs per image
+        const float2* base = reinterpret_cast<const float2*>(part) + (long long)n * L;
+        const long long i0 = L * j / EOD_AB, i1 = L * (j + 1) / EOD_AB;
+        for (long long i = i0 + tid; i < i1; i += 256) {
+            const float q = base[i].y;
+            m = fmaxf(m, (q == q) ? q : __uint_as_float(0x7f800000u));
+        }
+    };
+    scan(part0, L0);
+    if (part1) scan(part1, L1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) ab[(long long)n * EOD_AB + j] = sqrtf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bound_direct_kernel(const T* __restrict__ x, long long per_image, float* __restrict__ ab, int accumulate) {
+    constexpr int EPC = dt<T>::epc;
+    __shared__ float red[4];
+    const int j = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const long long chunks = per_image / EPC;  // (per_image % EPC == 0: checked by the launcher)
+    const long long i0 = chunks * j / EOD_AB, i1 = chunks * (j + 1) / EOD_AB;
+    const i32x4* base = reinterpret_cast<const i32x4*>(x + (long long)n * per_image);
+    unsigned mb = 0;  // max over |x| as an ordered bit pattern: for non-negative floats the integer order IS the float order, and NaN sorts above inf
+    for (long long i = i0 + tid; i < i1; i += 256) {
+        const i32x4 raw = base[i];
+        if constexpr (EPC == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mb = max(mb, (unsigned)raw[e] & 0x7fffffffu);
+        } else {
+            const half8 h = __builtin_bit_cast(half8, raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mb = max(mb, __float_as_uint((float)h[e]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
+    if ((tid & 63) == 0) red[tid >> 6] = __uint_as_float(mb);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned r = accumulate ? __float_as_uint(ab[(long long)n * EOD_AB + j]) : 0u;  // (a second source of a virtual concat)
+        for (int w = 0; w < 4; ++w) r = max(r, __float_as_uint(red[w]));
+        ab[(long long)n * EOD_AB + j] = __uint_as_float(r > 0x7f800000u ? 0x7f800000u : r);  // NaN -> inf
+    }
+}
+
+extern "C" int eod_act_bound(const void* x, int dtype, int N, int64_t per_image, const float* part0, int P0, int C0, const float* part1,
+                             int P1, int C1, float* ab, int accumulate, void* stream) {
+    EOD_REQUIRE(ab && N > 0 && N <= 65535, "act_bound: bad args");
+    const dim3 grid(EOD_AB, N), block(256);
+    if (part0) {
+        EOD_REQUIRE(P0 > 0 && C0 > 0 && (!part1 || (P1 > 0 && C1 > 0)) && !accumulate, "act_bound: bad partial-sum geometry");
+        hipLaunchKernelGGL(act_bound_parts_kernel, grid, block, 0, (hipStream_t)stream, part0, (long long)P0 * C0, part1, (long long)P1 * C1, ab);
+    } else {
+        EOD_REQUIRE(x && per_image > 0 && (dtype == EOD_F32 || dtype == EOD_F16), "act_bound: bad args");
+        EOD_REQUIRE(per_image % (16 / eod_esize(dtype)) == 0 && eod_aligned16(x), "act_bound: 16-byte chunks per image required");
+        if (dtype == EOD_F16)
+            hipLaunchKernelGGL(act_bound_direct_kernel<half_t>, grid, block, 0, (hipStream_t)stream, (const half_t*)x, (long long)per_image, ab, accumulate);
+        else
+            hipLaunchKernelGGL(act_bound_direct_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, (long long)per_image, ab, accumulate);
+    }
+    EOD_CHECK_LAUNCH("act_bound");
     return EOD_OK;
 }
 

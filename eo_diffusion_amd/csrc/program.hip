@@ -7,8 +7,10 @@
 //
 // eod_small_desc field use per op kind:
 //   GN_PARTIAL : p[0]=x p[1]=part            i = {dtype, N, HW, C, P, Ctot, coff}
-//   GN_FINALIZE: p[0]=part0 p[1]=gamma p[2]=beta p[3]=film p[4]=scale_shift p[5]=part1   l = {HW, film_stride}
+//   GN_FINALIZE: p[0]=part0 p[1]=gamma p[2]=beta p[3]=film p[4]=scale_shift p[5]=part1 p[6]=ab_raw p[7]=ab_norm   l = {HW, film_stride}
 //                i = {N, P0, C0, groups, P1, C1}    f = {eps}
+//   ACT_BOUND  : p[0]=x p[1]=part0 p[2]=part1 p[3]=ab     l = {per_image}   i = {dtype, N, P0, C0, P1, C1, accumulate}
+//   ATTN_NAT   : p[0]=qkv p[1]=out p[2]=lse p[3]=qkv_bound   i = {dtype, N, T, C, heads, d, q_off, k_off, v_off, head_stride}
 //   GN_APPLY   : p[0]=x p[1]=scale_shift p[2]=y   i = {dtype, N, HW, C, Ctot, coff, silu}
 //   SOFTMAX    : p[0]=s p[1]=p               l = {lds, ldp, rows}   i = {dtype, n}
 //   TO_NHWC    : p[0]=src0 p[1]=src1 p[2]=dst     i = {C0, C1, dtype, N, H, W, c_pad}
@@ -122,7 +124,11 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
             case EOD_OP_ATTN: rc = eod_attention_fwd(&o.u.attn, stream); break;
             case EOD_OP_ATTN_NAT:
                 rc = eod_attention_fwd_nat(s.p[0], (void*)s.p[1], (float*)s.p[2], s.i[0], s.i[1], s.i[2], s.i[3], s.i[4], s.i[5], s.i[6], s.i[7], s.i[8],
-                                           s.i[9], stream);
+                                           s.i[9], (const float*)s.p[3], stream);
+                break;
+            case EOD_OP_ACT_BOUND:
+                rc = eod_act_bound(s.p[0], s.i[0], s.i[1], s.l[0], (const float*)s.p[1], s.i[2], s.i[3], (const float*)s.p[2], s.i[4], s.i[5],
+                                   (float*)s.p[3], s.i[6], stream);
                 break;
             case EOD_OP_DROPOUT:
                 rc = eod_dropout(s.p[0], (void*)s.p[1], s.i[0], s.l[0], s.f[0], (uint64_t)s.l[1], (uint32_t)s.i[1], (uint32_t)s.i[2], stream);
@@ -137,7 +143,7 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
             case EOD_OP_GN_FINALIZE:
                 rc = eod_gn_finalize((const float*)s.p[0], s.i[1], s.i[2], (const float*)s.p[5], s.i[4], s.i[5], s.i[0], s.l[0],
                                      s.i[3], s.f[0], (const float*)s.p[1], (const float*)s.p[2], (const float*)s.p[3], s.l[1],
-                                     (float*)s.p[4], stream);
+                                     (float*)s.p[4], (float*)s.p[6], (float*)s.p[7], stream);
                 break;
             case EOD_OP_GN_APPLY:
                 rc = eod_gn_apply(s.p[0], s.i[0], s.i[1], s.i[2], s.i[3], (const float*)s.p[1], s.i[4], s.i[5], s.i[6], (void*)s.p[2], stream);

@@ -15,8 +15,10 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_DROPOUT, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX, OP_TEMB,
-                   OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
+from ._lib import (OP_ACT_BOUND, OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_DROPOUT, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX,
+                   OP_TEMB, OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
+
+AB = 32  # entries per image of an activation bound table (csrc/common.h: EOD_AB)
 
 # precision mode -> storage dtype of activations.  "fp32x3": fp32 storage, the 3x3 halo convs compute every product as three fp16
 # MFMAs on split operands (csrc/igemm.hip, eod_conv_desc.w_split); everything else runs exactly as in "fp32".
@@ -36,11 +38,12 @@ def require_gpu(t, what):
 
 class Act:
     """Channels-last activation handle: tensor of shape [N, H, W, C] in the storage dtype."""
-    __slots__ = ("t", "N", "H", "W", "C", "stats")
+    __slots__ = ("t", "N", "H", "W", "C", "stats", "bound")
 
     def __init__(self, t, N, H, W, C, stats=None):
         self.t, self.N, self.H, self.W, self.C = t, N, H, W, C
         self.stats = stats  # (fp32 tensor [N][P][C][2], P): GroupNorm partial sums emitted by the producing conv
+        self.bound = None   # fp32x3 programs: bound table [N][32] of this tensor once something has produced one (Program.bound_of)
 
     @property
     def HW(self):
@@ -107,6 +110,7 @@ class Program:
         self._timer = None
         self.L = _lib.lib()
         self.nbytes = 0
+        self._bounds = {}        # fp32x3: (data_ptr of every source of a virtual concat) -> bound table [N][32] of the raw concat
         self.drop_ops = []       # indices of OP_DROPOUT descriptors (their `step` field advances every run)
         self.drop_seed = int(torch.initial_seed()) & (2**63 - 1)
         self.drop_step = 0
@@ -202,6 +206,45 @@ class Program:
     def bind(self, name, op_index, setter):
         self.bindings.setdefault(name, []).append((op_index, setter))
 
+    # ------------------------------------------------------------------ activation bound tables (fp32x3 programs, csrc/common.h)
+    def bound_of(self, srcs):
+        """Bound table [N][32] (fp32, device) of the virtual concat of `srcs` (Acts) as it is stored -- every split-fp16 consumer of a
+        tensor that is NOT behind a fused GroupNorm derives its per-image operand scale from it.  Taken, in this order, from: a GroupNorm
+        finalize that already covered exactly these tensors (gn_stats), the tensor's own table (a producer that knows a bound: the
+        normalising pass, resampling, attention), the partial sums of the producing convs' epilogues (one tiny launch, no pass over the
+        data), a direct max|x| pass.  None outside fp32x3 programs."""
+        if not self.split:
+            return None
+        key = tuple(s.t.data_ptr() for s in srcs)
+        hit = self._bounds.get(key)
+        if hit is not None:
+            return hit
+        if len(srcs) == 1 and srcs[0].bound is not None:
+            return srcs[0].bound
+        ab = self.empty((srcs[0].N, AB), torch.float32, zero=True)
+        if all(s.stats is not None for s in srcs) and len(srcs) <= 2:
+            s0, s1 = srcs[0], (srcs[1] if len(srcs) > 1 else None)
+            self._small(OP_ACT_BOUND, p=(0, ptr(s0.stats[0]), ptr(s1.stats[0]) if s1 else 0, ptr(ab)), l=(0,),
+                        i=(self.dt, s0.N, s0.stats[1], s0.C, s1.stats[1] if s1 else 0, s1.C if s1 else 0))
+        elif len(srcs) == 1:
+            x = srcs[0]
+            self._small(OP_ACT_BOUND, p=(ptr(x.t), 0, 0, ptr(ab)), l=(x.t.numel() // x.N,), i=(self.dt, x.N, 0, 0, 0, 0))
+        else:  # several sources without epilogue statistics: one direct pass each, accumulated entry-wise into the same table
+            for k, x in enumerate(srcs):
+                self._small(OP_ACT_BOUND, p=(ptr(x.t), 0, 0, ptr(ab)), l=(x.t.numel() // x.N,), i=(self.dt, x.N, 0, 0, 0, 0, int(k > 0)))
+        self._bounds[key] = ab
+        if len(srcs) == 1:
+            srcs[0].bound = ab
+        return ab
+
+    def bound_of_tensor(self, t, n):
+        """direct max|x| bound table of a plain tensor whose first axis splits into n images (operands of the x3 GEMMs)"""
+        if not self.split:
+            return None
+        ab = self.empty((n, AB), torch.float32, zero=True)
+        self._small(OP_ACT_BOUND, p=(ptr(t), 0, 0, ptr(ab)), l=(t.numel() // n,), i=(self.dt, n, 0, 0, 0, 0))
+        return ab
+
     def conv_up4_ok(self, x, cout):
         """True if the library has the parity-class form of `3x3 conv over the nearest-2x upsampling of x` for this geometry"""
         if os.environ.get("EOD_UP4", "1") == "0" or self.precision == "fp32":
@@ -247,7 +290,7 @@ class Program:
             probe.out_nchw_f32 = int(out_nchw_f32)
             probe.w_split = int(self.split and isinstance(w_packed, _LazyConvW))  # (the fusion threshold depends on the product form)
             if not self.L.eod_conv_gn_fusable(C.byref(probe)):
-                x = self.gn_apply([x] + ([x2] if x2 is not None else []), gn[0], silu=gn[1])
+                x = self.gn_apply([x] + ([x2] if x2 is not None else []), gn[0], silu=gn[1])  # (carries the normalised tensor's bound table)
                 x2, gn = None, None
         if upsample == "up4":  # w_packed = pack_conv_up4(weight): the parity-class form of the nearest-2x conv
             upsample = 3
@@ -259,6 +302,14 @@ class Program:
         wo = (weff + 2 * pad - ksize) // stride + 1
         if upsample == 4:
             ho, wo = x.H // 2, x.W // 2
+        ab = ab_skip = None
+        if self.split:
+            # fp32x3: the kernel derives its per-image operand scale from the bound table of what it splits -- the normalised tensor
+            # behind a fused GroupNorm (its finalize wrote that table), the stored tensor otherwise; likewise for the fused skip conv's
+            # input.  (Looked up BEFORE the conv is pushed: a table that does not exist yet is one more op in front of it.)
+            ab = getattr(gn[0], "eod_bound_norm", None) if gn is not None else self.bound_of([x] + ([x2] if x2 is not None else []))
+            if skip is not None:
+                ab_skip = self.bound_of(list(skip[0]))
         op, idx = self._push(OP_CONV)
         d = op.u.conv
         d.x, d.x2 = ptr(x.t), ptr(x2.t) if x2 is not None else 0
@@ -298,6 +349,9 @@ class Program:
             d.w = ptr(w_packed)
         if gn is not None:
             d.gn_scale_shift, d.gn_silu = ptr(gn[0]), int(gn[1])
+        if d.w_split:
+            assert ab is not None and (skip is None or ab_skip is not None), "fp32x3: no bound table for this conv input"
+            d.a_bound, d.skip_bound = ptr(ab), ptr(ab_skip)
         wsz = self.L.eod_conv_workspace_size(C.byref(d))
         if wsz > 0:  # split-K partial tiles (small maps)
             ws = self.empty((wsz // 4,), torch.float32)
@@ -320,8 +374,11 @@ class Program:
         return y, idx
 
     def gemm(self, a, b, c, M, N, K, lda, ldb, ldc, *, bias=None, bias_mode=1, res=None, alpha=1.0, c_f32=False,
-             nb0=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0):
-        """C = alpha*A.B^T (+bias)(+res); a/b/c are tensors, *_off element offsets into them."""
+             nb0=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, a_bound=None, b_bound=None):
+        """C = alpha*A.B^T (+bias)(+res); a/b/c are tensors, *_off element offsets into them.  fp32x3 programs run it as the split-fp16
+        product (x3) when K % 8 == 0: a_bound / b_bound = bound table [nb0][32] of that operand (bound_of / bound_of_tensor /
+        weight_bound; indexed by the outer batch index = image), None = the operand is known to stay below 4094 in magnitude (softmax
+        weights).  Activations stacked along M (nb0 == 1 over several images) have no per-image scale here: run those as 1x1 convs."""
         op, idx = self._push(OP_GEMM)
         d = op.u.gemm
         es = self.tdtype.itemsize
@@ -335,7 +392,21 @@ class Program:
         d.dtype, d.M, d.N, d.K, d.nb0, d.nb1 = self.dt, M, N, K, nb0, nb1
         d.bias_mode, d.c_f32, d.alpha = (bias_mode if bias is not None else 0), int(c_f32), alpha
         d.x3 = int(self.split and K % 8 == 0 and os.environ.get("EOD_GEMM_X3", "1") != "0")  # fp32x3 mode: split-fp16 products
+        if d.x3:
+            for t in (a_bound, b_bound):
+                assert t is None or tuple(t.shape) == (nb0, AB), "gemm: bound tables are [nb0][32]"
+            d.a_bound, d.b_bound = ptr(a_bound), ptr(b_bound)
         return idx
+
+    def weight_bound(self, w, n):
+        """bound table [n][32] of a parameter tensor that every image shares (an operand of an x3 GEMM): one max|w| pass at BUILD time
+        (parameters are constants of a plan), the row repeated per image"""
+        if not self.split:
+            return None
+        one = torch.zeros((1, AB), dtype=torch.float32, device=self.device)
+        check(self.L.eod_act_bound(ptr(w), _lib.dtype_id(w.dtype), 1, w.numel(), 0, 0, 0, 0, 0, 0, ptr(one), 0, current_stream_ptr(self.device)),
+              "act_bound")
+        return self.own(one.expand(n, AB).contiguous())
 
     def _small(self, kind, p=(), l=(), i=(), f=()):
         op, idx = self._push(kind)
@@ -373,9 +444,18 @@ class Program:
         self.last_gn_parts = parts  # (partial-sum tensor, P, C) per source: the training path derives mean / rstd from them
         ss = self.empty((N, ctot, 2), torch.float32)
         p1 = parts[1] if len(parts) == 2 else (None, 0, 0)
+        ab_raw = ab_norm = None
+        if self.split and groups <= AB:
+            # fp32x3: the finalize also writes the bound tables its consumers scale their split operands by (csrc/common.h): of the
+            # normalised tensor (the conv behind this GroupNorm) and of the stored one (skip / resampling convs over the same tensors)
+            ab_raw, ab_norm = self.empty((N, AB), torch.float32, zero=True), self.empty((N, AB), torch.float32, zero=True)
+            self._bounds.setdefault(tuple(s.t.data_ptr() for s in srcs), ab_raw)
+            if len(srcs) == 1 and srcs[0].bound is None:
+                srcs[0].bound = ab_raw
         self._small(OP_GN_FINALIZE,
-                    p=(ptr(parts[0][0]), ptr(gamma), ptr(beta), ptr(film) if film is not None else 0, ptr(ss), ptr(p1[0])),
+                    p=(ptr(parts[0][0]), ptr(gamma), ptr(beta), ptr(film) if film is not None else 0, ptr(ss), ptr(p1[0]), ptr(ab_raw), ptr(ab_norm)),
                     l=(HW, film_stride), i=(N, parts[0][1], parts[0][2], groups, p1[1], p1[2]), f=(eps,))
+        ss.eod_bound_norm = ab_norm
         return ss
 
     def gn_apply(self, srcs, ss, *, silu):
@@ -384,6 +464,7 @@ class Program:
         N, H, W = x0.N, x0.H, x0.W
         ctot = sum(s.C for s in srcs)
         y = self.act(N, H, W, ctot)
+        y.bound = getattr(ss, "eod_bound_norm", None)  # (|SiLU(v)| <= |v|: the table holds with and without the activation)
         coff = 0
         for s in srcs:
             self._small(OP_GN_APPLY, p=(ptr(s.t), ptr(ss), ptr(y.t)), i=(self.dt, N, H * W, s.C, ctot, coff, int(silu)))
@@ -404,9 +485,11 @@ class Program:
         a.dtype, a.N, a.T, a.C, a.heads, a.d, a.dpad, a.k_off = self.dt, N, T, Cc, heads, d, dpad, k_off
         return idx
 
-    def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None):
-        """fused attention on the natural qkv layout [N][T][3C] (fp16, head dim % 8 == 0 and <= 64, any T): eod_attention_fwd_nat"""
-        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse)), i=(self.dt, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride))
+    def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None, qkv_bound=None):
+        """fused attention on the natural qkv layout [N][T][3C] (head dim % 8 == 0 and <= 64, any T): eod_attention_fwd_nat.  fp32 storage
+        (fp32x3): qkv_bound = bound table [N][32] of qkv (None: |q|, |k|, |v| < 4094 guaranteed by the caller)"""
+        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse), ptr(qkv_bound)),
+                           i=(self.dt, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride))
 
     def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):
         return self._small(OP_SOFTMAX, p=(ptr(s_f32), ptr(p_out)), l=(lds, ldp, rows), i=(self.dt, n))
@@ -431,6 +514,8 @@ class Program:
             o = int(pad_tl) if mode == 2 else 0
             ho, wo = (x.H - o) // 2, (x.W - o) // 2
         y = self.act(x.N, ho, wo, x.C)
+        if mode in (0, 1, 3):  # averages and copies stay inside the input's bound
+            y.bound = x.bound
         self._small(OP_POOL, p=(ptr(x.t), ptr(y.t)), i=(self.dt, x.N, x.H, x.W, x.C, mode, int(pad_tl)))
         return y
 

@@ -88,6 +88,11 @@ typedef struct {
                             eod_conv_split_ok(d) == 1 (fp32, C0 and C1 multiples of 8 -- or w_tapmajor with eod_pack_conv_weight_tapmajor_split);
                             rel. error ~2^-22 per product */
     const float* w_scale; /* device pointer to {s, 1/(16 s)} written by eod_pack_conv_weight_split (w_split only) */
+    const float* a_bound; /* w_split: bound table [N][32] fp32 (device) of the tensor the conv SPLITS -- x | x2 as the conv sees them, i.e. behind
+                            the fused GroupNorm + SiLU when gn_scale_shift is set: entry maximum per image >= max|element|.  The kernel
+                            derives a power-of-two operand scale per image from it (no host synchronisation), so the product is
+                            fp32-grade for inputs of any magnitude.  Written by eod_gn_finalize (ab_norm / ab_raw) or eod_act_bound.
+                            NULL = the caller guarantees |element| < 4094 (fixed scale 16) */
     /* ResBlock skip connection fused into out_layers' conv (unet_openai.py:352, 385: `return self.skip_connection(x) + h`): y gets
      * sum_c skip_w[co][c] * X(n, ho, wo, c) on top of the 3x3 conv, X = the block input (skip_x | skip_x2 as a virtual concat) at the
      * output resolution.  The skip tensor is never written: same accumulators, the K loop simply continues over X's channels.
@@ -98,6 +103,8 @@ typedef struct {
     const void* skip_x2;
     const void* skip_w;
     int32_t skip_C0, skip_C1;
+    const float* skip_bound; /* w_split: bound table [N][32] of skip_x | skip_x2 (see a_bound; the launch runs on the smaller of the two
+                            scales because both phases feed one accumulator); NULL = |element| < 4094 guaranteed */
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
@@ -144,7 +151,10 @@ typedef struct {
     int32_t c_f32;     /* 1: store c as fp32 regardless of dtype */
     float alpha;
     int32_t x3;        /* 1 (dtype EOD_F32, K % 8 == 0): every product as three fp16 MFMAs on operands split into hi + lo halves in LDS
-                          (the fp32x3 precision mode, see eod_conv_desc.w_split); |a|, |b| must stay below 4094 */
+                          (the fp32x3 precision mode, see eod_conv_desc.w_split) */
+    const float* a_bound; /* x3: bound tables [nb0][32] of a / b (see eod_conv_desc.a_bound; indexed by the OUTER batch index b0 = image);
+                          NULL = that operand is known to stay below 4094 in magnitude (softmax weights) */
+    const float* b_bound;
 } eod_gemm_desc;
 int eod_gemm_nt(const eod_gemm_desc* d, void* stream);
 
@@ -189,7 +199,15 @@ int eod_gn_partial(const void* x, int dtype, int N, int HW, int C, float* part, 
                    int coff, void* stream);
 int eod_gn_finalize(const float* part0, int P0, int C0, const float* part1, int P1, int C1, int N, int64_t HW,
                     int groups, float eps, const float* gamma, const float* beta, const float* film,
-                    int64_t film_stride, float* scale_shift, void* stream);
+                    int64_t film_stride, float* scale_shift, float* ab_raw, float* ab_norm, void* stream);
+/* ab_raw / ab_norm (optional OUT, [N][32] fp32, groups <= 32): bound tables for the split-fp16 consumers of the tensor(s) the statistics
+ * were taken of (eod_conv_desc.a_bound / skip_bound): entry g of image n = an upper bound of max|x| (ab_raw) and of max|x*scale + shift|
+ * (ab_norm; also bounds its SiLU) over group g, from the largest partial sum of squares -- no extra pass over the tensor.
+ * eod_act_bound writes the same table for a tensor without a GroupNorm in front of its consumer: from the partial sums a conv epilogue
+ * emitted (part0 [N][P0][C0][2] | part1), or -- part0 == NULL -- as the exact max|x| of x ([N][per_image] elements, any finite fp32;
+ * accumulate = 1: entry-wise maximum with what the table already holds -- the further sources of a virtual concat). */
+int eod_act_bound(const void* x, int dtype, int N, int64_t per_image, const float* part0, int P0, int C0, const float* part1, int P1,
+                  int C1, float* ab, int accumulate, void* stream);
 int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot,
                  int coff, int silu, void* y, void* stream);
 
@@ -292,10 +310,11 @@ enum {
     EOD_OP_POOL = 10, EOD_OP_ATTN = 11,
     EOD_OP_TRANSPOSE = 12, /* eod_transpose_gather (training forward: transposed q|k|v for the attention GEMMs) */
     EOD_OP_ATTN_NAT = 13,  /* eod_attention_fwd_nat */
-    EOD_OP_DROPOUT = 14    /* eod_dropout (training forward) */
+    EOD_OP_DROPOUT = 14,   /* eod_dropout (training forward) */
+    EOD_OP_ACT_BOUND = 15  /* eod_act_bound */
 };
 typedef struct {
-    const void* p[6];
+    const void* p[8];
     int64_t l[4];
     int32_t i[10];
     float f[2];
@@ -410,7 +429,8 @@ int eod_scale_f32(float* x, int64_t n, float s, void* stream);
  *   EOD_F32: fp32 in / out, fp32 online softmax, both contractions as three fp16 MFMAs per product on operands split into
  *            hi + lo halves (fp32-grade, ~2^-22 per product; csrc/attn_x3.hip) */
 int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off, int k_off,
-                          int v_off, int head_stride, void* stream);
+                          int v_off, int head_stride, const float* qkv_bound, void* stream);
+/* qkv_bound (EOD_F32 only): bound table [N][32] of the qkv tensor (eod_conv_desc.a_bound); NULL = |q|, |k|, |v| < 4094 guaranteed */
 /* flash-style attention backward (fp16, head dim a multiple of 8 and <= 64, any T): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /
  * k_off / v_off + head*head_stride + j), dO [N][T][C], the forward's log-sum-exp lse [N][heads][T] (eod_attn_desc.lse) and
  * D[n][h][t] = sum_j dO*O (eod_rowdot).  P is rebuilt tile by tile in registers: nothing T x T touches HBM (csrc/attn_bwd.hip) */

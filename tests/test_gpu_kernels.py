@@ -248,7 +248,7 @@ def test_conv_fused_epilogue_concat_residual_temb(prec, dims):
     assert rel_l2(got, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("shape", [(2, 32, 8, 8), (2, 96, 7, 7), (1, 128, 32, 32), (3, 224, 5, 3), (2, 1024, 4, 4),
                                    (2, 1280, 6, 5), (1, 2560, 3, 3)])  # (the last two: more than 256 16-byte chunks per pixel -> channel blocks)
 @pytest.mark.parametrize("silu", [True, False])
@@ -265,10 +265,10 @@ def test_group_norm_silu(prec, shape, silu):
     ref = F.group_norm(x, 32, gam, bet, eps=1e-5)
     if silu:
         ref = F.silu(ref)
-    assert rel_l2(got, ref) < (2e-6 if prec == "fp32" else 2e-3)
+    assert rel_l2(got, ref) < (2e-3 if prec == "fp16" else 2e-6)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 def test_group_norm_across_concat_seam(prec):
     """GN over a virtual concat whose groups straddle the seam: 64 | 32 channels -> 3 per group"""
     from eo_diffusion_amd.engine import Act
@@ -285,7 +285,7 @@ def test_group_norm_across_concat_seam(prec):
 
     got = run_program(prec, torch.cat([x0, x1], 1), emit)
     ref = F.silu(F.group_norm(torch.cat([x0, x1], 1), 32, gam, bet, eps=1e-5))
-    assert rel_l2(got, ref) < (2e-6 if prec == "fp32" else 2e-3)
+    assert rel_l2(got, ref) < (2e-3 if prec == "fp16" else 2e-6)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])   # fp32x3: both operands split into fp16 pairs in LDS (eod_gemm_desc.x3)
@@ -363,14 +363,13 @@ def test_conv_with_fused_input_groupnorm(prec, dims, silu):
     assert rel_l2(got, ref) < TOL[prec]
 
 
-@pytest.mark.parametrize("mag", [1.0, 1e-2, 1e2, 1e-4])
+@pytest.mark.parametrize("mag", [1.0, 1e-2, 1e2, 1e-4, 1e-6, 1e4, 1e8, 1e-12, 3e18])
 @pytest.mark.parametrize("wmag", [1.0, 1e-3, 30.0])
 def test_fp32x3_product_is_fp32_grade_at_any_magnitude(mag, wmag):
-    """the split-fp16 product (three fp16 MFMAs per product, per-tensor power-of-two weight scale, activation scale 16, fp16
-    subnormals for the low halves) against a float64 convolution: as accurate as the exact-fp32 MFMA path for activations from
-    1e-2 to 1e2 and weights from 1e-3 to 30 -- not just inside the 1e-5 gate.  The low half of an activation has an ABSOLUTE
-    resolution of 2^-29 (fp16 subnormal quantum / activation scale 16), so a conv input whose values are all ~1e-4 (never the case
-    behind a GroupNorm) degrades gracefully to ~1e-5 relative: that floor is pinned here too."""
+    """the split-fp16 product (three fp16 MFMAs per product, per-tensor power-of-two weight scale, per-IMAGE power-of-two activation
+    scale derived on the device from the tensor's bound table, fp16 subnormals for the low halves) against a float64 convolution: as
+    accurate as the exact-fp32 MFMA path for activations of ANY magnitude (1e-12 ... 3e18 here; round 2's fixed activation scale of 16
+    overflowed above 4094 and lost the low halves below ~1e-4) and weights from 1e-3 to 30 -- not just inside the 1e-5 gate."""
     N, Cin, H, W, Cout = 1, 256, 32, 32, 128
     x = synth_input("x3x", (N, Cin, H, W), 51, scale=mag)
     w = synth_input("x3w", (Cout, Cin, 3, 3), 51, scale=wmag / math.sqrt(Cin * 9))
@@ -387,13 +386,10 @@ def test_fp32x3_product_is_fp32_grade_at_any_magnitude(mag, wmag):
         err[prec] = rel_l2(run_program(prec, x, emit), ref)
         assert emit.split == (1 if prec == "fp32x3" else 0)  # the split kernel really ran
     print(f"activations ~{mag:g}, weights ~{wmag:g}: exact fp32 {err['fp32']:.2e}, fp32x3 {err['fp32x3']:.2e}")
-    if mag >= 1e-2:
-        assert err["fp32x3"] < 1e-6 and err["fp32x3"] < 4 * err["fp32"] + 2e-7
-    else:
-        assert err["fp32x3"] < 2.0 ** -29 / (0.5 * mag)  # the documented absolute floor
+    assert err["fp32x3"] < 1e-6 and err["fp32x3"] < 4 * err["fp32"] + 2e-7
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("dims", [(2, 3, 16, 16, 128), (1, 7, 32, 16, 128), (2, 13, 8, 24, 64), (1, 4, 7, 9, 32), (1, 3, 64, 64, 128)])
 def test_first_conv_tapmajor(prec, dims):
     """thin-input 3x3 conv (UNet input conv, unet_openai.py:609): K over the flattened [tap][channel] axis
@@ -502,7 +498,7 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order):
     qd = qh.to(DEV)
     out = torch.empty((N * T, C), dtype=torch.float16, device=DEV)
     lse = torch.empty((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, st),
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, st),
                "attention_fwd_nat")
     assert rel_l2(out.float().cpu().reshape(N, T, C), O.detach()) < 3e-3
     lse_ref = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) / math.sqrt(d), -1)
@@ -540,7 +536,7 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
     qd = qkv.to(DEV)
     out = torch.full((N, T, C), 9.0, dtype=torch.float16, device=DEV)
     lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs,
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0,
                                        current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu(), ref) < 3e-3
@@ -550,10 +546,11 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
                                                  (64, 4, 8, False), (4096, 2, 64, False)])
 @pytest.mark.parametrize("mag", [0.8, 4.0])
-def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag):
+@pytest.mark.parametrize("bound", [False, True])
+def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, bound):
     """the fp32-storage instance of eod_attention_fwd_nat (fp32 online softmax, both contractions as three fp16 MFMAs per product
     on split operands; the T x T weights never exist) vs a float64 softmax(q k^T / sqrt(d)) v: fp32-grade, also for peaked
-    softmax rows (mag 4: logits of +-50)"""
+    softmax rows (mag 4: logits of +-50); with the fixed operand scale (no table) and with the per-image scale from a bound table"""
     from eo_diffusion_amd import _lib
     from eo_diffusion_amd.engine import current_stream_ptr
     L = _lib.lib()
@@ -567,9 +564,15 @@ def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag):
     qd = qkv.to(DEV)
     out = torch.full((N, T, C), 9.0, dtype=torch.float32, device=DEV)
     lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
+    ab = torch.zeros((N, 32), dtype=torch.float32, device=DEV)
+    st = current_stream_ptr(torch.device(DEV))
+    if bound:
+        _lib.check(L.eod_act_bound(qd.data_ptr(), _lib.EOD_F32, N, T * 3 * C, 0, 0, 0, 0, 0, 0, ab.data_ptr(), 0, st), "act_bound")
     _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F32, N, T, C, heads, d, qo, ko, vo, hs,
-                                       current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
+                                       ab.data_ptr() if bound else 0, st), "attention_fwd_nat")
     torch.cuda.synchronize()
+    if bound:
+        assert torch.equal(ab.cpu().max(1).values, qkv.abs().amax((1, 2)))  # the direct pass is the exact max|x| per image
     err = rel_l2(out.cpu(), ref)
     f32 = rel_l2((torch.softmax(S.float(), -1) @ v.float()).permute(0, 2, 1, 3).reshape(N, T, C), ref)  # what plain fp32 torch gives
     print(f"T={T} d={d} mag={mag}: fused fp32x3 attention {err:.2e}, torch fp32 {f32:.2e}")
@@ -660,7 +663,7 @@ def test_group_norm_silu_backward_kernels(prec, N, C0, C1, H, W, silu):
     p1 = (parts[1].data_ptr(), P, C1) if C1 else (0, 0, 0)
     ss, mr = f32(N, Ct, 2), f32(N, G, 2)
     gd, bd = gam.to(DEV), bet.to(DEV)
-    _lib.check(L.eod_gn_finalize(parts[0].data_ptr(), P, C0, p1[0], p1[1], p1[2], N, HW, G, 1e-5, gd.data_ptr(), bd.data_ptr(), 0, 0, ss.data_ptr(), st), "gn_finalize")
+    _lib.check(L.eod_gn_finalize(parts[0].data_ptr(), P, C0, p1[0], p1[1], p1[2], N, HW, G, 1e-5, gd.data_ptr(), bd.data_ptr(), 0, 0, ss.data_ptr(), 0, 0, st), "gn_finalize")
     _lib.check(L.eod_gn_mean_rstd(parts[0].data_ptr(), P, C0, p1[0], p1[1], p1[2], N, HW, G, 1e-5, mr.data_ptr(), st), "gn_mean_rstd")
     part, coef, gb = f32(N, P, Ct, 2), f32(N, Ct, 3), f32(N, Ct, 2)
     for xs, c, off in srcs:

@@ -42,7 +42,7 @@ def test_attention_vs_golden(prec, name, monkeypatch):
     assert rel_l2(y, g["y"]) < TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 def test_resample_vs_golden(prec, monkeypatch):
     from eo_diffusion_amd.backbones.unet_openai import Downsample, Upsample
     monkeypatch.setenv("EOD_PRECISION", prec)
@@ -154,7 +154,7 @@ def test_factory_presets_vs_oracle(prec, factory, size):
     assert rel_l2(out, ref) < (2e-5 if prec == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("shape", [(1, 3, 16, 48), (3, 3, 40, 24)])
 def test_unet_non_square_and_odd_batch(prec, shape):
     """the UNet itself is shape-agnostic (only EODiffusion assumes square images): non-square maps, batch 1 / 3"""
