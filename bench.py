@@ -255,11 +255,16 @@ def time_sampling(args, m, dev, rank, world, use_dist, dist, timing=True):
         for _ in range(args.steps):
             x_t = one_step(x_t, i)
             i = i - 1 if i > 0 else T - 1
+        gathered = None
         if use_dist:  # the one collective of the path: gather the final images
-            out = torch.empty((world * N, 3, S, S), dtype=torch.float32, device=x_t.device)
-            dist.all_gather_into_tensor(out, x_t.contiguous())
+            gathered = torch.empty((world * N, 3, S, S), dtype=torch.float32, device=x_t.device)
+            dist.all_gather_into_tensor(gathered, x_t.contiguous())
         barrier()
         dt = time.perf_counter() - t0
+    if gathered is not None:  # (outside the timed region) the collective really delivered this rank's shard
+        time_sampling.collective = {"op": "all_gather_into_tensor", "backend": dist.get_backend(), "world": world,
+                                    "bytes_per_rank": x_t.numel() * 4, "device": str(gathered.device),
+                                    "own_shard_bit_equal": bool(torch.equal(gathered[rank * N:(rank + 1) * N], x_t))}
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=x_t.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -422,6 +427,8 @@ def main():
         }
         if stub:
             res["stub"] = True
+        if getattr(time_sampling, "collective", None):
+            res["collective"] = time_sampling.collective
         if parity:
             parity.pop("probe_output", None)
             res["parity_probe"] = parity

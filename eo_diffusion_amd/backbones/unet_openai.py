@@ -376,7 +376,10 @@ class ResBlock(TimestepBlock):
 def _qkv_attention_standalone(mod, qkv):
     """QKVAttention(Legacy).forward(qkv) (unet_openai.py:465-481 / 497-515) as its own call: qkv [N, 3*H*d, T] -> [N, H*d, T].
     One layout pass to the kernels' [N][T][3C] form, the fused attention kernel (eod_attention_fwd_nat; the T x T weights never exist),
-    one pass back.  fp16 mode: fp16 storage; fp32 / fp32x3: fp32 in and out with split-fp16 products and fp32 softmax."""
+    one pass back.  Precision = EOD_PRECISION (a bare QKVAttention module has no enclosing model to ask): fp16 -> fp16 storage; fp32x3
+    AND fp32 -> fp32 in and out, fp32 softmax, both contractions as split-fp16 products (~2^-22 per product, safe at any magnitude: the
+    operand scale comes from a max|x| pass over qkv).  There is no exact-fp32-MFMA instance of the fused kernel: the `fp32` mode is
+    SUBSTITUTED by the fp32x3 product here (same 1e-5 gate); inside AttentionBlock the exact mode keeps its exact GEMM path."""
     require_gpu(qkv, type(mod).__name__)
     bs, width, length = qkv.shape
     nh = mod.n_heads

@@ -263,7 +263,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
         for (int r = 0; r < 16; ++r) dq[t][r] = 0.0f;
 
     const int nkt = (p.T + 63) / 64;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one key tile; RAGGED (compile-time) = the last tile of a sequence that is not a multiple of 64 keys: only that instance masks keys
+    // beyond T.  A zero-filled key row gives s = 0 and dP = 0, so dS = -exp(-lse) 2^12 D there: finite in fp32 and multiplied by a
+    // zero K row, but it enters the MFMA as fp16 -- once every logit of a query row is very negative (lse << 0) it overflows to inf,
+    // and inf x 0 is NaN in that query's dQ.  Full tiles have no such rows and keep the unmasked form.
+    auto tile = [&](const int kt, auto ragged_c) {
+        constexpr bool RAGGED = decltype(ragged_c)::value;
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -292,8 +297,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                // (keys beyond T need no mask: their K rows are zero-filled, so a finite dS there adds exactly 0 to dQ)
-                const float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][r], a2, -my_l2));  // P x 2^12
+                float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][r], a2, -my_l2));  // P x 2^12
+                if constexpr (RAGGED) {
+                    const int key = kt * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pe = key < p.T ? pe : 0.0f;
+                }
                 dp[mt][r] = pe * (dp[mt][r] - my_D);  // dS^T x 2^12
             }
         // ---- dQ += dS K  (contraction over the 64 keys held in registers, permuted order; B = K rows via transposed reads) ----
@@ -308,7 +316,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
                     dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs, bk, dq[t], 0, 0, 0);
                 }
             }
-    }
+    };
+    const int nfull = (p.T & 63) ? nkt - 1 : nkt;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nkt - 1, std::true_type{});
     half_t* out = reinterpret_cast<half_t*>(p.dqkv) + (long long)n * p.T * 3 * p.C;
 #pragma unroll
     for (int t = 0; t < DT; ++t) {

@@ -20,9 +20,14 @@ def shard_bounds(n_total, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_samples(local, n_total, group=None):
-    """All-gather ragged per-rank shards [n_r, ...] into [n_total, ...] on every rank (one collective)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def gather_samples(local, n_total, group=None, force_gather=False):
+    """All-gather ragged per-rank shards [n_r, ...] into [n_total, ...] on every rank (one collective).  A single rank returns its
+    shard as it is -- unless force_gather: then the collective runs even in a one-rank group (the RCCL all_gather_into_tensor on
+    device memory, executed for real on a one-GPU box; tests/test_gpu_dist.py)."""
+    initialised = dist.is_available() and dist.is_initialized()
+    if force_gather and not initialised:
+        raise RuntimeError("gather_samples(force_gather=True) needs an initialised process group")
+    if not initialised or (dist.get_world_size(group) == 1 and not force_gather):
         assert local.shape[0] == n_total
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -44,9 +49,9 @@ def gather_samples(local, n_total, group=None):
 
 @torch.no_grad()
 def sharded_sampling(model, n_samples, *, seed=0, clipped_reverse_diffusion=True, cond=None, y=None, device=None,
-                     group=None, progress=False):
+                     group=None, progress=False, force_gather=False):
     """EODiffusion.sampling over all ranks of `group`: every rank returns the full [n_samples, C, H, W] tensor.
-    cond / y are the GLOBAL tensors (each rank slices its own rows)."""
+    cond / y are the GLOBAL tensors (each rank slices its own rows).  force_gather: see gather_samples."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_bounds(n_samples, world, rank)
@@ -55,4 +60,4 @@ def sharded_sampling(model, n_samples, *, seed=0, clipped_reverse_diffusion=True
     yy = y[lo:hi] if y is not None else None
     local = model.sampling(hi - lo, clipped_reverse_diffusion=clipped_reverse_diffusion, device=dev, cond=c, y=yy,
                            rng="philox", seed=seed, sample_offset=lo, progress=progress)
-    return gather_samples(local, n_samples, group=group)
+    return gather_samples(local, n_samples, group=group, force_gather=force_gather)

@@ -644,7 +644,7 @@ class Program:
                 out.append(dict(kind="softmax", flops=0.0, bytes=s.l[2] * (4 * s.i[1] + es * s.l[1]), label="softmax"))
             else:
                 out.append(dict(kind={OP_GN_FINALIZE: "gn_finalize", OP_TEMB: "temb", OP_TO_NHWC: "to_nhwc",
-                                      OP_TO_NCHW: "to_nchw", OP_POOL: "resample"}.get(k, str(k)), flops=0.0, bytes=0.0,
+                                      OP_TO_NCHW: "to_nchw", OP_POOL: "resample", OP_ACT_BOUND: "act_bound"}.get(k, str(k)), flops=0.0, bytes=0.0,
                                 label=""))
         return out
 

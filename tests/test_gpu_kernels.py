@@ -472,9 +472,13 @@ def test_softmax_long_rows_forward_and_backward(prec, n, ld):
 
 @pytest.mark.parametrize("T,heads,d,new_order", [(128, 2, 16, False), (256, 2, 32, True), (256, 1, 48, False), (384, 2, 64, False), (128, 3, 8, True),
                                                  (49, 2, 16, False), (196, 1, 32, True), (200, 2, 48, False), (64, 2, 64, False)])
-def test_flash_attention_backward_vs_autograd(T, heads, d, new_order):
+@pytest.mark.parametrize("neg_logits", [False, True])
+def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits):
     """eod_attention_fwd (with log-sum-exp) + eod_rowdot + eod_attention_bwd against torch autograd of
-    softmax(q k^T / sqrt(d)) v on the natural qkv layout (legacy [h][q|k|v][d] and new [q|k|v][h][d] orders)"""
+    softmax(q k^T / sqrt(d)) v on the natural qkv layout (legacy [h][q|k|v][d] and new [q|k|v][h][d] orders).
+    neg_logits: every logit of every row is around -35 (q and k carry opposite offsets, as a negative b_q . b_k bias term gives):
+    lse << 0, so exp(-lse) is huge -- on a ragged last key tile (T = 49, 196, 200) a zero-filled key row then has an unbounded
+    dS = -exp(-lse) D that becomes inf in fp16 and NaN against the zero K row unless the tile masks keys beyond T"""
     from eo_diffusion_amd import _lib
     from eo_diffusion_amd.engine import current_stream_ptr
     L = _lib.lib()
@@ -482,6 +486,11 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order):
     qkv = synth_input(f"fa{T}{d}", (N, T, 3 * C), 7, scale=0.7)
     dO = synth_input(f"fd{T}{d}", (N, T, C), 8, scale=0.5)
     qo, ko, vo, hs = (0, C, 2 * C, d) if new_order else (0, d, 2 * d, 3 * d)
+    if neg_logits:
+        off = math.sqrt(35.0 / math.sqrt(d))  # q . k / sqrt(d) = -off^2 d / sqrt(d) + O(1) = -35
+        for h in range(heads):
+            qkv[:, :, qo + h * hs: qo + h * hs + d] = 0.3 * qkv[:, :, qo + h * hs: qo + h * hs + d] + off
+            qkv[:, :, ko + h * hs: ko + h * hs + d] = 0.3 * qkv[:, :, ko + h * hs: ko + h * hs + d] - off
 
     def split(t):  # -> q, k, v as [N, heads, T, d]
         idx = lambda off: torch.stack([t[:, :, off + h * hs: off + h * hs + d] for h in range(heads)], 1)
@@ -512,10 +521,13 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order):
                                    qo, ko, vo, hs, st), "attention_bwd")
     torch.cuda.synchronize()
     g = dqkv.float().cpu()
+    assert torch.isfinite(g).all()
     for name, off in (("dq", qo), ("dk", ko), ("dv", vo)):
         for h in range(heads):
             a, b_ = g[:, :, off + h * hs: off + h * hs + d], ref_in.grad[:, :, off + h * hs: off + h * hs + d]
-            assert rel_l2(a, b_) < 6e-3, (name, h, rel_l2(a, b_))
+            # (neg_logits: q and k carry a common offset of +-off that cancels in dQ = sum_s dS_s k_s because sum_s dS_s = 0 -- the
+            #  fp16 rounding of dS is amplified by |off| / spread = ~10x against the result; 1.5e-2 there)
+            assert rel_l2(a, b_) < (1.5e-2 if neg_logits else 6e-3), (name, h, rel_l2(a, b_))
 
 
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
