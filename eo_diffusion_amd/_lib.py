@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ("Ho", i32), ("Wo", i32), ("out_nchw_f32", i32), ("alpha", f32), ("stats", vp), ("stats_slots", i32),
                 ("gn_silu", i32), ("gn_scale_shift", vp), ("workspace", vp), ("workspace_bytes", i64),
                 ("w_tapmajor", i32), ("w_split", i32), ("w_scale", vp), ("a_bound", vp),
-                ("skip_x", vp), ("skip_x2", vp), ("skip_w", vp), ("skip_C0", i32), ("skip_C1", i32), ("skip_bound", vp)]
+                ("skip_x", vp), ("skip_x2", vp), ("skip_w", vp), ("skip_C0", i32), ("skip_C1", i32), ("skip_bound", vp), ("x_presplit", i32)]
 
 
 class GemmDesc(C.Structure):
@@ -69,6 +69,8 @@ class Op(C.Structure):
 SYMBOLS = {
     "eod_last_error": (C.c_char_p, []),
     "eod_version": (i32, []),
+    "eod_set_option": (i32, [C.c_char_p, i32]),
+    "eod_get_option": (i32, [C.c_char_p]),
     "eod_struct_size": (i32, [i32]),
     "eod_conv2d_igemm": (i32, [C.POINTER(ConvDesc), vp]),
     "eod_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
@@ -96,7 +98,7 @@ SYMBOLS = {
     "eod_dropout": (i32, [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "eod_rowdot": (i32, [vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
     "eod_scale_f32": (i32, [vp, i64, f32, vp]),
-    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "eod_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
     "eod_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i32, i64, i32, vp]),
@@ -123,7 +125,7 @@ SYMBOLS = {
     "eod_pack_conv_weight_split": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "eod_pack_conv_weight_split_pair": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eod_conv_workspace_size": (i64, [C.POINTER(ConvDesc)]),
-    "eod_gn_apply": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp]),
+    "eod_gn_apply": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp]),
     "eod_attention_fwd": (i32, [C.POINTER(AttnDesc), vp]),
     "eod_softmax_rows": (i32, [vp, i64, vp, i64, i32, i64, i32, vp]),
     "eod_time_embed": (i32, [C.POINTER(TembDesc), vp]),

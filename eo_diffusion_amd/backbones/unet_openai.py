@@ -477,15 +477,18 @@ class AttentionBlock(_Emitter):
             # one projection GEMM, no packed q|k / transposed v operands, T x T never materialised (eod_attention_fwd_nat;
             # fp32x3: fp32 in / out with split-fp16 products, the projections run as 1x1 convs of the same product type)
             qo, ko, vo, hs = (0, Cc, 2 * Cc, d_nat) if self.attention.new_order else (0, d_nat, 2 * d_nat, 3 * d_nat)
-            xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps)
+            xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps,
+                                 split_out=prog.split)  # (fp32x3: written pre-split for the qkv conv, its only consumer)
             if prog.split:
                 # (stats=True: the epilogue's sums of squares give the bound table q / k / v are scaled by -- no pass over qkv)
                 qkv, _ = prog.conv(xn, prog.pack_conv(self.qkv.weight.view(3 * Cc, Cc, 1, 1)), prog.f32(self.qkv.bias), 3 * Cc,
                                    ksize=1, stride=1, pad=0, stats=True)
                 a = prog.act(N, x.H, x.W, Cc)
                 qkv_bound = prog.bound_of([qkv])
-                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs, qkv_bound=qkv_bound)
-                a.bound = qkv_bound  # a = convex combinations of v: |a| <= max|v| <= the bound of qkv
+                # a = convex combinations of v rows: |a| <= max|v| <= the bound of qkv -> known BEFORE the kernel runs, so it writes a
+                # pre-split for proj_out (its only consumer), which then needs no split pass per K-step
+                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs, qkv_bound=qkv_bound, out_presplit=Cc % 8 == 0)
+                a.bound, a.presplit = qkv_bound, Cc % 8 == 0
                 out, _ = prog.conv(a, prog.pack_conv(self.proj_out.weight.view(Cc, Cc, 1, 1)), prog.f32(self.proj_out.bias), Cc,
                                    ksize=1, stride=1, pad=0, res=x, stats=True)
                 return out

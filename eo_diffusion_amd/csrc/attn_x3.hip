@@ -63,6 +63,8 @@ struct AttnX3P {
     int N, T, C, heads, d, q_off, k_off, v_off, hs;
     float scale_log2;  // log2(e) / sqrt(d)
     const float* ab;   // bound table [N][EOD_AB] of qkv, or NULL
+    int out_ps;        // write `out` PRE-SPLIT ([8 x fp16 hi | 8 x fp16 lo] per 8 channels of s_n * out, s_n from `ab`: rows of out are
+                       // convex combinations of v rows, so the table of qkv bounds them) for the proj_out conv (eod_conv_desc.x_presplit)
 };
 
 template <int DS, int DT>
@@ -81,7 +83,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
     const float* base = p.qkv + (long long)n * p.T * ld;
     // operand scale of this image (wave-uniform), 1 / s, and the exponent's factor log2(e) / sqrt(d) / s^2 (exact: powers of two)
     AbScale asc = {16.0f, 1.0f};
-    if (p.ab) asc = ab_scale_of(ab_wave_bound(p.ab, n), AX_KMIN);
+    float out_s = 16.0f;  // scale of the pre-split output: what its consumer derives from the same table (default exponent range)
+    if (p.ab) {
+        const float B = ab_wave_bound(p.ab, n);
+        asc = ab_scale_of(B, AX_KMIN);
+        out_s = ab_scale_of(B).s;
+    }
     const float AX_SCALE = asc.s, rscale = asc.inv * 0.0625f;
     const float scale_log2 = p.scale_log2 * rscale * rscale;
 
@@ -247,14 +254,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = o[t][4 * g4 + e] * inv;
-                    *reinterpret_cast<f32x4*>(op + j0) = v;
+                    if (p.out_ps) {
+                        // lanes l (lh = 0) and l + 32 (lh = 1) hold the two halves of one 8-channel group of the same query: the first
+                        // stores [hi 0-3 | hi 4-7] at the group's first 16 bytes, the second [lo 0-3 | lo 4-7] behind it
+                        half4 h4, l4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            half_t hi, lo;
+                            ax_split(v[e] * out_s, hi, lo);
+                            h4[e] = hi; l4[e] = lo;
+                        }
+                        typedef int i32x2 __attribute__((ext_vector_type(2)));
+                        const i32x2 hb = __builtin_bit_cast(i32x2, h4), lb = __builtin_bit_cast(i32x2, l4);
+                        const int s0 = lh ? hb[0] : lb[0], s1 = lh ? hb[1] : lb[1];
+                        const int r0 = __shfl_xor(s0, 32), r1 = __shfl_xor(s1, 32);
+                        const i32x4 w = lh ? i32x4{r0, r1, lb[0], lb[1]} : i32x4{hb[0], hb[1], r0, r1};
+                        *reinterpret_cast<i32x4*>(op + j0) = w;
+                    } else {
+                        *reinterpret_cast<f32x4*>(op + j0) = v;
+                    }
                 }
             }
     }
 }
 
 int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int d, int q_off, int k_off, int v_off,
-                             int head_stride, const float* qkv_bound, hipStream_t st) {
+                             int head_stride, const float* qkv_bound, int out_presplit, hipStream_t st) {
     EOD_REQUIRE(q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && head_stride % 4 == 0 && eod_aligned16(qkv) && eod_aligned16(out) && C % 4 == 0,
                 "attention_fwd_nat (fp32): alignment of the head slices");
     AttnX3P p;
@@ -262,6 +287,7 @@ int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, in
     p.N = N; p.T = T; p.C = C; p.heads = heads; p.d = d; p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.hs = head_stride;
     p.scale_log2 = 1.4426950408889634f / sqrtf((float)d);
     p.ab = qkv_bound;
+    p.out_ps = out_presplit;
     const dim3 grid((T + 127) / 128, N * heads);
     const size_t lds = (size_t)256 * AX_ROWB;
     const int ds = (d + 15) / 16;

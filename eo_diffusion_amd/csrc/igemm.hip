@@ -67,7 +67,6 @@ struct IgemmP {
     float* stats;  // optional GroupNorm partial sums of the output: [N][stats_P][Cout][2]
     int stats_P, tiles_per_image;
     int splitk;    // conv: K-steps are split over gridDim.y workgroups; raw fp32 partial tiles go to `y` (= workspace)
-    int force_cfg; // 0 auto, 1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage (EOD_IGEMM_CFG, tuning only)
     float alpha;
     const float* w_scale;  // split-fp16 mode: device {s, 1/(s*A_SCALE)} of the packed weights (eod_pack_conv_weight_split)
     // row-decode grid: the M axis enumerates (image, Hd x Wd) positions.  Normally that is the output map (Hd = Ho, Wd = Wo).  Parity
@@ -90,6 +89,7 @@ struct IgemmP {
     const float* skip_bound;
     const float* b_bound;
     int ab_tab_off;  // generic kernel: byte offset in LDS of the per-image {s, 16/s} table of a tile that straddles images
+    int a_ps;        // generic split kernel: the A operand arrives PRE-SPLIT from HBM (eod_conv_desc.x_presplit): no rewrite in LDS
 };
 
 template <typename T> struct Mma;
@@ -136,9 +136,6 @@ template <> struct Mma<float> {
 // 32 % issuing, 44 % stalled on issue (the matrix pipe shared by two waves), 24 % parked at s_waitcnt / s_barrier.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define EOD_SPLIT_ASCALE 16.0f  // operand scale without a bound table
-__device__ __forceinline__ void mma_f16(const i32x4& a, const i32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-}
 // four fp32 values (one 16-byte chunk, already multiplied by the activation scale) -> packed {hi[4]} , {lo[4]} (2 dwords each)
 __device__ __forceinline__ void split4(const f32x4& f, int (&hi)[2], int (&lo)[2]) {
     half4 h, l;
@@ -487,7 +484,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
 
 template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmP p) {
-    static_assert(!SPLIT || (sizeof(T) == 4 && STAGES == 2), "split-fp16 product: fp32 storage, 2-stage ring");
+    static_assert(!SPLIT || (sizeof(T) == 4 && STAGES == 2 && MS == 16), "split-fp16 product: fp32 storage, 2-stage ring, 16x16x32 MFMAs");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only (see conv3x3_halo_kernel)");
     constexpr int ES = sizeof(T);
     constexpr int EPC = 16 / ES;   // elements per 16-byte chunk
@@ -775,9 +772,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if constexpr (SPLIT) {
-            // this wave's A pieces of step kt have landed: rewrite each fp32 chunk pair in place as [8 x hi | 8 x lo] (x 16), see
-            // the fp32x3 note at the top; masked lanes were zero-filled by the DMA and stay zero.  Weights arrive pre-split.
+            // this wave's A pieces of step kt have landed: rewrite each fp32 chunk pair in place as [8 x hi | 8 x lo] (x s), see
+            // the fp32x3 note at the top; masked lanes were zero-filled by the DMA and stay zero.  Weights arrive pre-split -- and so
+            // does A when its producer wrote it that way (a_ps: the normalising pass in front of qkv, the attention in front of
+            // proj_out): the LDS-DMA then delivers the finished image and this K-step has no VALU work at all.
             char* sa = smem + (kt % STAGES) * STAGE;
+            if (!(CONV && p.a_ps)) {
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 char* ptr = sa + (wave + NW * i) * 1024 + lane * 16;
@@ -785,6 +785,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) f[e] *= a_s[i];
                 *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (a_chunk[i] & 1) != 0);
+            }
             }
             if constexpr (!CONV) {  // GEMM (attention with wide heads): the B operand is an fp32 activation too
 #pragma unroll
@@ -848,36 +849,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa16[i]), __builtin_bit_cast(half8, fb16[j]), acc[i][j], 0, 0, 0);
-            }
-            continue;
-        } else if constexpr (SPLIT) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int ch = 2 * (2 * s + lh);
-                const int ohi = (ch ^ sw) * 16, olo = ((ch + 1) ^ sw) * 16;
-                i32x4 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ah[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + ohi);
-                    al[i] = *reinterpret_cast<const i32x4*>(sb + a_rd + i * 32 * BKB + olo);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + ohi);
-                    bl[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * 32 * BKB + olo);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) mma_f16(al[i], bh[j], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) mma_f16(ah[i], bl[j], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) mma_f16(ah[i], bh[j], acc[i][j]);
             }
             continue;
         }
@@ -953,7 +924,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void conv3x3_halo_kernel(const IgemmP p) {
     static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M == 2), "fused skip conv: 16x16x32 instances of the 8x16 tile");
-    static_assert(!SPLIT || sizeof(T) == 4, "the split-fp16 product is a mode of fp32 storage");
+    static_assert(!SPLIT || (sizeof(T) == 4 && MS == 16), "the split-fp16 product is a mode of fp32 storage, on 16x16x32 MFMAs");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only");
     constexpr bool XF = GN || SPLIT;  // the staged patch pieces are rewritten in place by the wave that DMA'd them
     constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
@@ -1303,36 +1274,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, fa16[i]), __builtin_bit_cast(half8, fb16[j]), acc[i][j], 0, 0, 0);
-                }
-            } else if constexpr (SPLIT) {
-                // 2 sub-steps of 16 k; lane half lh of sub-step s owns chunk pair 2s+lh: [8 x hi] at chunk 2(2s+lh), [8 x lo] right
-                // behind it.  Three fp16 MFMAs per 32x32 tile into the one fp32 accumulator, smallest terms first.
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int ch = 2 * (2 * s + lh);
-                    i32x4 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        ah[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + ((ch ^ asw[i]) << 4));
-                        al[i] = *reinterpret_cast<const i32x4*>(abuf + arow[i] + (((ch + 1) ^ asw[i]) << 4));
-                    }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        bh[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + ((ch ^ bsw) << 4));
-                        bl[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * 32 * BKB + (((ch + 1) ^ bsw) << 4));
-                    }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) mma_f16(al[i], bh[j], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) mma_f16(ah[i], bl[j], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) mma_f16(ah[i], bh[j], acc[i][j]);
                 }
             } else {
             // fragments are read ONE sub-step ahead of the MFMAs that consume them (two register sets), and the order
@@ -2063,22 +2004,47 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long l
 
 // ------------------------------------------------------------------------------------------ host side
 #include <stdlib.h>
-// MFMA shape of the fp16 products in the halo kernel: 16 (default, v_mfma_f32_16x16x32_f16) or 32 (EOD_MFMA_SHAPE=32, A/B switch)
-static int halo_mfma_shape() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("EOD_MFMA_SHAPE");
-        v = (e && atoi(e) == 32) ? 32 : 16;
+#include <string.h>
+// Kernel-selection options (each has ONE measured-best default; the losing arm stays reachable for same-box A/B runs and for the
+// per-switch parity tests, through the environment at first use or eod_set_option at any time):
+//   skip_fuse         EOD_SKIP_FUSE=0          ResBlock 1x1 skip convs as launches of their own instead of inside out_layers' conv
+//   head              EOD_HEAD=0               the output head on the 32-column halo instance instead of conv_head_kernel
+//   halo_bn256        EOD_HALO_BN256=0         256- / 512-column convs as two 4-wave workgroups per pixel tile instead of one 8-wave one
+//   gn_fuse_max_cout  EOD_GN_FUSE_MAX_COUT=n   widest conv that takes its input GroupNorm in its patch staging (-1: the defaults)
+// (Round 2's EOD_IGEMM_CFG / EOD_MFMA_SHAPE / EOD_HALO_SPLIT_N / EOD_CONV_PARITY arms were measured slower and are gone: the fp16
+// products run on v_mfma_f32_16x16x32_f16, 384-column convs as 256 + 128, zero-insertion convs as four parity-class launches.)
+enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_COUNT };
+static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout"};
+static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT"};
+static int g_opt[OPT_COUNT] = {1, 1, 1, -1};
+static bool g_opt_init = false;
+static int opt(int k) {
+    if (!g_opt_init) {
+        for (int i = 0; i < OPT_COUNT; ++i) {
+            const char* e = getenv(g_opt_env[i]);
+            if (e) g_opt[i] = atoi(e);
+        }
+        g_opt_init = true;
     }
-    return v;
+    return g_opt[k];
 }
-static int igemm_forced_cfg() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("EOD_IGEMM_CFG");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
+extern "C" int eod_set_option(const char* name, int value) {
+    (void)opt(0);
+    for (int i = 0; name && i < OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_name[i])) {
+            const int prev = g_opt[i];
+            g_opt[i] = value;
+            return prev;
+        }
+    eod_set_error("set_option: unknown option '%s'", name ? name : "(null)");
+    return EOD_EINVAL;
+}
+extern "C" int eod_get_option(const char* name) {
+    (void)opt(0);
+    for (int i = 0; name && i < OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_name[i])) return g_opt[i];
+    eod_set_error("get_option: unknown option '%s'", name ? name : "(null)");
+    return EOD_EINVAL;
 }
 
 template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32>
@@ -2176,43 +2142,27 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
 }
 
 template <typename T, bool CONV> static int launch_T(IgemmP& p, int batch, hipStream_t st) {
-    if constexpr (sizeof(T) == 2) {
-        if (halo_mfma_shape() == 16 && p.force_cfg != 2) {  // fp16 products on v_mfma_f32_16x16x32_f16
-            if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2, false, 16>(p, batch, st);
-            if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2, false, 16>(p, batch, st);
-            return launch_cfg<T, CONV, 128, 128, 2, 2, 2, false, 16>(p, batch, st);
-        }
+    if constexpr (sizeof(T) == 2) {  // fp16 products on v_mfma_f32_16x16x32_f16
+        if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2, false, 16>(p, batch, st);
+        if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2, false, 16>(p, batch, st);
+        return launch_cfg<T, CONV, 128, 128, 2, 2, 2, false, 16>(p, batch, st);
+    } else {                         // exact fp32: v_mfma_f32_32x32x2_f32
+        if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2>(p, batch, st);
+        if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2>(p, batch, st);
+        // (a 256x128 tile / 8 waves / 3-stage ring measured 0-5 % SLOWER than two co-resident 128x128 workgroups per CU)
+        return launch_cfg<T, CONV, 128, 128, 2, 2, 2>(p, batch, st);
     }
-    if (p.Ncols <= 32) return launch_cfg<T, CONV, 128, 32, 4, 1, 2>(p, batch, st);
-    if (p.Ncols <= 64) return launch_cfg<T, CONV, 128, 64, 4, 1, 2>(p, batch, st);
-    // 256x128 tile / 8 waves / 3-stage ring (144 KiB LDS, one workgroup per CU, DMA prefetched 2 K-steps deep) is kept
-    // as a tuning variant (EOD_IGEMM_CFG=2): measured 0-5 % SLOWER than two co-resident 128x128 workgroups per CU.
-    if (p.force_cfg == 2) return launch_cfg<T, CONV, 256, 128, 4, 2, 3>(p, batch, st);
-    return launch_cfg<T, CONV, 128, 128, 2, 2, 2>(p, batch, st);
 }
 
-static bool igemm_bn256() {  // EOD_HALO_BN256=0 switches the 8-wave 256-column forms off everywhere (A/B)
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EOD_HALO_BN256");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return on != 0;
-}
 // fp32 conv as the split-fp16 product on the generic kernel (1x1, stride 2, ragged maps)
 static int launch_conv_split(IgemmP& p, int batch, hipStream_t st) {
-    if (halo_mfma_shape() == 16) {
-        if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true, 16>(p, batch, st);
-        if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true, 16>(p, batch, st);
-        // 256 columns per 8-wave workgroup: the pixel rows of a K-step are fetched and split once for two N-tiles (these launches are
-        // bound by that in-place split: four pieces per wave against 48 MFMAs) -- the qkv / proj 1x1 convs of the attention blocks
-        if (p.Ncols % 256 == 0 && batch == 1 && ((p.M + 127) / 128) * (p.Ncols / 256) >= 256 && igemm_bn256())
-            return launch_cfg<float, true, 128, 256, 2, 4, 2, true, 16>(p, batch, st);
-        return launch_cfg<float, true, 128, 128, 2, 2, 2, true, 16>(p, batch, st);
-    }
-    if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true>(p, batch, st);
-    if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true>(p, batch, st);
-    return launch_cfg<float, true, 128, 128, 2, 2, 2, true>(p, batch, st);
+    if (p.Ncols <= 32) return launch_cfg<float, true, 128, 32, 4, 1, 2, true, 16>(p, batch, st);
+    if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true, 16>(p, batch, st);
+    // 256 columns per 8-wave workgroup: the pixel rows of a K-step are fetched and split once for two N-tiles (these launches are
+    // bound by that in-place split: four pieces per wave against 48 MFMAs) -- the qkv / proj 1x1 convs of the attention blocks
+    if (p.Ncols % 256 == 0 && batch == 1 && ((p.M + 127) / 128) * (p.Ncols / 256) >= 256 && opt(OPT_HALO_BN256))
+        return launch_cfg<float, true, 128, 256, 2, 4, 2, true, 16>(p, batch, st);
+    return launch_cfg<float, true, 128, 128, 2, 2, 2, true, 16>(p, batch, st);
 }
 
 // row length (elements) of tap-major packed weights: 9*C0 rounded up to whole 128-byte K-steps
@@ -2222,35 +2172,24 @@ extern "C" int eod_conv_tapmajor_ldk(int C0, int dtype) {
 }
 
 // which kernel configuration a conv descriptor gets (shared by the launcher and eod_conv_stats_slots)
-static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo, int force) {
+static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo) {
     // wide convs (128-column tiles) and the narrow NCHW-fp32 head conv (32-column tiles, 4x1 waves)
-    const bool shape_ok = ((d->Cout > 64 && !d->out_nchw_f32) || (d->Cout <= 32 && d->out_nchw_f32 && !d->upsample && force != 5)) && d->upsample != 2;
-    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 &&
-           shape_ok && !d->w_tapmajor && force != 3 && force != 2 && force != 1;
+    const bool shape_ok = ((d->Cout > 64 && !d->out_nchw_f32) || (d->Cout <= 32 && d->out_nchw_f32 && !d->upsample)) && d->upsample != 2;
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 && shape_ok && !d->w_tapmajor;
 }
-static bool halo_big(const eod_conv_desc* d, int Ho, int force) { return force == 4 && Ho % 16 == 0; }
-static int conv_waves_m(const eod_conv_desc* d, bool halo, int force) {
-    if (halo) return 2;
-    if (d->Cout <= 64) return 4;
-    return force == 2 ? 4 : 2;
-}
-static int conv_bm(const eod_conv_desc* d, bool halo, int force) { return (!halo && d->Cout > 64 && force == 2) ? 256 : 128; }
+static int conv_waves_m(const eod_conv_desc* d, bool halo) { return (halo || d->Cout > 64) ? 2 : 4; }
+static int conv_bm(const eod_conv_desc* d, bool halo) { return 128; }
 
 // 1 if this conv can run as the split-fp16 product (fp32 storage, weights packed by eod_pack_conv_weight_split): whole chunk
 // pairs (8 channels) per source; every kernel variant has it except the thin-input (tap-major) first conv
-static bool conv_split_ok(const eod_conv_desc* d, int Ho, int Wo, int force) {
+static bool conv_split_ok(const eod_conv_desc* d, int Ho, int Wo) {
     // (thin-input first conv: the K axis is [tap][C0] flattened and padded to whole K-steps, so its 8-k pairs always exist)
-    return d->dtype == EOD_F32 && (d->w_tapmajor || (d->C0 % 8 == 0 && d->C1 % 8 == 0)) && d->upsample != 2 && force != 7;
+    return d->dtype == EOD_F32 && (d->w_tapmajor || (d->C0 % 8 == 0 && d->C1 % 8 == 0)) && d->upsample != 2;
 }
-// zero-insertion upsampling through the four parity-class launches (see eod_conv2d_igemm); EOD_CONV_PARITY=0 keeps the single
-// full-grid launch that multiplies the inserted zeros (tuning / A-B only)
+// zero-insertion upsampling through the four parity-class launches (see eod_conv2d_igemm); other geometries keep the single full-grid
+// launch that multiplies the inserted zeros
 static bool conv_parity_ok(const eod_conv_desc* d, int Ho, int Wo) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EOD_CONV_PARITY");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return on && d->upsample == 2 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && !d->out_nchw_f32 && !d->stats &&
+    return d->upsample == 2 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && !d->out_nchw_f32 && !d->stats &&
            !d->w_tapmajor && !d->w_split && Ho % 2 == 0 && Wo % 2 == 0;
 }
 // upsample = 3: nearest-2x upsampling + 3x3 conv as four 2x2-tap parity classes with pre-summed weights (conv_up4_halo_kernel)
@@ -2258,7 +2197,7 @@ static bool conv_up4_ok(const eod_conv_desc* d) {
     const bool store_ok = d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
     return d->upsample == 3 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && d->C1 == 0 && !d->x2 && d->Cout > 64 &&
            d->Cout % 8 == 0 && d->C0 % 8 == 0 && d->W % 16 == 0 && d->H % 8 == 0 && !d->out_nchw_f32 && !d->w_tapmajor && !d->gn_scale_shift &&
-           store_ok && halo_mfma_shape() == 16;
+           store_ok;
 }
 extern "C" int eod_conv_up4_ok(const eod_conv_desc* d) { return d && conv_up4_ok(d) ? 1 : 0; }
 // upsample = 4: backward-data of the parity-class upsample conv (conv_up4_halo_kernel<BWD>): x = dY [N][H][W][C0] on the (2H' x 2W') grid,
@@ -2266,8 +2205,7 @@ extern "C" int eod_conv_up4_ok(const eod_conv_desc* d) { return d && conv_up4_ok
 static bool conv_up4_bwd_ok(const eod_conv_desc* d) {
     return d->upsample == 4 && d->dtype == EOD_F16 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && d->C1 == 0 && !d->x2 &&
            d->Cout > 64 && d->Cout % 8 == 0 && d->C0 % 8 == 0 && d->H % 2 == 0 && d->W % 2 == 0 && d->Ho == d->H / 2 && d->Wo == d->W / 2 &&
-           d->Wo % 16 == 0 && d->Ho % 8 == 0 && !d->out_nchw_f32 && !d->w_tapmajor && !d->gn_scale_shift && !d->stats && !d->w_split &&
-           halo_mfma_shape() == 16;
+           d->Wo % 16 == 0 && d->Ho % 8 == 0 && !d->out_nchw_f32 && !d->w_tapmajor && !d->gn_scale_shift && !d->stats && !d->w_split;
 }
 extern "C" int eod_conv_up4_bwd_ok(const eod_conv_desc* d) { return d && conv_up4_bwd_ok(d) ? 1 : 0; }
 static int conv_up4_bwd(const eod_conv_desc* d, void* stream) {
@@ -2287,52 +2225,34 @@ static int conv_up4_bwd(const eod_conv_desc* d, void* stream) {
 }
 // the UNet's output head on conv_head_kernel (EOD_HEAD=0: the 32-column halo instance, A/B)
 static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EOD_HEAD");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
+    const bool on = opt(OPT_HEAD) != 0;
     const bool store_ok = d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
     return on && halo_ok && d->out_nchw_f32 && d->Cout <= 16 && d->gn_scale_shift && d->C1 == 0 && !d->x2 && !d->upsample && !d->res && !d->cbias &&
-           !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C && halo_mfma_shape() == 16;
+           !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C;
 }
 // 256-column convs with a fused GroupNorm on the 8-wave instance that shares one patch between the two N-tiles (EOD_HALO_BN256=0: off, A/B)
 static bool halo_bn256(const eod_conv_desc* d) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EOD_HALO_BN256");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
+    const bool on = opt(OPT_HALO_BN256) != 0;
     // only where it still fills the chip: one 8-wave workgroup occupies a CU, so fewer than 256 of them leave CUs idle (32 x 32 maps at
     // batch 8: 128 workgroups, measured -20 %; the choice never changes a result: same K order, same MFMAs)
     const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * (d->Cout / 256);
-    return on && d->Cout % 256 == 0 && !d->upsample && wgs >= 256 && halo_mfma_shape() == 16;
+    return on && d->Cout % 256 == 0 && !d->upsample && wgs >= 256;
 }
-// 384, 640, ... columns: all but the last 128 on the 8-wave form, as a launch of its own (EOD_HALO_SPLIT_N=0: off)
+// 384, 640, ... columns: all but the last 128 on the 8-wave form, as a launch of its own
 static bool halo_bn256_plus128(const eod_conv_desc* d) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EOD_HALO_SPLIT_N");
-        const char* f = getenv("EOD_HALO_BN256");
-        on = ((e && atoi(e) == 0) || (f && atoi(f) == 0)) ? 0 : 1;
-    }
+    const bool on = opt(OPT_HALO_BN256) != 0;
     const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * ((d->Cout - 128) / 256);
-    return on && d->Cout > 256 && d->Cout % 256 == 128 && !d->upsample && wgs >= 256 && halo_mfma_shape() == 16;
+    return on && d->Cout > 256 && d->Cout % 256 == 128 && !d->upsample && wgs >= 256;
 }
 // ResBlock 1x1 skip conv fused behind the 3x3 K loop (conv3x3_halo_kernel<SKIP>; EOD_SKIP_FUSE=0: off, A/B)
 static bool conv_skip_geom_ok(const eod_conv_desc* d) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EOD_SKIP_FUSE");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
+    const bool on = opt(OPT_SKIP_FUSE) != 0;
     if (!on || !d || d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->upsample || d->pad_tl || d->C1 != 0 || d->x2 || d->res ||
-        d->out_nchw_f32 || d->w_tapmajor || d->Cout <= 64 || d->Cout % 8 || d->C0 % 8 || halo_mfma_shape() != 16)
+        d->out_nchw_f32 || d->w_tapmajor || d->Cout <= 64 || d->Cout % 8 || d->C0 % 8)
         return false;
     if (d->skip_C0 <= 0 || d->skip_C0 % 8 || d->skip_C1 < 0 || d->skip_C1 % 8) return false;
     const int Ho = d->H, Wo = d->W;
-    const int force = igemm_forced_cfg();
-    if (!conv_uses_halo(d, Ho, Wo, force) || halo_big(d, Ho, force)) return false;
+    if (!conv_uses_halo(d, Ho, Wo)) return false;
     return d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
 }
 extern "C" int eod_conv_skip_ok(const eod_conv_desc* d) { return conv_skip_geom_ok(d) ? 1 : 0; }
@@ -2341,7 +2261,7 @@ extern "C" int eod_conv_split_ok(const eod_conv_desc* d) {
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
     const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
-    return conv_split_ok(d, Ho, Wo, igemm_forced_cfg()) ? 1 : 0;
+    return conv_split_ok(d, Ho, Wo) ? 1 : 0;
 }
 
 // 1 if eod_conv2d_igemm can apply GroupNorm(+SiLU) to the conv INPUT on the fly (gn_scale_shift) for this geometry.
@@ -2352,21 +2272,17 @@ extern "C" int eod_conv_gn_fusable(const eod_conv_desc* d) {
     if (!d || d->upsample) return 0;
     const int Ho = (d->H + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (d->W + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
-    static int env_cout = -2;
-    if (env_cout == -2) {
-        const char* e = getenv("EOD_GN_FUSE_MAX_COUT");
-        env_cout = e ? atoi(e) : -1;
-    }
+    const int env_cout = opt(OPT_GN_FUSE_MAX_COUT);
     // measured (same-box A/B of bench.py): fp32 storage with the split product pays for the fusion at every width (a separate pass
     // moves 8 bytes per element; 384 / 512-wide layers: step -0.2 ms), fp16 storage up to 256 output channels
     const int max_cout = env_cout >= 0 ? env_cout : (d->w_split ? 512 : 256);
     if (d->Cout > max_cout) return 0;
-    return conv_uses_halo(d, Ho, Wo, igemm_forced_cfg()) ? 1 : 0;
+    return conv_uses_halo(d, Ho, Wo) ? 1 : 0;
 }
 
 // split-K factor of a conv that the generic kernel would run with too few workgroups to fill the chip (small maps)
-static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo, int force) {
-    if (halo || d->out_nchw_f32 || d->Cout % 4 || d->w_tapmajor || force == 6) return 1;
+static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo) {
+    if (halo || d->out_nchw_f32 || d->Cout % 4 || d->w_tapmajor) return 1;
     // the factor must NOT depend on the batch size: the K summation order of a sample has to be the same whether it is
     // computed alone or inside a larger batch (bit-exact batch-sharding invariance), so a nominal batch of 16 is used
     const long long M = 16LL * Ho * Wo;
@@ -2387,8 +2303,7 @@ extern "C" int64_t eod_conv_workspace_size(const eod_conv_desc* d) {
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
     const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
-    const int force = igemm_forced_cfg();
-    const int s = conv_splitk(d, Ho, Wo, conv_uses_halo(d, Ho, Wo, force), force);
+    const int s = conv_splitk(d, Ho, Wo, conv_uses_halo(d, Ho, Wo));
     return s > 1 ? (int64_t)s * d->N * Ho * Wo * d->Cout * 4 : 0;
 }
 
@@ -2398,12 +2313,11 @@ extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
     const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
-    const int force = igemm_forced_cfg();
-    const bool halo = conv_uses_halo(d, Ho, Wo, force);
-    if (conv_splitk(d, Ho, Wo, halo, force) > 1) return 0;  // split-K tiles are reduced by a second pass
-    const int bm = conv_bm(d, halo, force);
+    const bool halo = conv_uses_halo(d, Ho, Wo);
+    if (conv_splitk(d, Ho, Wo, halo) > 1) return 0;  // split-K tiles are reduced by a second pass
+    const int bm = conv_bm(d, halo);
     if ((Ho * Wo) % bm != 0) return 0;  // tiles must not straddle images
-    return (Ho * Wo / bm) * conv_waves_m(d, halo, force);
+    return (Ho * Wo / bm) * conv_waves_m(d, halo);
 }
 
 extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
@@ -2465,27 +2379,28 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.tapmajor_log2 = cpt == 1 ? 0 : cpt == 2 ? 1 : 2;
         p.ldk = eod_conv_tapmajor_ldk(d->C0, d->dtype);
     }
-    p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
-    // 3x3 / stride 1 / pad 1 on maps that tile into 8x16 patches: halo-patch kernel (EOD_IGEMM_CFG=3 disables it)
-    const bool halo_ok = conv_uses_halo(d, Ho, Wo, p.force_cfg);
+    // 3x3 / stride 1 / pad 1 on maps that tile into 8x16 patches: halo-patch kernel
+    const bool halo_ok = conv_uses_halo(d, Ho, Wo);
     if (d->stats) {
         const int slots = eod_conv_stats_slots(d);
         EOD_REQUIRE(slots > 0 && slots == d->stats_slots, "conv: stats_slots=%d but this geometry provides %d", d->stats_slots, slots);
         p.stats = d->stats;
         p.stats_P = slots;
-        p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok, p.force_cfg);
+        p.tiles_per_image = Ho * Wo / conv_bm(d, halo_ok);
     }
-    EOD_REQUIRE(!d->w_split || (conv_split_ok(d, Ho, Wo, p.force_cfg) && d->w_scale),
+    EOD_REQUIRE(!d->w_split || (conv_split_ok(d, Ho, Wo) && d->w_scale),
                 "conv: w_split needs a geometry for which eod_conv_split_ok(d) == 1 and the w_scale of eod_pack_conv_weight_split");
     p.w_scale = d->w_split ? d->w_scale : nullptr;
     p.a_bound = d->w_split ? d->a_bound : nullptr;
+    EOD_REQUIRE(!d->x_presplit || (d->w_split && d->a_bound && !halo_ok && !d->upsample && !d->w_tapmajor && !d->gn_scale_shift),
+                "conv: x_presplit needs w_split with the producer's bound table, on the generic kernel (1x1 / stride-2 / small maps)");
+    p.a_ps = d->x_presplit;
     p.skip_bound = (d->w_split && d->skip_x) ? d->skip_bound : nullptr;
     if (d->upsample == 3) {
         EOD_REQUIRE(conv_up4_ok(d), "conv: upsample = 3 (parity-class form of the nearest-2x conv) needs a geometry for which eod_conv_up4_ok(d) == 1");
         return d->dtype == EOD_F16 ? launch_up4<half_t, false>(p, st) : launch_up4<float, true>(p, st);
     }
-    const bool m16 = halo_mfma_shape() == 16;
     if (conv_head_ok(d, halo_ok)) {  // output head: GroupNorm + SiLU fused, <= 16 channels, NCHW fp32 (conv_head_kernel)
         p.gn_ss = d->gn_scale_shift;
         p.gn_silu = d->gn_silu;
@@ -2531,9 +2446,9 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
             EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
-            if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, true, true>(p, st);
-            if (m16 && halo_bn256(d)) return launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(p, st);
-            if (m16 && halo_bn256_plus128(d)) {
+            if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st);
+            if (halo_bn256(d)) return launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(p, st);
+            if (halo_bn256_plus128(d)) {
                 IgemmP q = p;
                 q.Ncols = d->Cout - 128;
                 const int rc = launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(q, st);
@@ -2541,13 +2456,13 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
                 p.n_base = d->Cout - 128;
                 return launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st);
             }
-            return m16 ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true, true>(p, st);
+            return launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st);
         }
-        if (d->Cout <= 32) return m16 ? launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st) : launch_halo<float, 32, 4, 1, false, 2, false, true>(p, st);
-        if (d->upsample) return m16 ? launch_halo<float, 128, 2, 2, true, 2, false, true, 16>(p, st) : launch_halo<float, 128, 2, 2, true, 2, false, true>(p, st);
-        return m16 ? launch_halo<float, 128, 2, 2, false, 2, false, true, 16>(p, st) : launch_halo<float, 128, 2, 2, false, 2, false, true>(p, st);
+        if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st);
+        if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false, true, 16>(p, st);
+        return launch_halo<float, 128, 2, 2, false, 2, false, true, 16>(p, st);
     }
-    if (halo_ok && d->dtype == EOD_F16 && m16 && !halo_big(d, Ho, p.force_cfg)) {
+    if (halo_ok && d->dtype == EOD_F16) {
         if (d->gn_scale_shift) {
             EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
             p.gn_ss = d->gn_scale_shift;
@@ -2560,29 +2475,19 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         if (d->upsample) return launch_halo<half_t, 128, 2, 2, true, 2, false, false, 16>(p, st);
         return launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16>(p, st);
     }
-    if (halo_ok) {
-        if (d->Cout <= 32) {  // head conv (out_nchw_f32): HBM-bound, the patch removes the 9x re-gather of the input
-            if (d->gn_scale_shift) {
-                p.gn_ss = d->gn_scale_shift;
-                p.gn_silu = d->gn_silu;
-                return d->dtype == EOD_F16 ? launch_halo<half_t, 32, 4, 1, false, 2, true>(p, st) : launch_halo<float, 32, 4, 1, false, 2, true>(p, st);
-            }
-            return d->dtype == EOD_F16 ? launch_halo<half_t, 32, 4, 1, false, 2, false>(p, st) : launch_halo<float, 32, 4, 1, false, 2, false>(p, st);
-        }
+    if (halo_ok) {  // exact fp32 (v_mfma_f32_32x32x2_f32 on the same byte-oriented LDS image)
         if (d->gn_scale_shift) {  // GroupNorm(+SiLU) of the input fused into the patch staging
             EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
-            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false, 2, true>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true>(p, st);
+            return d->Cout <= 32 ? launch_halo<float, 32, 4, 1, false, 2, true>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true>(p, st);
         }
-        if (halo_big(d, Ho, p.force_cfg) && !d->upsample && !d->stats)  // tuning variant: 16x16 tile, 8 waves, 3-stage weight ring
-            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 4, 2, false, 3, false>(p, st) : launch_halo<float, 128, 4, 2, false, 3, false>(p, st);
-        if (d->upsample)
-            return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, true, 2, false>(p, st) : launch_halo<float, 128, 2, 2, true, 2, false>(p, st);
-        return d->dtype == EOD_F16 ? launch_halo<half_t, 128, 2, 2, false, 2, false>(p, st) : launch_halo<float, 128, 2, 2, false, 2, false>(p, st);
+        if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false>(p, st);  // head conv (out_nchw_f32)
+        if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false>(p, st);
+        return launch_halo<float, 128, 2, 2, false, 2, false>(p, st);
     }
     EOD_REQUIRE(!d->gn_scale_shift, "conv: fused input GroupNorm needs the halo-patch kernel (ask eod_conv_gn_fusable first)");
-    const int splitk = conv_splitk(d, Ho, Wo, false, p.force_cfg);
+    const int splitk = conv_splitk(d, Ho, Wo, false);
     if (splitk > 1) {
         // small maps: too few output tiles to fill 256 CUs -> split the K loop over gridDim.y workgroups (fp32 partial
         // tiles in the caller's workspace), then one deterministic reduce + bias/residual pass
@@ -2659,11 +2564,10 @@ extern "C" int eod_gemm_nt(const eod_gemm_desc* d, void* stream) {
     p.M = d->M; p.Ncols = d->N; p.K = d->K;
     p.taps = 1;
     p.alpha = d->alpha;
-    p.force_cfg = igemm_forced_cfg();
     hipStream_t st = (hipStream_t)stream;
     const int batch = d->nb0 * d->nb1;
     if (d->x3) {  // fp32 operands, every product as three fp16 MFMAs on operands split in LDS (the fp32x3 mode's attention GEMMs)
-        EOD_REQUIRE(d->dtype == EOD_F32 && d->K % 8 == 0 && halo_mfma_shape() == 16, "gemm: x3 needs fp32 operands and K %% 8 == 0");
+        EOD_REQUIRE(d->dtype == EOD_F32 && d->K % 8 == 0, "gemm: x3 needs fp32 operands and K %% 8 == 0");
         p.a_bound = d->a_bound;
         p.b_bound = d->b_bound;
         if (p.Ncols <= 32) return launch_cfg<float, false, 128, 32, 4, 1, 2, true, 16>(p, batch, st);

@@ -286,13 +286,28 @@ extern "C" int eod_act_bound(const void* x, int dtype, int N, int64_t per_image,
 // apply: y[n][pix][coff + c] = act(x[n][pix][c] * scale[n][coff+c] + shift[n][coff+c])
 // slab decomposition of common.h (gn_slab); y rows are Ctot wide (materialises the concat, normalised).
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool SILU>
+// SPLIT (fp32 storage): y is written PRE-SPLIT for a split-fp16 consumer (eod_conv_desc.x_presplit): the two threads that own the
+// 16-byte chunks of one 8-channel group (lanes l, l ^ 1: blockDim.x is even) exchange halves through DPP, exactly like the in-LDS
+// rewrite of the conv kernels (igemm.hip: split_pair_exchange), scaled by the image's power-of-two s from the bound table.
+template <typename T, bool SILU, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int HW, int C, const float* __restrict__ ss, int Ctot,
-                                                      int coff, T* __restrict__ y, int per) {
+                                                      int coff, T* __restrict__ y, int per, const float* __restrict__ ab = nullptr) {
     constexpr int EPC = dt<T>::epc, U = 4;
     constexpr bool FAST = (EPC == 8);
     const int tx = threadIdx.x, ty = threadIdx.y, RY = blockDim.y;
     const int n = blockIdx.y;
+    float osc = 1.0f;
+    if constexpr (SPLIT) {  // (before any thread leaves: the table maximum is a wave-wide reduction)
+        const int lin = ty * blockDim.x + tx;
+        float b = 0.0f;
+        if ((lin & 63) < EOD_AB) {
+            b = ab[(long long)n * EOD_AB + (lin & 63)];
+            b = (b == b) ? b : __uint_as_float(0x7f800000u);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o));
+        osc = ab_scale_of(__shfl(b, 0)).s;
+    }
     const int col = blockIdx.z * blockDim.x + tx;  // chunk column of this thread (channel blocks along z for wide layers)
     if (col >= C / EPC) return;
     const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
@@ -334,6 +349,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                     o[e] = v;
                 }
                 outv = __builtin_bit_cast(i32x4, o);
+                if constexpr (SPLIT) {
+                    half4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o[e] * osc;
+                        h[e] = (half_t)v;
+                        l[e] = (half_t)(v - (float)h[e]);
+                    }
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    const i32x2 hb = __builtin_bit_cast(i32x2, h), lb = __builtin_bit_cast(i32x2, l);
+                    const bool odd = (col & 1) != 0;  // the even chunk of a pair keeps [hi_even | hi_odd], the odd one [lo_even | lo_odd]
+                    const int s0 = odd ? hb[0] : lb[0], s1 = odd ? hb[1] : lb[1];
+                    const int r0 = __builtin_amdgcn_mov_dpp(s0, 0xB1, 0xF, 0xF, true), r1 = __builtin_amdgcn_mov_dpp(s1, 0xB1, 0xF, 0xF, true);
+                    outv = odd ? i32x4{r0, r1, lb[0], lb[1]} : i32x4{hb[0], hb[1], r0, r1};
+                }
             }
             *reinterpret_cast<i32x4*>(yb + (long long)(pix + u * RY) * Ctot) = outv;
         }
@@ -341,15 +371,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 }
 
 extern "C" int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot, int coff,
-                            int silu, void* y, void* stream) {
+                            int silu, void* y, const float* split_bound, void* stream) {
     EOD_REQUIRE(x && y && scale_shift && N > 0 && HW > 0 && C > 0, "gn_apply: bad args");
     const int epc = 16 / eod_esize(dtype);
     EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_apply: channel alignment");
     EOD_REQUIRE(N <= 65535, "gn_apply: N=%d unsupported", N);
     EOD_REQUIRE(eod_aligned16(x) && eod_aligned16(y), "gn_apply: alignment");
-    const GnSlab g = gn_slab(N, HW, C, epc, 4);
-    const dim3 grid(g.P, N, g.nz), block(g.cpp, g.ry);
+    GnSlab g = gn_slab(N, HW, C, epc, 4);
     hipStream_t st = (hipStream_t)stream;
+    if (split_bound) {
+        EOD_REQUIRE(dtype == EOD_F32 && C % 8 == 0 && Ctot % 8 == 0 && coff % 8 == 0, "gn_apply: split_out needs fp32 storage and whole 8-channel groups");
+        if (g.cpp & 1) {  // the two chunks of an 8-channel group must sit in neighbouring lanes
+            g.cpp += 1;
+            g.ry = 256 / g.cpp > 0 ? 256 / g.cpp : 1;
+            const int quantum = g.ry * 4;
+            g.per = (g.per + quantum - 1) / quantum * quantum;
+            g.P = (HW + g.per - 1) / g.per;
+        }
+        const dim3 grid(g.P, N, g.nz), block(g.cpp, g.ry);
+        if (silu) hipLaunchKernelGGL((gn_apply_kernel<float, true, true>), grid, block, 0, st, (const float*)x, HW, C, scale_shift, Ctot, coff, (float*)y, g.per, split_bound);
+        else hipLaunchKernelGGL((gn_apply_kernel<float, false, true>), grid, block, 0, st, (const float*)x, HW, C, scale_shift, Ctot, coff, (float*)y, g.per, split_bound);
+        EOD_CHECK_LAUNCH("gn_apply");
+        return EOD_OK;
+    }
+    const dim3 grid(g.P, N, g.nz), block(g.cpp, g.ry);
 #define LAUNCH(T, S) hipLaunchKernelGGL((gn_apply_kernel<T, S>), grid, block, 0, st, (const T*)x, HW, C, scale_shift, Ctot, coff, (T*)y, g.per)
     if (dtype == EOD_F16) {
         if (silu) LAUNCH(half_t, true); else LAUNCH(half_t, false);

@@ -38,12 +38,14 @@ def require_gpu(t, what):
 
 class Act:
     """Channels-last activation handle: tensor of shape [N, H, W, C] in the storage dtype."""
-    __slots__ = ("t", "N", "H", "W", "C", "stats", "bound")
+    __slots__ = ("t", "N", "H", "W", "C", "stats", "bound", "presplit")
 
     def __init__(self, t, N, H, W, C, stats=None):
         self.t, self.N, self.H, self.W, self.C = t, N, H, W, C
         self.stats = stats  # (fp32 tensor [N][P][C][2], P): GroupNorm partial sums emitted by the producing conv
         self.bound = None   # fp32x3 programs: bound table [N][32] of this tensor once something has produced one (Program.bound_of)
+        self.presplit = False  # fp32x3: the tensor holds [8 x fp16 hi | 8 x fp16 lo] groups of s_n * x (s_n from `bound`), for ONE
+        #                        split-fp16 consumer on the generic conv kernel (eod_conv_desc.x_presplit); nothing else can read it
 
     @property
     def HW(self):
@@ -172,7 +174,7 @@ class Program:
         cout, cin = w.shape[0], w.shape[1]
         assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3
         ldk = self.L.eod_conv_tapmajor_ldk(cin_pad, self.dt)
-        if self.split and os.environ.get("EOD_FIRST_X3", "1") != "0":  # fp32x3 program: split-fp16 pairs + device scale (conv() sets w_split)
+        if self.split:  # fp32x3 program: split-fp16 pairs + device scale (conv() sets w_split)
             dst, scale = self.empty((cout, ldk), torch.float32), self.empty((2,), torch.float32)
             check(self.L.eod_pack_conv_weight_tapmajor_split(ptr(w), ptr(dst), ptr(scale), cout, cin, cin_pad,
                                                              current_stream_ptr(self.device)), "pack_conv_weight_tapmajor_split")
@@ -320,6 +322,9 @@ class Program:
         d.ksize, d.stride, d.pad, d.upsample, d.pad_tl = ksize, stride, pad, int(upsample), int(pad_tl)
         d.Ho, d.Wo, d.out_nchw_f32, d.alpha = ho, wo, int(out_nchw_f32), 1.0
         d.w_tapmajor = int(w_tapmajor)
+        if x.presplit or (x2 is not None and x2.presplit):
+            assert self.split and gn is None and skip is None and (x2 is None or x2.presplit == x.presplit), "pre-split input: plain split conv only"
+            d.x_presplit = 1
         if skip is not None:
             ssrc, sw, sb = skip
             assert res is None and x2 is None and self.conv_skip_ok(x, cout, ssrc), "fused skip conv: ask conv_skip_ok first"
@@ -352,6 +357,7 @@ class Program:
         if d.w_split:
             assert ab is not None and (skip is None or ab_skip is not None), "fp32x3: no bound table for this conv input"
             d.a_bound, d.skip_bound = ptr(ab), ptr(ab_skip)
+        assert not d.x_presplit or d.w_split, "a pre-split tensor needs the split-fp16 conv (channel counts that are multiples of 8)"
         wsz = self.L.eod_conv_workspace_size(C.byref(d))
         if wsz > 0:  # split-K partial tiles (small maps)
             ws = self.empty((wsz // 4,), torch.float32)
@@ -391,7 +397,7 @@ class Program:
         d.sa0, d.sa1, d.sb0, d.sb1, d.sc0, d.sc1 = sa[0], sa[1], sb[0], sb[1], sc[0], sc[1]
         d.dtype, d.M, d.N, d.K, d.nb0, d.nb1 = self.dt, M, N, K, nb0, nb1
         d.bias_mode, d.c_f32, d.alpha = (bias_mode if bias is not None else 0), int(c_f32), alpha
-        d.x3 = int(self.split and K % 8 == 0 and os.environ.get("EOD_GEMM_X3", "1") != "0")  # fp32x3 mode: split-fp16 products
+        d.x3 = int(self.split and K % 8 == 0)  # fp32x3 mode: split-fp16 products
         if d.x3:
             for t in (a_bound, b_bound):
                 assert t is None or tuple(t.shape) == (nb0, AB), "gemm: bound tables are [nb0][32]"
@@ -458,23 +464,28 @@ class Program:
         ss.eod_bound_norm = ab_norm
         return ss
 
-    def gn_apply(self, srcs, ss, *, silu):
-        """y = act(x*scale + shift) as a separate pass; materialises the (normalised) concat of `srcs`."""
+    def gn_apply(self, srcs, ss, *, silu, split_out=False):
+        """y = act(x*scale + shift) as a separate pass; materialises the (normalised) concat of `srcs`.  split_out (fp32x3): y is
+        written PRE-SPLIT for its one consumer, a split-fp16 conv on the generic kernel (the qkv projection behind AttentionBlock.norm):
+        that conv then DMAs finished [hi | lo] rows into LDS instead of re-splitting its pixel rows every K-step."""
         x0 = srcs[0]
         N, H, W = x0.N, x0.H, x0.W
         ctot = sum(s.C for s in srcs)
         y = self.act(N, H, W, ctot)
         y.bound = getattr(ss, "eod_bound_norm", None)  # (|SiLU(v)| <= |v|: the table holds with and without the activation)
+        split_out = bool(split_out and self.split and y.bound is not None and ctot % 8 == 0 and all(s.C % 8 == 0 for s in srcs))
+        y.presplit = split_out
         coff = 0
         for s in srcs:
-            self._small(OP_GN_APPLY, p=(ptr(s.t), ptr(ss), ptr(y.t)), i=(self.dt, N, H * W, s.C, ctot, coff, int(silu)))
+            self._small(OP_GN_APPLY, p=(ptr(s.t), ptr(ss), ptr(y.t), ptr(y.bound) if split_out else 0),
+                        i=(self.dt, N, H * W, s.C, ctot, coff, int(silu)))
             coff += s.C
         return y
 
-    def group_norm(self, srcs, gamma, beta, *, silu, eps=1e-5, groups=32, film=None, film_stride=0):
-        """GroupNorm32 [+FiLM] [+SiLU] as stats + separate apply pass (returns the normalised Act)."""
+    def group_norm(self, srcs, gamma, beta, *, silu, eps=1e-5, groups=32, film=None, film_stride=0, split_out=False):
+        """GroupNorm32 [+FiLM] [+SiLU] as stats + separate apply pass (returns the normalised Act; split_out: see gn_apply)."""
         ss = self.gn_stats(srcs, gamma, beta, eps=eps, groups=groups, film=film, film_stride=film_stride)
-        return self.gn_apply(srcs, ss, silu=silu)
+        return self.gn_apply(srcs, ss, silu=silu, split_out=split_out)
 
     def attention(self, qk, vT, out, N, T, Cc, heads, d, dpad, ld_qk, ldt, k_off, lse=None):
         """fused flash-style attention (fp16, head dim <= 64): eod_attention_fwd; lse: optional fp32 [N][heads][T] output"""
@@ -485,10 +496,11 @@ class Program:
         a.dtype, a.N, a.T, a.C, a.heads, a.d, a.dpad, a.k_off = self.dt, N, T, Cc, heads, d, dpad, k_off
         return idx
 
-    def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None, qkv_bound=None):
+    def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None, qkv_bound=None, out_presplit=False):
         """fused attention on the natural qkv layout [N][T][3C] (head dim % 8 == 0 and <= 64, any T): eod_attention_fwd_nat.  fp32 storage
-        (fp32x3): qkv_bound = bound table [N][32] of qkv (None: |q|, |k|, |v| < 4094 guaranteed by the caller)"""
-        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse), ptr(qkv_bound)),
+        (fp32x3): qkv_bound = bound table [N][32] of qkv (None: |q|, |k|, |v| < 4094 guaranteed by the caller); out_presplit: `out` is
+        written pre-split (scale from qkv_bound) for the proj_out conv"""
+        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse), ptr(qkv_bound)), l=(int(out_presplit),),
                            i=(self.dt, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride))
 
     def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):
@@ -611,7 +623,7 @@ class Program:
                 halo = geo and d.Cout > 64 and not d.out_nchw_f32 and not d.w_tapmajor  # mirrors conv_uses_halo() in csrc/igemm.hip
                 head = geo and d.Cout <= 32 and d.out_nchw_f32 and not d.upsample  # 32-column instance (HBM-bound head conv)
                 headk = head and bool(d.gn_scale_shift) and d.Cout <= 16 and d.C1 == 0 and cin <= 384 and self.precision != "fp32" \
-                    and os.environ.get("EOD_HEAD", "1") != "0"  # mirrors conv_head_ok()
+                    and self.L.eod_get_option(b"head") != 0  # mirrors conv_head_ok()
                 up4 = d.upsample == 3  # parity-class form of the nearest-2x conv: the algorithm's 9 taps are executed as 4 (pre-summed)
                 out.append(dict(kind="conv", flops=fl, bytes=by, exec_flops=fl * (4.0 / 9.0 if up4 else 1.0),
                                 kernel="conv_up4_halo_kernel" if up4 else "conv3x3_halo_kernel" if halo else

@@ -31,6 +31,12 @@ enum { EOD_F32 = 0, EOD_F16 = 1 };
 
 const char* eod_last_error(void);
 int eod_version(void);
+/* Kernel-selection options ("skip_fuse", "head", "halo_bn256": 1 / 0; "gn_fuse_max_cout": n, -1 = default): every option has one
+ * measured-best default, the other arm computes the same function on another kernel (same-box A/B runs, per-switch parity tests).
+ * Read from the environment (EOD_SKIP_FUSE, EOD_HEAD, EOD_HALO_BN256, EOD_GN_FUSE_MAX_COUT) at first use; returns the previous value,
+ * or EOD_EINVAL for an unknown name.  Plans built before a change keep the kernels they were built with. */
+int eod_set_option(const char* name, int value);
+int eod_get_option(const char* name);
 /* sizeof() of the descriptor structs as compiled (1 conv, 2 gemm, 3 temb, 4 small, 5 op): lets a
  * foreign-language binding verify its mirror of the layouts at load time. */
 int eod_struct_size(int kind);
@@ -105,6 +111,10 @@ typedef struct {
     int32_t skip_C0, skip_C1;
     const float* skip_bound; /* w_split: bound table [N][32] of skip_x | skip_x2 (see a_bound; the launch runs on the smaller of the two
                             scales because both phases feed one accumulator); NULL = |element| < 4094 guaranteed */
+    int32_t x_presplit;  /* w_split, generic-kernel geometries (1x1, stride 2): x | x2 are PRE-SPLIT -- 4 bytes per element, every 8
+                            channels as [8 x fp16 hi | 8 x fp16 lo] of s_n * x with s_n = the power-of-two scale that a_bound gives for
+                            image n -- written by a producer that knew the bound beforehand (eod_gn_apply split_out, the fp32-storage
+                            attention).  The conv DMAs the rows straight into its LDS image: no split pass per K-step. */
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
@@ -209,7 +219,9 @@ int eod_gn_finalize(const float* part0, int P0, int C0, const float* part1, int 
 int eod_act_bound(const void* x, int dtype, int N, int64_t per_image, const float* part0, int P0, int C0, const float* part1, int P1,
                   int C1, float* ab, int accumulate, void* stream);
 int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot,
-                 int coff, int silu, void* y, void* stream);
+                 int coff, int silu, void* y, const float* split_bound, void* stream);
+/* split_bound (EOD_F32, C / Ctot / coff multiples of 8): write y PRE-SPLIT for a split-fp16 consumer (eod_conv_desc.x_presplit):
+ * [8 x fp16 hi | 8 x fp16 lo] per 8 channels of s_n * y, s_n from this bound table [N][32] (eod_gn_finalize's ab_norm). NULL = plain. */
 
 /* ------------------------------------------------------------------------------------------
  * k8: fused ("flash"-style) QKVAttention / QKVAttentionLegacy forward (unet_openai.py:465-481, 497-515):
@@ -429,8 +441,10 @@ int eod_scale_f32(float* x, int64_t n, float s, void* stream);
  *   EOD_F32: fp32 in / out, fp32 online softmax, both contractions as three fp16 MFMAs per product on operands split into
  *            hi + lo halves (fp32-grade, ~2^-22 per product; csrc/attn_x3.hip) */
 int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off, int k_off,
-                          int v_off, int head_stride, const float* qkv_bound, void* stream);
-/* qkv_bound (EOD_F32 only): bound table [N][32] of the qkv tensor (eod_conv_desc.a_bound); NULL = |q|, |k|, |v| < 4094 guaranteed */
+                          int v_off, int head_stride, const float* qkv_bound, int out_presplit, void* stream);
+/* qkv_bound (EOD_F32 only): bound table [N][32] of the qkv tensor (eod_conv_desc.a_bound); NULL = |q|, |k|, |v| < 4094 guaranteed.
+ * out_presplit (EOD_F32 only): `out` is written pre-split for a split-fp16 conv (eod_conv_desc.x_presplit with a_bound = qkv_bound:
+ * rows of out are convex combinations of v rows, so the table of qkv bounds them). */
 /* flash-style attention backward (fp16, head dim a multiple of 8 and <= 64, any T): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /
  * k_off / v_off + head*head_stride + j), dO [N][T][C], the forward's log-sum-exp lse [N][heads][T] (eod_attn_desc.lse) and
  * D[n][h][t] = sum_j dO*O (eod_rowdot).  P is rebuilt tile by tile in registers: nothing T x T touches HBM (csrc/attn_bwd.hip) */

@@ -331,3 +331,47 @@ def test_ldm_p_sample_loop_vs_reference_trajectory():
     m = _ldm_with_model_py_tables(u, 20)
     out = m.p_sample_loop((2, 3, 16, 16), x_T=g["x_T"], noises=list(g["noises"])).cpu()
     assert rel_l2(out, g["out"]) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ every kernel-selection switch, both arms
+SWITCHES = ["up4", "skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout"]
+
+
+@pytest.mark.parametrize("prec", ["fp32x3", "fp16"])
+@pytest.mark.parametrize("switch", SWITCHES)
+def test_a0_256_forward_with_each_kernel_switch_off(prec, switch, monkeypatch):
+    """Every kernel-selection switch has one default arm (what the other tests of this file run) and one alternative arm that
+    computes the same function on other kernels: EOD_UP4=0 (nine-tap convs behind an upsampling), skip_fuse=0 (1x1 skip convs as
+    launches of their own), head=0 (the output head on the 32-column halo instance), halo_bn256=0 (256- / 512-column convs on two 4-wave
+    workgroups), gn_fuse_max_cout=0 (every GroupNorm as a separate pass).  Each alternative arm is held to the SAME oracle gate at the
+    metric's image size, and the launch program is checked to really differ from the default one."""
+    from eo_diffusion_amd import _lib
+    L = _lib.lib()
+    x, t, ref, *_ = _a0_256_oracle()
+
+    def program_signature(u):
+        prog = u.program_for(2, 3, 0, 256, 256, torch.device(DEV), False)
+        st = prog.op_stats()
+        return (len(st), tuple(s.get("kernel", s["kind"]) for s in st))
+
+    base = _unet("A0", 256, prec).to(DEV).eval()
+    sig0 = program_signature(base)
+    prev = None
+    try:
+        if switch == "up4":
+            monkeypatch.setenv("EOD_UP4", "0")
+        else:
+            assert L.eod_get_option(switch.encode()) == (-1 if switch == "gn_fuse_max_cout" else 1), "the test expects the default arm"
+            prev = L.eod_set_option(switch.encode(), 0)
+        u = _unet("A0", 256, prec).to(DEV).eval()
+        sig1 = program_signature(u)
+        if switch != "halo_bn256":  # (that one changes the instance inside eod_conv2d_igemm, not the op list)
+            assert sig1 != sig0, f"{switch}=0 did not change the launch program"
+        with torch.no_grad():
+            out = u(x.to(DEV), t.to(DEV)).cpu()
+    finally:
+        if prev is not None:
+            L.eod_set_option(switch.encode(), prev)
+    err = rel_l2(out, ref)
+    print(f"A0@256 forward [{prec}] with {switch}=0: rel-L2 = {err:.3e}")
+    assert err < TOL[prec]

@@ -261,7 +261,7 @@ def test_attention_qkv_of_any_magnitude(kind, T, heads, d):
     ab = torch.zeros((N, 32), dtype=torch.float32, device=DEV)
     st = current_stream_ptr(torch.device(DEV))
     _lib.check(L.eod_act_bound(qd.data_ptr(), _lib.EOD_F32, N, T * 3 * C, 0, 0, 0, 0, 0, 0, ab.data_ptr(), 0, st), "act_bound")
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), 0, _lib.EOD_F32, N, T, C, heads, d, 0, d, 2 * d, hs, ab.data_ptr(), st),
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), 0, _lib.EOD_F32, N, T, C, heads, d, 0, d, 2 * d, hs, ab.data_ptr(), 0, st),
                "attention_fwd_nat")
     torch.cuda.synchronize()
     got = out.cpu()
@@ -364,3 +364,31 @@ def test_no_clip_sampling_whose_x_t_exceeds_4094():
     err = rel_per_image(out, ref)
     print(f"20 no-clip DDPM steps, max|x_t| {min(float(s.abs().max()) for s in states):.3g} .. {max(float(s.abs().max()) for s in states):.3g}: rel-L2 = {err:.3e}")
     assert err < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ pre-split producers
+@pytest.mark.parametrize("kind", ["heavy", "mixed", "huge", "per_image"])
+@pytest.mark.parametrize("case", [(2, 128, 16, 16, 384), (1, 384, 64, 64, 1152), (3, 96, 7, 9, 40)])
+def test_groupnorm_written_presplit_feeds_a_1x1_conv(kind, case):
+    """AttentionBlock.norm -> qkv (unet_openai.py:427-428, 414): the normalising pass writes its output PRE-SPLIT ([8 x hi | 8 x lo] per
+    8 channels, scaled per image from the finalize's bound table) and the 1x1 conv DMAs those rows straight into its LDS image
+    (eod_conv_desc.x_presplit) -- same result as the float64 GroupNorm + conv, for a residual stream of any magnitude"""
+    N, C, H, W, Cout = case
+    x = adversarial(kind, f"ps{case}", (N, C, H, W), 85)
+    w = synth_input(f"dompw{case}", (Cout, C, 1, 1), 85, scale=1.0 / math.sqrt(C))
+    b = synth_input("dompb", (Cout,), 85, scale=0.1)
+    gam = 1.0 + 0.2 * synth_input("dompg", (C,), 85)
+    bet = 0.1 * synth_input("dompbt", (C,), 85)
+
+    def build(prog):
+        a = Act(nhwc(prog, x), N, H, W, C)
+        xn = prog.group_norm([a], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV)), silu=False, split_out=True)
+        assert xn.presplit and xn.bound is not None
+        y, i = prog.conv(xn, prog.pack_conv(w.to(DEV)), prog.f32(b.to(DEV)), Cout, ksize=1, stride=1, pad=0)
+        d = prog.ops[i].u.conv
+        assert d.w_split == 1 and d.x_presplit == 1 and d.a_bound
+        return y
+
+    got, _ = run(build)
+    ref = F.conv2d(F.group_norm(x.double(), 32, gam.double(), bet.double(), eps=1e-5), w.double(), b.double())
+    assert rel_per_image(got, ref) < GATE

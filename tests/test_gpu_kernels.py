@@ -93,7 +93,7 @@ def test_conv3x3_with_fused_1x1_skip_vs_torch(prec, gn, case):
     to_act = lambda t: Act(prog.own(t.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), t.shape[0], H, W, t.shape[1])
     ah, axs = to_act(h), [to_act(t) for t in xs]
     if not prog.conv_skip_ok(ah, Cout, axs):
-        pytest.skip("fused skip conv not available in this configuration (EOD_SKIP_FUSE=0 / EOD_MFMA_SHAPE=32)")
+        pytest.skip("fused skip conv not available in this configuration (EOD_SKIP_FUSE=0)")
     g = (prog.gn_stats([ah], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True) if gn else None
     y, _ = prog.conv(ah, prog.pack_conv(w3.to(DEV)), prog.f32(b3.to(DEV)), Cout, gn=g, stats=True, skip=(axs, w1.to(DEV), b1.to(DEV)))
     prog.run()
@@ -175,7 +175,7 @@ def test_conv_nearest_upsample_parity_class_form_vs_torch(prec, gn, case):
     bet = 0.1 * synth_input("u4e", (Cout,), 43)
 
     def emit(prog, a):
-        if os.environ.get("EOD_MFMA_SHAPE") == "32" or os.environ.get("EOD_UP4") == "0":
+        if os.environ.get("EOD_UP4") == "0":
             pytest.skip("the parity-class kernels are switched off by the environment (A/B run)")
         assert prog.conv_up4_ok(a, Cout)
         y, _ = prog.conv(a, prog.pack_conv_up4(w.to(DEV)), prog.f32(b.to(DEV)), Cout, ksize=3, stride=1, pad=1, upsample="up4", stats=True)
@@ -507,7 +507,7 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits
     qd = qh.to(DEV)
     out = torch.empty((N * T, C), dtype=torch.float16, device=DEV)
     lse = torch.empty((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, st),
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0, st),
                "attention_fwd_nat")
     assert rel_l2(out.float().cpu().reshape(N, T, C), O.detach()) < 3e-3
     lse_ref = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) / math.sqrt(d), -1)
@@ -548,7 +548,7 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
     qd = qkv.to(DEV)
     out = torch.full((N, T, C), 9.0, dtype=torch.float16, device=DEV)
     lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0,
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0,
                                        current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu(), ref) < 3e-3
@@ -581,7 +581,7 @@ def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, boun
     if bound:
         _lib.check(L.eod_act_bound(qd.data_ptr(), _lib.EOD_F32, N, T * 3 * C, 0, 0, 0, 0, 0, 0, ab.data_ptr(), 0, st), "act_bound")
     _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F32, N, T, C, heads, d, qo, ko, vo, hs,
-                                       ab.data_ptr() if bound else 0, st), "attention_fwd_nat")
+                                       ab.data_ptr() if bound else 0, 0, st), "attention_fwd_nat")
     torch.cuda.synchronize()
     if bound:
         assert torch.equal(ab.cpu().max(1).values, qkv.abs().amax((1, 2)))  # the direct pass is the exact max|x| per image
@@ -712,7 +712,7 @@ def test_conv_nearest_upsample_parity_class_backward_data_vs_autograd(case):
     def emit(prog, a):  # a = dY as the program's input activation
         L = prog.L
         st = current_stream_ptr(prog.device)
-        if os.environ.get("EOD_MFMA_SHAPE") == "32" or os.environ.get("EOD_UP4") == "0":
+        if os.environ.get("EOD_UP4") == "0":
             pytest.skip("the parity-class kernels are switched off by the environment (A/B run)")
         assert prog.conv_up4_bwd_ok(a, Cx)
         wd_ = w.to(DEV).contiguous()

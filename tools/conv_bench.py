@@ -27,6 +27,12 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, upsample)
     "dn_256": (16, 128, 128, 256, 256, 3, 2, False),
     "head_128": (16, 256, 256, 128, 3, 3, 1, False),   # output head: NCHW fp32 output (use with --gn: conv_head_kernel)
     "head_192": (16, 128, 128, 192, 3, 3, 1, False),
+    "qkv_384": (8, 64, 64, 384, 1152, 1, 1, False),    # A1 attention blocks at T = 4096: qkv and proj_out 1x1 convs
+    "proj_384": (8, 64, 64, 384, 384, 1, 1, False),
+    "qkv_512": (8, 32, 32, 512, 1536, 1, 1, False),
+    "proj_512": (8, 32, 32, 512, 512, 1, 1, False),
+    "dn_384": (16, 64, 64, 384, 384, 3, 2, False),
+    "first_3": (16, 256, 256, 4, 128, 3, 1, False),
 }
 
 def main():
@@ -37,6 +43,7 @@ def main():
     ap.add_argument("--gn", action="store_true")
     ap.add_argument("--up4", action="store_true", help="upsample shapes through conv_up4_halo_kernel")
     ap.add_argument("--batch", type=int, default=0, help="override the batch size of the shapes (default 16)")
+    ap.add_argument("--presplit", action="store_true", help="fp32x3, 1x1 shapes: the input comes PRE-SPLIT from a normalising pass (the qkv conv behind AttentionBlock.norm)")
     a = ap.parse_args()
     dev = "cuda:0"
     for name in a.shapes.split(","):
@@ -48,6 +55,8 @@ def main():
         w = prog.pack_conv(torch.randn((Cout, Cin, k, k), device=dev) * 0.02)
         b = prog.empty((Cout,), torch.float32); b.normal_()
         gn = None
+        if a.presplit and k == 1 and a.prec == "fp32x3":
+            x = prog.group_norm([x], prog.f32(torch.ones(Cin, device=dev)), prog.f32(torch.zeros(Cin, device=dev)), silu=False, split_out=True)
         if a.gn and not ups and k == 3:
             gn = (prog.gn_stats([x], prog.f32(torch.ones(Cin, device=dev)), prog.f32(torch.zeros(Cin, device=dev))), True)
         if ups and a.up4 and prog.conv_up4_ok(x, Cout):  # the parity-class form of the nearest-2x conv (4/9 of the MACs; flops below = algorithmic)
@@ -60,12 +69,15 @@ def main():
         prog.finalize()
         for _ in range(3): prog.run()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        # HIP events around the conv op only (the program may hold a statistics / bound-table / normalising op in front of it)
+        prog.enable_timing(a.iters, only=[_i])
         for _ in range(a.iters): prog.run()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / a.iters
+        runs, ms = prog.read_timing()
+        prog.disable_timing()
+        dt = ms[_i] / runs * 1e-3
         fl = 2.0 * N * (y.H * y.W if y is not None else H * W) * Cout * Cin * k * k
-        print(f"{name:8s} {a.prec}{' gn' if gn else ''} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
+        print(f"{name:8s} {a.prec}{' gn' if gn else ''}{' presplit' if x.presplit else ''} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
 
 if __name__ == "__main__":
     main()
