@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("EOD_LIBRARY") or os.path.join(_HERE, "lib", "libeodif
 
 EOD_F32, EOD_F16 = 0, 1
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
- OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT, OP_DROPOUT, OP_ACT_BOUND) = range(1, 16)
+ OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT, OP_DROPOUT, OP_ACT_BOUND, OP_BOUND_AFFINE) = range(1, 17)
 
 vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                 ("Ho", i32), ("Wo", i32), ("out_nchw_f32", i32), ("alpha", f32), ("stats", vp), ("stats_slots", i32),
                 ("gn_silu", i32), ("gn_scale_shift", vp), ("workspace", vp), ("workspace_bytes", i64),
                 ("w_tapmajor", i32), ("w_split", i32), ("w_scale", vp), ("a_bound", vp),
-                ("skip_x", vp), ("skip_x2", vp), ("skip_w", vp), ("skip_C0", i32), ("skip_C1", i32), ("skip_bound", vp), ("x_presplit", i32)]
+                ("skip_x", vp), ("skip_x2", vp), ("skip_w", vp), ("skip_C0", i32), ("skip_C1", i32), ("skip_bound", vp), ("x_presplit", i32), ("y_presplit_bound", vp)]
 
 
 class GemmDesc(C.Structure):
@@ -98,7 +98,9 @@ SYMBOLS = {
     "eod_dropout": (i32, [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "eod_rowdot": (i32, [vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
     "eod_scale_f32": (i32, [vp, i64, f32, vp]),
-    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "eod_weight_l1max": (i32, [vp, i32, i32, vp, vp, vp]),
+    "eod_bound_affine": (i32, [vp, vp, vp, i32, vp]),
     "eod_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eod_gemm_tn": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, f32, i32, i32, i64, i64, i64, i64, i64, i64, vp]),
     "eod_softmax_bwd_rows": (i32, [vp, i64, vp, i64, vp, i32, i64, i32, vp]),

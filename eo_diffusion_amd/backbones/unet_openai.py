@@ -480,14 +480,21 @@ class AttentionBlock(_Emitter):
             xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps,
                                  split_out=prog.split)  # (fp32x3: written pre-split for the qkv conv, its only consumer)
             if prog.split:
-                # (stats=True: the epilogue's sums of squares give the bound table q / k / v are scaled by -- no pass over qkv)
-                qkv, _ = prog.conv(xn, prog.pack_conv(self.qkv.weight.view(3 * Cc, Cc, 1, 1)), prog.f32(self.qkv.bias), 3 * Cc,
-                                   ksize=1, stride=1, pad=0, stats=True)
+                # The whole block runs on PRE-SPLIT operands where the geometry allows (whole 128-row conv tiles per image): norm writes
+                # xn pre-split; the qkv conv's epilogue writes q / k / v pre-split, scaled from an A-PRIORI bound of its output
+                # (|W xn + b| <= max row L1 norm * max|xn| + max|b|: prog.linear_bound); the attention kernel then loads Q fragments and
+                # LDS-DMAs K / V tiles as they are -- no split arithmetic -- and writes a pre-split for proj_out (rows of a are convex
+                # combinations of v rows: the table of qkv bounds them).  Otherwise the table of qkv comes from the conv epilogue's sums
+                # of squares (no pass over qkv) and the kernels split in LDS / registers.
+                bq = prog.f32(self.qkv.bias)
+                ps = xn.presplit and T % 128 == 0 and T >= 256 and Cc % 8 == 0  # (whole conv tiles per image, no split-K shapes)
+                qkv_bound = prog.linear_bound(xn.bound, self.qkv.weight.view(3 * Cc, Cc), bq) if ps else None
+                qkv, _ = prog.conv(xn, prog.pack_conv(self.qkv.weight.view(3 * Cc, Cc, 1, 1)), bq, 3 * Cc, ksize=1, stride=1, pad=0,
+                                   stats=not ps, y_presplit_bound=qkv_bound)
                 a = prog.act(N, x.H, x.W, Cc)
-                qkv_bound = prog.bound_of([qkv])
-                # a = convex combinations of v rows: |a| <= max|v| <= the bound of qkv -> known BEFORE the kernel runs, so it writes a
-                # pre-split for proj_out (its only consumer), which then needs no split pass per K-step
-                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs, qkv_bound=qkv_bound, out_presplit=Cc % 8 == 0)
+                if not ps:
+                    qkv_bound = prog.bound_of([qkv])
+                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs, qkv_bound=qkv_bound, out_presplit=Cc % 8 == 0, in_presplit=ps)
                 a.bound, a.presplit = qkv_bound, Cc % 8 == 0
                 out, _ = prog.conv(a, prog.pack_conv(self.proj_out.weight.view(Cc, Cc, 1, 1)), prog.f32(self.proj_out.bias), Cc,
                                    ksize=1, stride=1, pad=0, res=x, stats=True)

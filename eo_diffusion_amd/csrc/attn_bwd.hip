@@ -470,19 +470,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
 }
 
 int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int d, int q_off, int k_off, int v_off,
-                             int head_stride, const float* qkv_bound, int out_presplit, hipStream_t st);  // csrc/attn_x3.hip
+                             int head_stride, const float* qkv_bound, int out_presplit, int in_presplit, hipStream_t st);  // csrc/attn_x3.hip
 
 extern "C" int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off,
-                                     int k_off, int v_off, int head_stride, const float* qkv_bound, int out_presplit, void* stream) {
+                                     int k_off, int v_off, int head_stride, const float* qkv_bound, int out_presplit, int in_presplit,
+                                     void* stream) {
     EOD_REQUIRE(qkv && out && N > 0 && T > 0 && heads > 0 && d > 0 && C == heads * d, "attention_fwd_nat: bad args");
     EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "attention_fwd_nat: bad dtype %d", dtype);
     EOD_REQUIRE(d % 8 == 0 && d <= 64, "attention_fwd_nat: the head dim must be a multiple of 8 and <= 64");
     if (dtype == EOD_F32) {  // fp32 storage: fp32-grade products as three fp16 MFMAs on split operands (csrc/attn_x3.hip)
         EOD_REQUIRE((long long)T * 3 * C * 4 < 0x7fffffffLL * 4LL, "attention_fwd_nat: sequence too long");
         return eod_attention_fwd_nat_x3((const float*)qkv, (float*)out, lse, N, T, C, heads, d, q_off, k_off, v_off, head_stride, qkv_bound,
-                                        out_presplit, (hipStream_t)stream);
+                                        out_presplit, in_presplit, (hipStream_t)stream);
     }
-    EOD_REQUIRE(!out_presplit, "attention_fwd_nat: a pre-split output exists for fp32 storage only");
+    EOD_REQUIRE(!out_presplit && !in_presplit, "attention_fwd_nat: pre-split tensors exist for fp32 storage only");
     EOD_REQUIRE(q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && head_stride % 8 == 0 && eod_aligned16(qkv) && ((uintptr_t)out & 7) == 0,
                 "attention_fwd_nat: alignment of the head slices");
     EOD_REQUIRE((long long)T * 3 * C * 2 < 0x7fffffffLL, "attention_fwd_nat: one image of qkv exceeds the 2 GiB window");

@@ -13,6 +13,11 @@
 //     conversion needs the values in registers anyway, and the loads of tile kt+1 are in flight while tile kt is computed;
 //   * Q never touches LDS: a lane's A... B-operand fragments are rows of its own query, loaded and split once;
 //   * one LDS buffer per operand half (4 x 8 KiB), two barriers per key tile; two workgroups per CU cover each other's barriers.
+// PS = true: qkv arrives PRE-SPLIT (the qkv conv's epilogue wrote [8 x fp16 hi | 8 x fp16 lo] per 8 channels, scaled per image from an
+// a-priori table: eod_conv_desc.y_presplit_bound).  Then nothing is converted here: a lane's Q fragments are 16-byte loads of the
+// finished hi / lo chunks, and the K / V tiles are staged by LDS-DMA (buffer_load ... lds, 64 lanes x 16 B = 8 key rows x 128 B per
+// instruction, the bank swizzle applied on the SOURCE side; channel groups beyond the head dim come from an out-of-range offset =
+// zeros), double buffered: the DMA of tile kt + 1 is in flight under the MFMAs of tile kt and the loop has ONE barrier per tile.
 // Layout: qkv [N][T][3C] fp32 as produced by the qkv projection (channel = q_off / k_off / v_off + head*head_stride + j),
 // out [N][T][C] fp32, optional lse [N][heads][T].  Any T, d % 8 == 0, d <= 64.
 #include "common.h"
@@ -21,7 +26,7 @@
 typedef __fp16 fp16x4c __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 constexpr int AX_ROWB = 128;       // LDS row = 64 halves (head dim padded with zeros)
-constexpr int AX_KMIN = -48;       // smallest operand scale 2^-48 (|q|, |k|, |v| up to 2^63: beyond that q.k overflows fp32 itself); keeps 1/s^2 normal
+constexpr int AX_KMIN = EOD_AB_KMIN_ATTN;  // smallest operand scale 2^-48 (common.h)
 
 __device__ __forceinline__ int ax_swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int ax_off(int row, int c) { return row * AX_ROWB + ((c ^ ax_swz(row)) << 4); }
@@ -67,13 +72,12 @@ struct AttnX3P {
                        // convex combinations of v rows, so the table of qkv bounds them) for the proj_out conv (eod_conv_desc.x_presplit)
 };
 
-template <int DS, int DT>
+typedef __attribute__((address_space(3))) void ax_lds_void;
+
+template <int DS, int DT, bool PS = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sKh = smem;                  // [64][128 B] each
-    char* sKl = smem + 64 * AX_ROWB;
-    char* sVh = smem + 128 * AX_ROWB;
-    char* sVl = smem + 192 * AX_ROWB;
+    constexpr int TILE = 64 * AX_ROWB, BUF = 4 * TILE;  // one buffer = K hi | K lo | V hi | V lo tiles of [64][128 B]; PS: two buffers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
@@ -104,6 +108,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
             if (q < p.T && j < p.d) {
                 a = *reinterpret_cast<const f32x4*>(qp + j);
                 c = *reinterpret_cast<const f32x4*>(qp + j + 4);
+            }
+            if constexpr (PS) {  // the 8-channel group is already [8 x hi | 8 x lo]
+                qh[ks] = __builtin_bit_cast(half8, a);
+                ql[ks] = __builtin_bit_cast(half8, c);
+                continue;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -146,13 +155,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
                 ax_split(rv[i][e] * AX_SCALE, hi, lo);
                 vh[e] = hi; vl[e] = lo;
             }
-            *reinterpret_cast<half4*>(sKh + off) = kh;
-            *reinterpret_cast<half4*>(sKl + off) = kl;
-            *reinterpret_cast<half4*>(sVh + off) = vh;
-            *reinterpret_cast<half4*>(sVl + off) = vl;
+            *reinterpret_cast<half4*>(smem + off) = kh;
+            *reinterpret_cast<half4*>(smem + TILE + off) = kl;
+            *reinterpret_cast<half4*>(smem + 2 * TILE + off) = vh;
+            *reinterpret_cast<half4*>(smem + 3 * TILE + off) = vl;
         }
     };
 
+    // PS: LDS-DMA staging.  One instruction = 8 key rows x 8 chunk slots; slot j of row r holds channel group j ^ swz(r) (ax_off),
+    // so the lane fetches THAT group's hi (or lo) chunk: source = key row + (group * 8 channels + 0 / 4) floats.  Wave w stages rows
+    // 16 w .. 16 w + 15 of each of the four tiles: 8 instructions per key tile and wave.
+    __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    auto dma_tile = [&](int kt, int buf) {
+        if constexpr (PS) {
+            char* b0 = smem + buf * BUF;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wave * 16 + i * 8 + (lane >> 3), key = kt * 64 + row;
+                const int grp = (lane & 7) ^ ax_swz(row);
+                const bool okr = key < p.T && grp * 8 < p.d;
+                const unsigned rowoff = (unsigned)(((long long)key * ld + h * p.hs + grp * 8) * 4);
+                const unsigned kofs = okr ? rowoff + (unsigned)p.k_off * 4u : 0x80000000u, vofs = okr ? rowoff + (unsigned)p.v_off * 4u : 0x80000000u;
+                char* dst = b0 + (wave * 16 + i * 8) * AX_ROWB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, (ax_lds_void*)(dst), 16, kofs, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, (ax_lds_void*)(dst + TILE), 16, okr ? kofs + 16u : 0x80000000u, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, (ax_lds_void*)(dst + 2 * TILE), 16, vofs, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_kv, (ax_lds_void*)(dst + 3 * TILE), 16, okr ? vofs + 16u : 0x80000000u, 0, 0, 0);
+            }
+        }
+    };
     f32x16 o[DT];  // O^T tiles: registers = output channel j, lane & 31 = query
 #pragma unroll
     for (int t = 0; t < DT; ++t)
@@ -160,15 +191,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
         for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
     float m_run = -INFINITY, l_run = 0.0f;
     const int nkt = (p.T + 63) / 64;
-    load_tile(0);
+    if constexpr (PS) dma_tile(0, 0); else load_tile(0);
     // one key tile; RAGGED (compile-time) = the last tile of a sequence that is not a multiple of 64 keys: only that instance carries
     // the per-element key mask (see attn_fwd_nat_kernel in attn_bwd.hip)
     auto tile = [&](const int kt, auto ragged_c) {
         constexpr bool RAGGED = decltype(ragged_c)::value;
+        char* const sKh = smem + (PS ? (kt & 1) * BUF : 0);
+        char* const sKl = sKh + TILE;
+        char* const sVh = sKh + 2 * TILE;
+        char* const sVl = sKh + 3 * TILE;
+        if constexpr (PS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile kt have landed ...
+            __builtin_amdgcn_s_barrier();                     // ... and everybody's; every wave is also done reading tile kt - 1
+            if (kt + 1 < nkt) dma_tile(kt + 1, (kt + 1) & 1);  // into the buffer tile kt - 1 just vacated, in flight under the MFMAs below
+        } else {
         __syncthreads();  // every wave is done reading the previous tile
         store_tile();     // (waits for this tile's global loads)
         __syncthreads();  // tile kt is visible
         if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+        }
         f32x16 s[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -279,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
 }
 
 int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int d, int q_off, int k_off, int v_off,
-                             int head_stride, const float* qkv_bound, int out_presplit, hipStream_t st) {
+                             int head_stride, const float* qkv_bound, int out_presplit, int in_presplit, hipStream_t st) {
     EOD_REQUIRE(q_off % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && head_stride % 4 == 0 && eod_aligned16(qkv) && eod_aligned16(out) && C % 4 == 0,
                 "attention_fwd_nat (fp32): alignment of the head slices");
     AttnX3P p;
@@ -289,8 +330,31 @@ int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, in
     p.ab = qkv_bound;
     p.out_ps = out_presplit;
     const dim3 grid((T + 127) / 128, N * heads);
-    const size_t lds = (size_t)256 * AX_ROWB;
     const int ds = (d + 15) / 16;
+    if (in_presplit) {
+        EOD_REQUIRE(qkv_bound && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && head_stride % 8 == 0 && C % 8 == 0,
+                    "attention_fwd_nat (fp32, pre-split qkv): needs the table the producer scaled by, and whole 8-channel groups");
+        EOD_REQUIRE((long long)T * 3 * C * 4 < 0x7fffffffLL, "attention_fwd_nat (fp32, pre-split qkv): one image of qkv exceeds the 2 GiB window");
+        const size_t lds2 = (size_t)2 * 256 * AX_ROWB;  // two buffers of four tiles (64 KiB: two workgroups per CU)
+#define EOD_AX_PS(DS_, DT_)                                                                                                          \
+        do {                                                                                                                     \
+            static bool attr = false;                                                                                            \
+            if (!attr) {                                                                                                         \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_nat_x3_kernel<DS_, DT_, true>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                               \
+                attr = true;                                                                                                     \
+            }                                                                                                                    \
+            hipLaunchKernelGGL((attn_fwd_nat_x3_kernel<DS_, DT_, true>), grid, dim3(256), lds2, st, p);                          \
+        } while (0)
+        if (ds == 1) EOD_AX_PS(1, 1);
+        else if (ds == 2) EOD_AX_PS(2, 1);
+        else if (ds == 3) EOD_AX_PS(3, 2);
+        else EOD_AX_PS(4, 2);
+#undef EOD_AX_PS
+        EOD_CHECK_LAUNCH("attention_fwd_nat (fp32, pre-split qkv)");
+        return EOD_OK;
+    }
+    const size_t lds = (size_t)256 * AX_ROWB;
     if (ds == 1) hipLaunchKernelGGL((attn_fwd_nat_x3_kernel<1, 1>), grid, dim3(256), lds, st, p);
     else if (ds == 2) hipLaunchKernelGGL((attn_fwd_nat_x3_kernel<2, 1>), grid, dim3(256), lds, st, p);
     else if (ds == 3) hipLaunchKernelGGL((attn_fwd_nat_x3_kernel<3, 2>), grid, dim3(256), lds, st, p);

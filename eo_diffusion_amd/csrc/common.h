@@ -77,6 +77,8 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 #define EOD_AB 32
 #define EOD_AB_KMIN (-113)  // B = inf / NaN / 2^127: s = 2^-113 keeps every finite fp32 value inside the fp16 range
 #define EOD_AB_KMAX 60      // images whose largest element is below 2^-46 keep s = 2^60 (graceful: |s x| < 2^14)
+#define EOD_AB_KMIN_ATTN (-48)  // attention operands (q, k, v): s >= 2^-48 keeps 1 / s^2 (the softmax exponent's factor) a normal number;
+                                // |q|, |k|, |v| up to 2^63 -- beyond that q . k overflows fp32 itself
 struct AbScale {
     float s, inv;  // operand scale, and 16 / s (what the epilogue multiplies by on top of the weights' 1 / (16 s_w))
 };

@@ -90,6 +90,7 @@ struct IgemmP {
     const float* b_bound;
     int ab_tab_off;  // generic kernel: byte offset in LDS of the per-image {s, 16/s} table of a tile that straddles images
     int a_ps;        // generic split kernel: the A operand arrives PRE-SPLIT from HBM (eod_conv_desc.x_presplit): no rewrite in LDS
+    const float* y_ps_bound;  // generic split kernel: write the output pre-split, scale per image from this table (y_presplit_bound)
 };
 
 template <typename T> struct Mma;
@@ -404,6 +405,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
     __builtin_amdgcn_wave_barrier();
 
+    // pre-split output: the image's power-of-two scale from the a-priori table of y (one image per tile: checked by the launcher)
+    float ps_scale = 1.0f;
+    if constexpr (CONV && OUTF32) {
+        if (p.y_ps_bound) ps_scale = ab_scale_of(ab_wave_bound(p.y_ps_bound, g.n_first), EOD_AB_KMIN_ATTN).s;
+    }
     // optional GroupNorm partial statistics of the STORED values (sum / sum of squares per output channel over the
     // wave's WM rows): accumulated per lane over its ITER rows, combined across the lanes that share a column chunk.
     const bool want_stats = CONV && p.stats != nullptr;
@@ -437,6 +443,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                     if (p.bias_mode == 4) ov = sizeof(T) == 2 ? __expf(v[e]) : expf(v[e]);
                 }
                 o_[e] = (OT)ov;
+            }
+        }
+        if constexpr (CONV && OUTF32) {
+            if (p.y_ps_bound) {
+                // PRE-SPLIT output (eod_conv_desc.y_presplit_bound): this lane's 4 channels and the neighbouring lane's (the other chunk
+                // of the 8-channel group, same row) become [8 x hi | 8 x lo] of s * y -- every lane takes part in the exchange
+                f32x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (float)o_[e] * ps_scale;
+                const i32x4 w4 = split_pair_exchange(v4, ((cj >> 2) & 1) != 0);
+                if (ok[it]) *reinterpret_cast<i32x4*>(reinterpret_cast<OT*>(p.y) + off[it]) = w4;
+                continue;
             }
         }
         if (!ok[it]) continue;
@@ -2396,6 +2414,10 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     EOD_REQUIRE(!d->x_presplit || (d->w_split && d->a_bound && !halo_ok && !d->upsample && !d->w_tapmajor && !d->gn_scale_shift),
                 "conv: x_presplit needs w_split with the producer's bound table, on the generic kernel (1x1 / stride-2 / small maps)");
     p.a_ps = d->x_presplit;
+    EOD_REQUIRE(!d->y_presplit_bound || (d->w_split && !halo_ok && !d->out_nchw_f32 && !d->stats && d->Cout % 8 == 0 && (Ho * Wo) % 128 == 0 &&
+                                         conv_splitk(d, Ho, Wo, false) <= 1),
+                "conv: y_presplit_bound needs w_split on the generic kernel, Cout %% 8 == 0, whole 128-row tiles per image, no statistics");
+    p.y_ps_bound = d->y_presplit_bound;
     p.skip_bound = (d->w_split && d->skip_x) ? d->skip_bound : nullptr;
     if (d->upsample == 3) {
         EOD_REQUIRE(conv_up4_ok(d), "conv: upsample = 3 (parity-class form of the nearest-2x conv) needs a geometry for which eod_conv_up4_ok(d) == 1");

@@ -534,3 +534,55 @@ extern "C" int eod_softmax_rows(const float* s, int64_t lds, void* p, int64_t ld
     EOD_CHECK_LAUNCH("softmax_rows");
     return EOD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// A-PRIORI bound of a linear layer's output: |y_r| = |sum_c w[r][c] x_c + b_r| <= (max_r sum_c |w[r][c]|) * max|x| + max|b|.
+// A producer that writes its output pre-split needs the scale BEFORE it has seen its own values: eod_weight_l1max condenses the
+// weight into coef = {max row L1 norm, max|bias|} once per plan (pack time), eod_bound_affine turns the input's table into the
+// output's every step (N x 32 multiply-adds).  The qkv projection in front of the fused attention uses it (unet_openai.py:414).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_l1max_kernel(const float* __restrict__ w, int rows, int cols, const float* __restrict__ bias,
+                                                           float* __restrict__ coef) {
+    __shared__ float red[4], best;
+    const int tid = threadIdx.x;
+    if (tid == 0) best = 0.0f;
+    float bm = 0.0f;
+    for (int r = 0; r < rows; ++r) {  // (one block: a few hundred thousand weights, once per plan)
+        float a = 0.0f;
+        for (int c = tid; c < cols; c += 256) a += fabsf(w[(long long)r * cols + c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = a;
+        __syncthreads();
+        if (tid == 0) best = fmaxf(best, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+    if (bias)
+        for (int r = tid; r < rows; r += 256) bm = fmaxf(bm, fabsf(bias[r]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = bm;
+    __syncthreads();
+    if (tid == 0) {
+        coef[0] = best * 1.0001f;  // (the fp32 sums above are rounded: keep the bound a bound)
+        coef[1] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+}
+extern "C" int eod_weight_l1max(const float* w, int rows, int cols, const float* bias, float* coef, void* stream) {
+    EOD_REQUIRE(w && coef && rows > 0 && cols > 0, "weight_l1max: bad args");
+    hipLaunchKernelGGL(weight_l1max_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, rows, cols, bias, coef);
+    EOD_CHECK_LAUNCH("weight_l1max");
+    return EOD_OK;
+}
+__global__ void bound_affine_kernel(const float* __restrict__ ab_in, const float* __restrict__ coef, float* __restrict__ ab_out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ab_out[i] = ab_in[i] * coef[0] + coef[1];
+}
+extern "C" int eod_bound_affine(const float* ab_in, const float* coef, float* ab_out, int N, void* stream) {
+    EOD_REQUIRE(ab_in && coef && ab_out && N > 0, "bound_affine: bad args");
+    const int n = N * EOD_AB;
+    hipLaunchKernelGGL(bound_affine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ab_in, coef, ab_out, n);
+    EOD_CHECK_LAUNCH("bound_affine");
+    return EOD_OK;
+}

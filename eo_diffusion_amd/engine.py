@@ -15,7 +15,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (OP_ACT_BOUND, OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_DROPOUT, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX,
+from ._lib import (OP_ACT_BOUND, OP_BOUND_AFFINE, OP_ATTN, OP_ATTN_NAT, OP_CONV, OP_DROPOUT, OP_GEMM, OP_GN_APPLY, OP_GN_FINALIZE, OP_GN_PARTIAL, OP_POOL, OP_SOFTMAX,
                    OP_TEMB, OP_TO_NCHW, OP_TO_NHWC, ConvDesc, GemmDesc, Op, TembDesc, check, ptr)
 
 AB = 32  # entries per image of an activation bound table (csrc/common.h: EOD_AB)
@@ -247,6 +247,20 @@ class Program:
         self._small(OP_ACT_BOUND, p=(ptr(t), 0, 0, ptr(ab)), l=(t.numel() // n,), i=(self.dt, n, 0, 0, 0, 0))
         return ab
 
+    def linear_bound(self, ab_in, weight2d, bias):
+        """A-PRIORI bound table of y = W x + b from the table of x: |y| <= (max row L1 norm of W) * max|x| + max|b|.  The two scalars
+        are condensed from the parameters once per plan (eod_weight_l1max, build time), the table itself is one tiny op per run.  A
+        producer that writes its output pre-split (the qkv projection in front of the fused attention) scales by it."""
+        w = self.f32(weight2d)
+        coef = torch.zeros((2,), dtype=torch.float32, device=self.device)
+        check(self.L.eod_weight_l1max(ptr(w), w.shape[0], w.numel() // w.shape[0], ptr(bias), ptr(coef), current_stream_ptr(self.device)),
+              "weight_l1max")
+        self.own(coef)
+        n = ab_in.shape[0]
+        ab = self.empty((n, AB), torch.float32, zero=True)
+        self._small(OP_BOUND_AFFINE, p=(ptr(ab_in), ptr(coef), ptr(ab)), i=(n,))
+        return ab
+
     def conv_up4_ok(self, x, cout):
         """True if the library has the parity-class form of `3x3 conv over the nearest-2x upsampling of x` for this geometry"""
         if os.environ.get("EOD_UP4", "1") == "0" or self.precision == "fp32":
@@ -279,7 +293,8 @@ class Program:
         return bool(self.L.eod_conv_skip_ok(C.byref(d)))
 
     def conv(self, x, w_packed, bias, cout, *, x2=None, ksize=3, stride=1, pad=1, upsample=False, pad_tl=False,
-             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None, w_tapmajor=False, skip=None):
+             cbias=None, cbias_stride=0, res=None, out_nchw_f32=False, out=None, stats=False, gn=None, w_tapmajor=False, skip=None,
+             y_presplit_bound=None):
         """gn = (scale_shift tensor from gn_stats(), silu): GroupNorm(+SiLU) of the conv INPUT.  Fused into the conv's
         patch staging when the library can (eod_conv_gn_fusable), otherwise applied by a separate pass first.
         skip = (srcs, weight, bias): add conv1x1(cat(srcs)) with that OI11 weight / bias in the same launch (only where
@@ -357,6 +372,9 @@ class Program:
         if d.w_split:
             assert ab is not None and (skip is None or ab_skip is not None), "fp32x3: no bound table for this conv input"
             d.a_bound, d.skip_bound = ptr(ab), ptr(ab_skip)
+        if y_presplit_bound is not None:  # the output is written pre-split, scaled from this a-priori table (linear_bound)
+            assert d.w_split and not stats and not out_nchw_f32, "pre-split output: split-fp16 conv on the generic kernel, no statistics"
+            d.y_presplit_bound = ptr(y_presplit_bound)
         assert not d.x_presplit or d.w_split, "a pre-split tensor needs the split-fp16 conv (channel counts that are multiples of 8)"
         wsz = self.L.eod_conv_workspace_size(C.byref(d))
         if wsz > 0:  # split-K partial tiles (small maps)
@@ -367,6 +385,8 @@ class Program:
         else:
             y = out if out is not None else self.act(x.N, ho, wo, cout)
             d.y = ptr(y.t)
+            if y_presplit_bound is not None:
+                y.presplit, y.bound = True, y_presplit_bound
             if stats:
                 slots = self.L.eod_conv_stats_slots(C.byref(d))
                 if slots > 0:  # the epilogue emits the next GroupNorm's per-channel partial sums for free
@@ -496,11 +516,12 @@ class Program:
         a.dtype, a.N, a.T, a.C, a.heads, a.d, a.dpad, a.k_off = self.dt, N, T, Cc, heads, d, dpad, k_off
         return idx
 
-    def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None, qkv_bound=None, out_presplit=False):
+    def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None, qkv_bound=None, out_presplit=False,
+                      in_presplit=False):
         """fused attention on the natural qkv layout [N][T][3C] (head dim % 8 == 0 and <= 64, any T): eod_attention_fwd_nat.  fp32 storage
         (fp32x3): qkv_bound = bound table [N][32] of qkv (None: |q|, |k|, |v| < 4094 guaranteed by the caller); out_presplit: `out` is
         written pre-split (scale from qkv_bound) for the proj_out conv"""
-        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse), ptr(qkv_bound)), l=(int(out_presplit),),
+        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse), ptr(qkv_bound)), l=(int(out_presplit), int(in_presplit)),
                            i=(self.dt, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride))
 
     def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):
@@ -656,7 +677,7 @@ class Program:
                 out.append(dict(kind="softmax", flops=0.0, bytes=s.l[2] * (4 * s.i[1] + es * s.l[1]), label="softmax"))
             else:
                 out.append(dict(kind={OP_GN_FINALIZE: "gn_finalize", OP_TEMB: "temb", OP_TO_NHWC: "to_nhwc",
-                                      OP_TO_NCHW: "to_nchw", OP_POOL: "resample", OP_ACT_BOUND: "act_bound"}.get(k, str(k)), flops=0.0, bytes=0.0,
+                                      OP_TO_NCHW: "to_nchw", OP_POOL: "resample", OP_ACT_BOUND: "act_bound", OP_BOUND_AFFINE: "act_bound"}.get(k, str(k)), flops=0.0, bytes=0.0,
                                 label=""))
         return out
 

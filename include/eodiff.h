@@ -115,6 +115,10 @@ typedef struct {
                             channels as [8 x fp16 hi | 8 x fp16 lo] of s_n * x with s_n = the power-of-two scale that a_bound gives for
                             image n -- written by a producer that knew the bound beforehand (eod_gn_apply split_out, the fp32-storage
                             attention).  The conv DMAs the rows straight into its LDS image: no split pass per K-step. */
+    const float* y_presplit_bound; /* w_split, generic-kernel geometries whose tiles lie inside one image (Ho*Wo % 128 == 0), Cout % 8 == 0:
+                            write y PRE-SPLIT, scaled per image from this table [N][32] (an a-priori bound of y: eod_bound_affine; exponent
+                            range of the attention kernels, s >= 2^-48) -- the qkv projection in front of eod_attention_fwd_nat(in_presplit).
+                            NULL = plain fp32 output */
 } eod_conv_desc;
 int eod_conv2d_igemm(const eod_conv_desc* d, void* stream);
 /* number of partial-sum slots per image the epilogue of this conv would write, or 0 if it cannot (tiles that straddle
@@ -218,6 +222,11 @@ int eod_gn_finalize(const float* part0, int P0, int C0, const float* part1, int 
  * accumulate = 1: entry-wise maximum with what the table already holds -- the further sources of a virtual concat). */
 int eod_act_bound(const void* x, int dtype, int N, int64_t per_image, const float* part0, int P0, int C0, const float* part1, int P1,
                   int C1, float* ab, int accumulate, void* stream);
+/* A-priori table of a linear layer's OUTPUT (a producer that writes pre-split needs its scale before it has seen its values):
+ * |y_r| <= (max_r sum_c |w[r][c]|) * max|x| + max|b|.  eod_weight_l1max: coef = {max row L1 norm of w [rows][cols], max|bias|} (device,
+ * once per plan); eod_bound_affine: ab_out[n][j] = ab_in[n][j] * coef[0] + coef[1]. */
+int eod_weight_l1max(const float* w, int rows, int cols, const float* bias, float* coef, void* stream);
+int eod_bound_affine(const float* ab_in, const float* coef, float* ab_out, int N, void* stream);
 int eod_gn_apply(const void* x, int dtype, int N, int HW, int C, const float* scale_shift, int Ctot,
                  int coff, int silu, void* y, const float* split_bound, void* stream);
 /* split_bound (EOD_F32, C / Ctot / coff multiples of 8): write y PRE-SPLIT for a split-fp16 consumer (eod_conv_desc.x_presplit):
@@ -323,7 +332,8 @@ enum {
     EOD_OP_TRANSPOSE = 12, /* eod_transpose_gather (training forward: transposed q|k|v for the attention GEMMs) */
     EOD_OP_ATTN_NAT = 13,  /* eod_attention_fwd_nat */
     EOD_OP_DROPOUT = 14,   /* eod_dropout (training forward) */
-    EOD_OP_ACT_BOUND = 15  /* eod_act_bound */
+    EOD_OP_ACT_BOUND = 15, /* eod_act_bound */
+    EOD_OP_BOUND_AFFINE = 16 /* eod_bound_affine */
 };
 typedef struct {
     const void* p[8];
@@ -441,10 +451,12 @@ int eod_scale_f32(float* x, int64_t n, float s, void* stream);
  *   EOD_F32: fp32 in / out, fp32 online softmax, both contractions as three fp16 MFMAs per product on operands split into
  *            hi + lo halves (fp32-grade, ~2^-22 per product; csrc/attn_x3.hip) */
 int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off, int k_off,
-                          int v_off, int head_stride, const float* qkv_bound, int out_presplit, void* stream);
+                          int v_off, int head_stride, const float* qkv_bound, int out_presplit, int in_presplit, void* stream);
 /* qkv_bound (EOD_F32 only): bound table [N][32] of the qkv tensor (eod_conv_desc.a_bound); NULL = |q|, |k|, |v| < 4094 guaranteed.
  * out_presplit (EOD_F32 only): `out` is written pre-split for a split-fp16 conv (eod_conv_desc.x_presplit with a_bound = qkv_bound:
- * rows of out are convex combinations of v rows, so the table of qkv bounds them). */
+ * rows of out are convex combinations of v rows, so the table of qkv bounds them).
+ * in_presplit (EOD_F32 only): qkv arrives pre-split (eod_conv_desc.y_presplit_bound = qkv_bound): q fragments are loaded as they are, K / V
+ * tiles staged by LDS-DMA, no split arithmetic in the kernel. */
 /* flash-style attention backward (fp16, head dim a multiple of 8 and <= 64, any T): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /
  * k_off / v_off + head*head_stride + j), dO [N][T][C], the forward's log-sum-exp lse [N][heads][T] (eod_attn_desc.lse) and
  * D[n][h][t] = sum_j dO*O (eod_rowdot).  P is rebuilt tile by tile in registers: nothing T x T touches HBM (csrc/attn_bwd.hip) */

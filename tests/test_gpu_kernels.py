@@ -507,7 +507,7 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits
     qd = qh.to(DEV)
     out = torch.empty((N * T, C), dtype=torch.float16, device=DEV)
     lse = torch.empty((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0, st),
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0, 0, st),
                "attention_fwd_nat")
     assert rel_l2(out.float().cpu().reshape(N, T, C), O.detach()) < 3e-3
     lse_ref = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) / math.sqrt(d), -1)
@@ -548,7 +548,7 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
     qd = qkv.to(DEV)
     out = torch.full((N, T, C), 9.0, dtype=torch.float16, device=DEV)
     lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0,
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0, 0,
                                        current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu(), ref) < 3e-3
@@ -581,7 +581,7 @@ def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, boun
     if bound:
         _lib.check(L.eod_act_bound(qd.data_ptr(), _lib.EOD_F32, N, T * 3 * C, 0, 0, 0, 0, 0, 0, ab.data_ptr(), 0, st), "act_bound")
     _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F32, N, T, C, heads, d, qo, ko, vo, hs,
-                                       ab.data_ptr() if bound else 0, 0, st), "attention_fwd_nat")
+                                       ab.data_ptr() if bound else 0, 0, 0, st), "attention_fwd_nat")
     torch.cuda.synchronize()
     if bound:
         assert torch.equal(ab.cpu().max(1).values, qkv.abs().amax((1, 2)))  # the direct pass is the exact max|x| per image
