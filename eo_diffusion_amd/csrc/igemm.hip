@@ -1470,8 +1470,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
 // read), in the usual [tap][4*Cout][Cin] format (split fp16 pairs for fp32 storage).  A workgroup = one 8x16 tile of STORED positions x
 // one class x 128 output channels: the ordinary (8+2) x (16+2) halo patch of the stored tensor, FOUR taps per 32/64-channel chunk instead
 // of nine, and the epilogue scatters to the (2i+p, 2j+q) positions of the (2H x 2W) output (decode_row, parity mode).
-// Schedule per chunk (4 K-steps): step s issues the weight tile of step s+1 and patch pieces 2s, 2s+1 of the NEXT chunk (s < 3); a
-// piece is split in place (fp32 storage) one step after it was issued, behind that step's MFMAs.  16x16x32 MFMAs only.
+// Schedule per chunk (4 K-steps): step s issues the weight tile of step s+1 and (s < 2) patch pieces 3s .. 3s+2 of the NEXT chunk; a
+// piece is split in place (fp32 storage) two steps after it was issued, behind that step's MFMAs.  16x16x32 MFMAs only.
 // =============================================================================================
 // BWD = true: the BACKWARD-DATA of that conv with the same machinery (training).  dX[m][n] = sum over the four classes of a 2x2-tap conv
 // of G_pq[i][j] = dY[2i+p][2j+q] (the class's stride-2 view of the output gradient) with the transposed class kernels: class (p, q)
@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / MS, TN = WN / MS;
     constexpr int LB = (BN / 8) / NW;
     constexpr int ABUF = PG * 1024, BSTAGE = BN * BKB;
-    static_assert(LAH == 6, "schedule: two patch pieces per K-step in steps 0..2");
+    static_assert(LAH == 6, "schedule: three patch pieces per K-step in steps 0 and 1");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;             // [2][ABUF]
@@ -1644,11 +1644,11 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
             const bool w_next = step + 1 < NSTEP;
             if (w_next) issue_weights((s + 1) & 3, s == 3 ? nxt : cur, sB + ((step + 1) & 1) * BSTAGE);
             int np = 0;
-            if (s < 3 && has_next) {
+            if (s < 2 && has_next) {  // three patch pieces of the next chunk in each of steps 0 and 1: every piece gets two full steps to land
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if ((wave + NW * (2 * s + k)) < PG) {
-                        issue_patch_piece(2 * s + k, nxt, abuf_next);
+                for (int k = 0; k < 3; ++k)
+                    if ((wave + NW * (3 * s + k)) < PG) {
+                        issue_patch_piece(3 * s + k, nxt, abuf_next);
                         ++np;
                     }
             }
@@ -1696,12 +1696,12 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
                 }
             }
             if constexpr (SPLIT) {
-                // the pieces issued ONE step ago (2(s-1), 2(s-1)+1): behind them in the vmcnt order are this step's weight DMA and pieces
-                if (s >= 1 && has_next) {
-                    wait_vm((w_next ? LB : 0) + np);
+                // the pieces issued TWO steps ago (3(s-2) ..): the wait at the top of this step (for this step's weights, which were issued
+                // after them) has already proven that they landed
+                if (s >= 2 && has_next) {
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if ((wave + NW * (2 * (s - 1) + k)) < PG) split_piece(2 * (s - 1) + k, abuf_next);
+                    for (int k = 0; k < 3; ++k)
+                        if ((wave + NW * (3 * (s - 2) + k)) < PG) split_piece(3 * (s - 2) + k, abuf_next);
                 }
             }
             np_prev = np;
@@ -2020,6 +2020,63 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long l
     }
 }
 
+// the same second pass with the next GroupNorm's per-channel partial sums of the STORED values on the way (one slot per image):
+// grid (ceil(Cout / 64), N), block 256 = 16 chunk columns (4 channels each) x 16 pixel lanes; the S partial tiles of a pixel are
+// fetched together (independent loads), summed in the fixed z order
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ ws, int S, long long M, int Cout, int HoWo, float alpha,
+                                                                  const float* __restrict__ bias, const float* __restrict__ cbias,
+                                                                  long long cbias_stride, const T* __restrict__ res, T* __restrict__ y,
+                                                                  float* __restrict__ stats) {
+    __shared__ float red[16][16][8];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, n = blockIdx.y;
+    const int c = (blockIdx.x * 16 + tx) * 4;
+    float ss[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < Cout) {
+        float b4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b4[k] = (bias ? bias[c + k] : 0.0f) + (cbias ? cbias[(long long)n * cbias_stride + c + k] : 0.0f);
+        const long long zs = M * Cout;
+        for (int pix = ty; pix < HoWo; pix += 16) {
+            const long long e = ((long long)n * HoWo + pix) * Cout + c;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            int z = 0;
+            for (; z + 4 <= S; z += 4) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ws + (long long)z * zs + e), v1 = *reinterpret_cast<const f32x4*>(ws + (long long)(z + 1) * zs + e);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(ws + (long long)(z + 2) * zs + e), v3 = *reinterpret_cast<const f32x4*>(ws + (long long)(z + 3) * zs + e);
+                a += v0; a += v1; a += v2; a += v3;
+            }
+            for (; z < S; ++z) a += *reinterpret_cast<const f32x4*>(ws + (long long)z * zs + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = a[k] * alpha + b4[k];
+                if (res) v += (float)res[e + k];
+                const T o = (T)v;
+                y[e + k] = o;
+                const float x = (float)o;
+                ss[k] += x;
+                sq[k] += x * x;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[ty][tx][2 * k] = ss[k];
+        red[ty][tx][2 * k + 1] = sq[k];
+    }
+    __syncthreads();
+    if (ty == 0 && c < Cout) {
+        float* dst = stats + ((long long)n * Cout + c) * 2;  // [N][1 slot][Cout][2]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r][tx][k];
+            dst[k] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 #include <stdlib.h>
 #include <string.h>
@@ -2256,6 +2313,13 @@ static bool halo_bn256(const eod_conv_desc* d) {
     const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * (d->Cout / 256);
     return on && d->Cout % 256 == 0 && !d->upsample && wgs >= 256;
 }
+// few pixel tiles (16 x 16 maps and smaller at batch 16): 64-column N-tiles double the workgroup count of a launch that cannot fill the
+// chip (a 384-column conv on a 16 x 16 map at batch 16 has 32 x 3 = 96 workgroups of 128 columns).  Decided from the PER-IMAGE geometry
+// at the nominal batch of 16, never from the actual batch -- and the choice never changes a result (same K order, same MFMA tiles).
+static bool halo_bn64(const eod_conv_desc* d) {
+    const long long wgs = 16LL * (d->H / 8) * (d->W / 16) * ((d->Cout + 127) / 128);
+    return d->Cout > 64 && !d->upsample && wgs < 256;
+}
 // 384, 640, ... columns: all but the last 128 on the 8-wave form, as a launch of its own
 static bool halo_bn256_plus128(const eod_conv_desc* d) {
     const bool on = opt(OPT_HALO_BN256) != 0;
@@ -2309,7 +2373,7 @@ static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo) {
     const int bk = 128 / eod_esize(d->dtype);
     const int kt = ((d->C0 + bk - 1) / bk + (d->C1 + bk - 1) / bk) * d->ksize * d->ksize;
     if (tiles >= 128 || kt < 8) return 1;
-    int s = (int)(256 / tiles);
+    int s = (int)(512 / tiles);  // two workgroups per CU (same-box A/B on the 64 x 64 configuration: 3.59 -> 3.47 ms per step against 256 / tiles)
     if (s > kt / 4) s = kt / 4;
     if (s > 16) s = 16;
     return s < 2 ? 1 : s;
@@ -2332,7 +2396,7 @@ extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const bool halo = conv_uses_halo(d, Ho, Wo);
-    if (conv_splitk(d, Ho, Wo, halo) > 1) return 0;  // split-K tiles are reduced by a second pass
+    if (conv_splitk(d, Ho, Wo, halo) > 1) return 1;  // split-K: the reduce pass takes the sums, one slot per image
     const int bm = conv_bm(d, halo);
     if ((Ho * Wo) % bm != 0) return 0;  // tiles must not straddle images
     return (Ho * Wo / bm) * conv_waves_m(d, halo);
@@ -2445,6 +2509,12 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.SC1 = d->skip_C1;
         p.gn_ss = d->gn_scale_shift;
         p.gn_silu = d->gn_silu;
+        if (halo_bn64(d)) {
+            if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 64, 2, 2, false, 2, true, true, 16, true>(p, st)
+                                                     : launch_halo<float, 64, 2, 2, false, 2, false, true, 16, true>(p, st);
+            return d->gn_scale_shift ? launch_halo<half_t, 64, 2, 2, false, 2, true, false, 16, true>(p, st)
+                                     : launch_halo<half_t, 64, 2, 2, false, 2, false, false, 16, true>(p, st);
+        }
         if (d->w_split && halo_bn256(d))
             return d->gn_scale_shift ? launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(p, st)
                                      : launch_halo<float, 256, 2, 4, false, 2, false, true, 16, true>(p, st);
@@ -2469,6 +2539,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
             if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st);
+            if (halo_bn64(d)) return launch_halo<float, 64, 2, 2, false, 2, true, true, 16>(p, st);
             if (halo_bn256(d)) return launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(p, st);
             if (halo_bn256_plus128(d)) {
                 IgemmP q = p;
@@ -2482,6 +2553,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         }
         if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st);
         if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false, true, 16>(p, st);
+        if (halo_bn64(d)) return launch_halo<float, 64, 2, 2, false, 2, false, true, 16>(p, st);
         return launch_halo<float, 128, 2, 2, false, 2, false, true, 16>(p, st);
     }
     if (halo_ok && d->dtype == EOD_F16) {
@@ -2490,11 +2562,13 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
             if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, true, false, 16>(p, st);
+            if (halo_bn64(d)) return launch_halo<half_t, 64, 2, 2, false, 2, true, false, 16>(p, st);
             if (halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16>(p, st);
             return launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16>(p, st);
         }
         if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, false, false, 16>(p, st);
         if (d->upsample) return launch_halo<half_t, 128, 2, 2, true, 2, false, false, 16>(p, st);
+        if (halo_bn64(d)) return launch_halo<half_t, 64, 2, 2, false, 2, false, false, 16>(p, st);
         return launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16>(p, st);
     }
     if (halo_ok) {  // exact fp32 (v_mfma_f32_32x32x2_f32 on the same byte-oriented LDS image)
@@ -2514,14 +2588,23 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         // small maps: too few output tiles to fill 256 CUs -> split the K loop over gridDim.y workgroups (fp32 partial
         // tiles in the caller's workspace), then one deterministic reduce + bias/residual pass
         EOD_REQUIRE(d->workspace && d->workspace_bytes >= eod_conv_workspace_size(d), "conv: workspace of %lld bytes required (eod_conv_workspace_size)", (long long)eod_conv_workspace_size(d));
-        EOD_REQUIRE(!d->stats, "conv: epilogue statistics are not available for split-K shapes");
         IgemmP q = p;
+        q.stats = nullptr;
         q.splitk = splitk;
         q.y = (char*)d->workspace;
         q.bias = nullptr; q.bias_mode = 0; q.cbias = nullptr; q.res = nullptr; q.alpha = 1.0f;
         const int rc = d->w_split ? launch_conv_split(q, splitk, st)
                                   : d->dtype == EOD_F16 ? launch_T<half_t, true>(q, splitk, st) : launch_T<float, true>(q, splitk, st);
         if (rc != EOD_OK) return rc;
+        if (d->stats) {  // reduce + the next GroupNorm's partial sums (one slot per image)
+            const dim3 grid((unsigned)((p.Cout + 63) / 64), (unsigned)d->N);
+            if (d->dtype == EOD_F16)
+                hipLaunchKernelGGL(splitk_reduce_stats_kernel<half_t>, grid, dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y, d->stats);
+            else
+                hipLaunchKernelGGL(splitk_reduce_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, d->stats);
+            EOD_CHECK_LAUNCH("splitk_reduce_stats");
+            return EOD_OK;
+        }
         const long long total4 = p.M * p.Cout / 4;
         const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
         if (d->dtype == EOD_F16)
