@@ -93,7 +93,8 @@ SYMBOLS = {
     "eod_gn_bwd_partial": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp]),
     "eod_gn_bwd_finalize": (i32, [vp, i32, i32, i32, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
     "eod_gn_bwd_params": (i32, [vp, i32, i32, f32, vp, vp, vp]),
-    "eod_gn_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "eod_gn_bwd_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "eod_gn_bwd_apply_slabs": (i32, [i32, i32, i32, i32]),
     "eod_add": (i32, [vp, vp, vp, i32, i64, vp]),
     "eod_dropout": (i32, [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "eod_rowdot": (i32, [vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),

@@ -568,16 +568,24 @@ extern "C" int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, 
 
 // apply: dx[n][pix][c] = k1*dz + k2*x + k3 (+ add[n][pix][c]);  one concat source per launch (C channels at coff)
 // (slab decomposition of common.h: the 5 per-channel coefficients of a thread's chunk stay in registers)
+// csum (optional): per-(image, slab, channel) sums of the STORED dx, csum[n][slab][c][0] -- dx is the output gradient dY of the conv
+// that produced x, and that conv's bias / timestep-projection gradients are exactly these sums (eod_channel_sums_finish), so the
+// backward-weights step needs no pass of its own over dY (eod_gn_partial) when the gradient comes straight out of this kernel.
 template <typename T, bool SILU, bool ADD>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ ss,
                                                           const float* __restrict__ coef, const T* __restrict__ add, int HW, int C, int Ctot,
-                                                          int coff, T* __restrict__ dx, int per) {
+                                                          int coff, T* __restrict__ dx, int per, float* __restrict__ csum) {
     constexpr int EPC = dt<T>::epc, U = 2;
     constexpr bool FAST = (EPC == 8);
+    __shared__ float red[256 * EPC];
     const int tx = threadIdx.x, ty = threadIdx.y, RY = blockDim.y;
     const int n = blockIdx.y;
     const int col = blockIdx.z * blockDim.x + tx;  // chunk column (channel blocks along z for wide layers)
-    if (col >= C / EPC) return;
+    const bool live = col < C / EPC;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.0f;
+    if (live) {
     const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
     float sc[EPC], sh[EPC], k1[EPC], k2[EPC], k3[EPC];
     const float* sp = ss + ((long long)n * Ctot + coff + col * EPC) * 2;
@@ -619,17 +627,34 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                 float v = k1[e] * dz + k2[e] * xf + k3[e];
                 if (ADD) v += (float)av[u][e];
                 ov[e] = (T)v;
+                acc[e] += (float)ov[e];
             }
             *reinterpret_cast<i32x4*>(ob + pu * C) = *reinterpret_cast<const i32x4*>(ov);
+        }
+    }
+    }
+    if (csum) {  // fixed-order sum over the block's pixel rows (ty), one slot per (image, slab)
+        const int CPP = blockDim.x;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[(ty * CPP + tx) * EPC + e] = acc[e];
+        __syncthreads();
+        if (ty == 0 && live) {
+            float* dst = csum + (((long long)n * gridDim.x + blockIdx.x) * C + col * EPC) * 2;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float t = 0.0f;
+                for (int r = 0; r < RY; ++r) t += red[(r * CPP + tx) * EPC + e];
+                dst[2 * e] = t;
+            }
         }
     }
 }
 
 template <typename T>
 static void launch_gn_bwd_apply(const GnSlab& g, int N, bool silu, hipStream_t st, const T* x, const T* dy, const float* ss, const float* coef,
-                                const T* add, int HW, int C, int Ctot, int coff, T* dx) {
+                                const T* add, int HW, int C, int Ctot, int coff, T* dx, float* csum) {
     const dim3 grid(g.P, N, g.nz), block(g.cpp, g.ry);
-#define LAUNCH(S, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, S, A>), grid, block, 0, st, x, dy, ss, coef, add, HW, C, Ctot, coff, dx, g.per)
+#define LAUNCH(S, A) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, S, A>), grid, block, 0, st, x, dy, ss, coef, add, HW, C, Ctot, coff, dx, g.per, csum)
     if (silu) {
         if (add) LAUNCH(true, true); else LAUNCH(true, false);
     } else {
@@ -638,8 +663,12 @@ static void launch_gn_bwd_apply(const GnSlab& g, int N, bool silu, hipStream_t s
 #undef LAUNCH
 }
 
+extern "C" int eod_gn_bwd_apply_slabs(int dtype, int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    return gn_slab(N, HW, C, 16 / eod_esize(dtype), 2).P;
+}
 extern "C" int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype, int N,
-                                int HW, int C, int Ctot, int coff, int silu, void* dx, void* stream) {
+                                int HW, int C, int Ctot, int coff, int silu, void* dx, float* csum, void* stream) {
     EOD_REQUIRE(x && dy && scale_shift && coef && dx && N > 0 && HW > 0 && C > 0, "gn_bwd_apply: bad args");
     const int epc = 16 / eod_esize(dtype);
     EOD_REQUIRE(C % epc == 0 && Ctot % epc == 0 && coff % epc == 0, "gn_bwd_apply: channel alignment");
@@ -648,9 +677,9 @@ extern "C" int eod_gn_bwd_apply(const void* x, const void* dy, const float* scal
     const GnSlab g = gn_slab(N, HW, C, epc, 2);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EOD_F16)
-        launch_gn_bwd_apply<half_t>(g, N, silu != 0, st, (const half_t*)x, (const half_t*)dy, scale_shift, coef, (const half_t*)add, HW, C, Ctot, coff, (half_t*)dx);
+        launch_gn_bwd_apply<half_t>(g, N, silu != 0, st, (const half_t*)x, (const half_t*)dy, scale_shift, coef, (const half_t*)add, HW, C, Ctot, coff, (half_t*)dx, csum);
     else
-        launch_gn_bwd_apply<float>(g, N, silu != 0, st, (const float*)x, (const float*)dy, scale_shift, coef, (const float*)add, HW, C, Ctot, coff, (float*)dx);
+        launch_gn_bwd_apply<float>(g, N, silu != 0, st, (const float*)x, (const float*)dy, scale_shift, coef, (const float*)add, HW, C, Ctot, coff, (float*)dx, csum);
     EOD_CHECK_LAUNCH("gn_bwd_apply");
     return EOD_OK;
 }

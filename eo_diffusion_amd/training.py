@@ -712,9 +712,12 @@ class UNetTrainer:
         if direct:
             # bias / timestep-projection gradients = per-channel sums of dY, taken from the NHWC tensor in place
             HW = Ho * Wo
-            Pn = max(1, min(256, HW // 64))
-            csum = bp.empty((N, Pn, dy.C, 2), torch.float32)
-            self._call(L.eod_gn_partial, ptr(dy.t), dt, N, HW, dy.C, ptr(csum), Pn, dy.C, 0)
+            if dy.stats is not None:  # the gradient came straight out of a GroupNorm backward, which summed its channels on the way
+                csum, Pn = dy.stats
+            else:
+                Pn = max(1, min(256, HW // 64))
+                csum = bp.empty((N, Pn, dy.C, 2), torch.float32)
+                self._call(L.eod_gn_partial, ptr(dy.t), dt, N, HW, dy.C, ptr(csum), Pn, dy.C, 0)
             if conv.bias is not None or rec.emb is not None:
                 self._call(L.eod_channel_sums_finish, ptr(csum), N, Pn, dy.C, cout, self.inv_scale,
                            ptr(self._param_grad(conv.bias)) if conv.bias is not None else 0,
@@ -813,8 +816,13 @@ class UNetTrainer:
         for s in rec.srcs:
             dx = bp.act(s.N, s.H, s.W, s.C)
             prev = self._pop_single(s)
+            # per-channel sums of dx on the way: if dx turns out to be the whole output gradient of the conv that produced s, that conv's
+            # bias / timestep-projection gradients come from them (no pass of their own over dY)
+            Ps = L.eod_gn_bwd_apply_slabs(dt, N, HW, s.C)
+            cs = bp.empty((N, Ps, s.C, 2), torch.float32, zero=True)
             self._call(L.eod_gn_bwd_apply, ptr(s.t), ptr(dy.t), ptr(rec.ss), ptr(coef), ptr(prev.t) if prev is not None else 0, dt,
-                       N, HW, s.C, ctot, coff, int(rec.silu), ptr(dx.t))
+                       N, HW, s.C, ctot, coff, int(rec.silu), ptr(dx.t), ptr(cs))
+            dx.stats = (cs, Ps)
             self._add_grad(s, dx)
             coff += s.C
 

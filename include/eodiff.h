@@ -430,7 +430,11 @@ int eod_gn_bwd_finalize(const float* part, int P, int Ctot, int N, int64_t HW, i
                         int64_t dfilm_stride, float* coef, float* gb, void* stream);
 int eod_gn_bwd_params(const float* gb, int N, int Ctot, float scale, float* dgamma, float* dbeta, void* stream);
 int eod_gn_bwd_apply(const void* x, const void* dy, const float* scale_shift, const float* coef, const void* add, int dtype,
-                     int N, int HW, int C, int Ctot, int coff, int silu, void* dx, void* stream);
+                     int N, int HW, int C, int Ctot, int coff, int silu, void* dx, float* csum, void* stream);
+/* csum (optional OUT): per-(image, slab, channel) sums of the stored dx, [N][eod_gn_bwd_apply_slabs(...)][C][2] (sum at [0]): dx is the
+ * output gradient of the conv that produced x, and that conv's bias / timestep-projection gradients are these sums
+ * (eod_channel_sums_finish) -- no separate eod_gn_partial pass over dY. */
+int eod_gn_bwd_apply_slabs(int dtype, int N, int HW, int C);
 int eod_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
 /* nn.Dropout of ResBlock.out_layers (unet_openai.py:339): y = x * keep / (1 - p); keep = Philox4x32-10(seed; element/4, layer, step)
  * -- forward and backward call it with the same key (x = activation / x = gradient), the mask is never stored */

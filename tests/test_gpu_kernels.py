@@ -686,7 +686,7 @@ def test_group_norm_silu_backward_kernels(prec, N, C0, C1, H, W, silu):
     dxs = []
     for xs, c, off in srcs:
         dx = torch.empty_like(xs)
-        _lib.check(L.eod_gn_bwd_apply(xs.data_ptr(), dyd.data_ptr(), ss.data_ptr(), coef.data_ptr(), 0, dt, N, HW, c, Ct, off, int(silu), dx.data_ptr(), st), "gn_bwd_apply")
+        _lib.check(L.eod_gn_bwd_apply(xs.data_ptr(), dyd.data_ptr(), ss.data_ptr(), coef.data_ptr(), 0, dt, N, HW, c, Ct, off, int(silu), dx.data_ptr(), 0, st), "gn_bwd_apply")
         dxs.append(dx.float().cpu().permute(0, 3, 1, 2))
     torch.cuda.synchronize()
     tol = 2e-5 if prec == "fp32" else 3e-3

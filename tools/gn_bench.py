@@ -48,8 +48,8 @@ for (N, HW, C, Ctot) in [(16, 65536, 128, 128), (16, 65536, 128, 256), (16, 1638
         ("gn_partial", nb, lambda: check(L.eod_gn_partial(p(x), dt, N, HW, C, p(part), P, Ctot, 0, st), "gn_partial")),
         ("gn_apply+silu", 2 * nb, lambda: check(L.eod_gn_apply(p(x), dt, N, HW, C, p(ss), Ctot, 0, 1, p(y), 0, st), "gn_apply")),
         ("gn_bwd_partial", 2 * nb, lambda: check(L.eod_gn_bwd_partial(p(x), p(dy), p(ss), dt, N, HW, C, p(part), P, Ctot, 0, 1, st), "bwd_partial")),
-        ("gn_bwd_apply", 3 * nb, lambda: check(L.eod_gn_bwd_apply(p(x), p(dy), p(ss), p(coef), 0, dt, N, HW, C, Ctot, 0, 1, p(dx), st), "bwd_apply")),
-        ("gn_bwd_apply+add", 4 * nb, lambda: check(L.eod_gn_bwd_apply(p(x), p(dy), p(ss), p(coef), p(add), dt, N, HW, C, Ctot, 0, 1, p(dx), st), "bwd_apply")),
+        ("gn_bwd_apply", 3 * nb, lambda: check(L.eod_gn_bwd_apply(p(x), p(dy), p(ss), p(coef), 0, dt, N, HW, C, Ctot, 0, 1, p(dx), 0, st), "bwd_apply")),
+        ("gn_bwd_apply+add", 4 * nb, lambda: check(L.eod_gn_bwd_apply(p(x), p(dy), p(ss), p(coef), p(add), dt, N, HW, C, Ctot, 0, 1, p(dx), 0, st), "bwd_apply")),
     ]
     print(f"N={N} HW={HW} C={C} of Ctot={Ctot} ({a.dtype}, tensor {nb / 2**20:.0f} MiB)")
     for name, byts, fn in rows:
