@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EOD_LIBRARY") or os.path.join(_HERE, "lib", "libeodiff.so")
 
 EOD_F32, EOD_F16 = 0, 1
+ATTN_OUT_PRESPLIT, ATTN_IN_PRESPLIT, ATTN_EXACT_F32 = 1, 2, 4  # eod_attention_fwd_nat flags
 (OP_CONV, OP_GEMM, OP_GN_PARTIAL, OP_GN_FINALIZE, OP_GN_APPLY, OP_SOFTMAX, OP_TEMB, OP_TO_NHWC, OP_TO_NCHW,
  OP_POOL, OP_ATTN, OP_TRANSPOSE, OP_ATTN_NAT, OP_DROPOUT, OP_ACT_BOUND, OP_BOUND_AFFINE) = range(1, 17)
 
@@ -99,7 +100,7 @@ SYMBOLS = {
     "eod_dropout": (i32, [vp, vp, i32, i64, f32, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
     "eod_rowdot": (i32, [vp, vp, i32, i64, i64, i64, i64, i64, i64, i32, vp, vp]),
     "eod_scale_f32": (i32, [vp, i64, f32, vp]),
-    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "eod_attention_fwd_nat": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "eod_weight_l1max": (i32, [vp, i32, i32, vp, vp, vp]),
     "eod_bound_affine": (i32, [vp, vp, vp, i32, vp]),
     "eod_attention_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

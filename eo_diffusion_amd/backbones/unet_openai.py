@@ -376,10 +376,9 @@ class ResBlock(TimestepBlock):
 def _qkv_attention_standalone(mod, qkv):
     """QKVAttention(Legacy).forward(qkv) (unet_openai.py:465-481 / 497-515) as its own call: qkv [N, 3*H*d, T] -> [N, H*d, T].
     One layout pass to the kernels' [N][T][3C] form, the fused attention kernel (eod_attention_fwd_nat; the T x T weights never exist),
-    one pass back.  Precision = EOD_PRECISION (a bare QKVAttention module has no enclosing model to ask): fp16 -> fp16 storage; fp32x3
-    AND fp32 -> fp32 in and out, fp32 softmax, both contractions as split-fp16 products (~2^-22 per product, safe at any magnitude: the
-    operand scale comes from a max|x| pass over qkv).  There is no exact-fp32-MFMA instance of the fused kernel: the `fp32` mode is
-    SUBSTITUTED by the fp32x3 product here (same 1e-5 gate); inside AttentionBlock the exact mode keeps its exact GEMM path."""
+    one pass back.  Precision = EOD_PRECISION (a bare QKVAttention module has no enclosing model to ask): fp16 -> fp16 storage and
+    MFMA; fp32x3 -> fp32 in and out, fp32 softmax, both contractions as split-fp16 products (~2^-22 per product, safe at any magnitude:
+    the operand scale comes from a max|x| pass over qkv); fp32 -> the same with exact fp32 MFMA products (csrc/attn_f32.hip)."""
     require_gpu(qkv, type(mod).__name__)
     bs, width, length = qkv.shape
     nh = mod.n_heads
@@ -389,8 +388,7 @@ def _qkv_attention_standalone(mod, qkv):
     if d % 8 or d > 64:
         raise _lib.EodError(f"{type(mod).__name__} standalone: head dim {d} must be a multiple of 8 and <= 64 (inside AttentionBlock the "
                             "other head sizes run through the GEMM path)")
-    prec = default_precision()
-    prog = Program(qkv.device, "fp16" if prec == "fp16" else "fp32x3")
+    prog = Program(qkv.device, default_precision())
     a0, i_in = prog.to_nhwc(bs, width, 0, 1, length, width)
     xin = qkv.detach().contiguous().float()
     prog.ops[i_in].u.small.p[0] = xin.data_ptr()
@@ -472,10 +470,11 @@ class AttentionBlock(_Emitter):
         assert x.C == Cc
         N, T = x.N, x.HW
         d_nat = Cc // nh
-        if (prog.precision in ("fp16", "fp32x3") and d_nat % 8 == 0 and d_nat <= 64 and os.environ.get("EOD_ATTN", "nat") == "nat"):
+        if d_nat % 8 == 0 and d_nat <= 64 and os.environ.get("EOD_ATTN", "nat") == "nat":
             # fused attention straight on the qkv projection's natural channel layout (legacy [h][q|k|v][d], new [q|k|v][h][d]):
-            # one projection GEMM, no packed q|k / transposed v operands, T x T never materialised (eod_attention_fwd_nat;
-            # fp32x3: fp32 in / out with split-fp16 products, the projections run as 1x1 convs of the same product type)
+            # one projection GEMM, no packed q|k / transposed v operands, T x T never materialised in ANY precision mode
+            # (eod_attention_fwd_nat; fp16: fp16 MFMA; fp32x3: fp32 in / out with split-fp16 products, the projections run as 1x1 convs
+            # of the same product type; fp32: exact fp32 MFMA, csrc/attn_f32.hip)
             qo, ko, vo, hs = (0, Cc, 2 * Cc, d_nat) if self.attention.new_order else (0, d_nat, 2 * d_nat, 3 * d_nat)
             xn = prog.group_norm([x], prog.f32(self.norm.weight), prog.f32(self.norm.bias), silu=False, eps=self.norm.eps,
                                  split_out=prog.split)  # (fp32x3: written pre-split for the qkv conv, its only consumer)

@@ -471,13 +471,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(const AttnFwdP p) 
 
 int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int d, int q_off, int k_off, int v_off,
                              int head_stride, const float* qkv_bound, int out_presplit, int in_presplit, hipStream_t st);  // csrc/attn_x3.hip
+int eod_attention_fwd_nat_f32(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int d, int q_off, int k_off, int v_off,
+                              int head_stride, hipStream_t st);  // csrc/attn_f32.hip
 
 extern "C" int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off,
-                                     int k_off, int v_off, int head_stride, const float* qkv_bound, int out_presplit, int in_presplit,
-                                     void* stream) {
+                                     int k_off, int v_off, int head_stride, const float* qkv_bound, int flags, void* stream) {
+    const int out_presplit = (flags & EOD_ATTN_OUT_PRESPLIT) != 0, in_presplit = (flags & EOD_ATTN_IN_PRESPLIT) != 0;
     EOD_REQUIRE(qkv && out && N > 0 && T > 0 && heads > 0 && d > 0 && C == heads * d, "attention_fwd_nat: bad args");
     EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "attention_fwd_nat: bad dtype %d", dtype);
     EOD_REQUIRE(d % 8 == 0 && d <= 64, "attention_fwd_nat: the head dim must be a multiple of 8 and <= 64");
+    if (dtype == EOD_F32 && (flags & EOD_ATTN_EXACT_F32)) {  // exact fp32 mode: IEEE fp32 products on v_mfma_f32_32x32x2_f32 (csrc/attn_f32.hip)
+        EOD_REQUIRE(!out_presplit && !in_presplit, "attention_fwd_nat: pre-split tensors belong to the split-fp16 product, not to the exact fp32 one");
+        return eod_attention_fwd_nat_f32((const float*)qkv, (float*)out, lse, N, T, C, heads, d, q_off, k_off, v_off, head_stride, (hipStream_t)stream);
+    }
     if (dtype == EOD_F32) {  // fp32 storage: fp32-grade products as three fp16 MFMAs on split operands (csrc/attn_x3.hip)
         EOD_REQUIRE((long long)T * 3 * C * 4 < 0x7fffffffLL * 4LL, "attention_fwd_nat: sequence too long");
         return eod_attention_fwd_nat_x3((const float*)qkv, (float*)out, lse, N, T, C, heads, d, q_off, k_off, v_off, head_stride, qkv_bound,

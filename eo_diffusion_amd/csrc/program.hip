@@ -10,7 +10,7 @@
 //   GN_FINALIZE: p[0]=part0 p[1]=gamma p[2]=beta p[3]=film p[4]=scale_shift p[5]=part1 p[6]=ab_raw p[7]=ab_norm   l = {HW, film_stride}
 //                i = {N, P0, C0, groups, P1, C1}    f = {eps}
 //   ACT_BOUND  : p[0]=x p[1]=part0 p[2]=part1 p[3]=ab     l = {per_image}   i = {dtype, N, P0, C0, P1, C1, accumulate}
-//   ATTN_NAT   : p[0]=qkv p[1]=out p[2]=lse p[3]=qkv_bound   i = {dtype, N, T, C, heads, d, q_off, k_off, v_off, head_stride}   l = {out_presplit, in_presplit}
+//   ATTN_NAT   : p[0]=qkv p[1]=out p[2]=lse p[3]=qkv_bound   i = {dtype, N, T, C, heads, d, q_off, k_off, v_off, head_stride}   l = {flags}
 //   BOUND_AFFINE: p[0]=ab_in p[1]=coef p[2]=ab_out   i = {N}
 //   GN_APPLY   : p[0]=x p[1]=scale_shift p[2]=y p[3]=split_bound   i = {dtype, N, HW, C, Ctot, coff, silu}
 //   SOFTMAX    : p[0]=s p[1]=p               l = {lds, ldp, rows}   i = {dtype, n}
@@ -125,7 +125,7 @@ static int run_impl(const eod_op* ops, int n_ops, void* stream, eod_timer* tm) {
             case EOD_OP_ATTN: rc = eod_attention_fwd(&o.u.attn, stream); break;
             case EOD_OP_ATTN_NAT:
                 rc = eod_attention_fwd_nat(s.p[0], (void*)s.p[1], (float*)s.p[2], s.i[0], s.i[1], s.i[2], s.i[3], s.i[4], s.i[5], s.i[6], s.i[7], s.i[8],
-                                           s.i[9], (const float*)s.p[3], (int)s.l[0], (int)s.l[1], stream);
+                                           s.i[9], (const float*)s.p[3], (int)s.l[0], stream);
                 break;
             case EOD_OP_BOUND_AFFINE:
                 rc = eod_bound_affine((const float*)s.p[0], (const float*)s.p[1], (float*)s.p[2], s.i[0], stream);

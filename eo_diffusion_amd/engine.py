@@ -521,7 +521,9 @@ class Program:
         """fused attention on the natural qkv layout [N][T][3C] (head dim % 8 == 0 and <= 64, any T): eod_attention_fwd_nat.  fp32 storage
         (fp32x3): qkv_bound = bound table [N][32] of qkv (None: |q|, |k|, |v| < 4094 guaranteed by the caller); out_presplit: `out` is
         written pre-split (scale from qkv_bound) for the proj_out conv"""
-        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse), ptr(qkv_bound)), l=(int(out_presplit), int(in_presplit)),
+        flags = (_lib.ATTN_OUT_PRESPLIT if out_presplit else 0) | (_lib.ATTN_IN_PRESPLIT if in_presplit else 0) | \
+            (_lib.ATTN_EXACT_F32 if self.precision == "fp32" else 0)  # (the exact mode: IEEE fp32 products, csrc/attn_f32.hip)
+        return self._small(OP_ATTN_NAT, p=(ptr(qkv), ptr(out), ptr(lse), ptr(qkv_bound)), l=(flags,),
                            i=(self.dt, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride))
 
     def softmax_rows(self, s_f32, lds, p_out, ldp, rows, n):

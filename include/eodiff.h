@@ -454,13 +454,16 @@ int eod_scale_f32(float* x, int64_t n, float s, void* stream);
  *   EOD_F16: K / V tiles staged row-major by LDS-DMA, V^T through transposed LDS reads (csrc/attn_bwd.hip)
  *   EOD_F32: fp32 in / out, fp32 online softmax, both contractions as three fp16 MFMAs per product on operands split into
  *            hi + lo halves (fp32-grade, ~2^-22 per product; csrc/attn_x3.hip) */
+enum { EOD_ATTN_OUT_PRESPLIT = 1, EOD_ATTN_IN_PRESPLIT = 2, EOD_ATTN_EXACT_F32 = 4 };
 int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off, int k_off,
-                          int v_off, int head_stride, const float* qkv_bound, int out_presplit, int in_presplit, void* stream);
-/* qkv_bound (EOD_F32 only): bound table [N][32] of the qkv tensor (eod_conv_desc.a_bound); NULL = |q|, |k|, |v| < 4094 guaranteed.
- * out_presplit (EOD_F32 only): `out` is written pre-split for a split-fp16 conv (eod_conv_desc.x_presplit with a_bound = qkv_bound:
- * rows of out are convex combinations of v rows, so the table of qkv bounds them).
- * in_presplit (EOD_F32 only): qkv arrives pre-split (eod_conv_desc.y_presplit_bound = qkv_bound): q fragments are loaded as they are, K / V
- * tiles staged by LDS-DMA, no split arithmetic in the kernel. */
+                          int v_off, int head_stride, const float* qkv_bound, int flags, void* stream);
+/* EOD_F32 only.  qkv_bound: bound table [N][32] of the qkv tensor (eod_conv_desc.a_bound); NULL = |q|, |k|, |v| < 4094 guaranteed.
+ * flags: EOD_ATTN_OUT_PRESPLIT: `out` is written pre-split for a split-fp16 conv (eod_conv_desc.x_presplit with a_bound = qkv_bound:
+ *        rows of out are convex combinations of v rows, so the table of qkv bounds them);
+ *        EOD_ATTN_IN_PRESPLIT: qkv arrives pre-split (eod_conv_desc.y_presplit_bound = qkv_bound): q fragments are loaded as they are,
+ *        K / V tiles staged by LDS-DMA, no split arithmetic in the kernel;
+ *        EOD_ATTN_EXACT_F32: IEEE fp32 products (v_mfma_f32_32x32x2_f32, csrc/attn_f32.hip) instead of the split-fp16 ones -- the
+ *        fused kernel of the exact `fp32` precision mode (no bound table, no pre-split tensors). */
 /* flash-style attention backward (fp16, head dim a multiple of 8 and <= 64, any T): dqkv [N][T][3C] from qkv [N][T][3C] (channel = q_off /
  * k_off / v_off + head*head_stride + j), dO [N][T][C], the forward's log-sum-exp lse [N][heads][T] (eod_attn_desc.lse) and
  * D[n][h][t] = sum_j dO*O (eod_rowdot).  P is rebuilt tile by tile in registers: nothing T x T touches HBM (csrc/attn_bwd.hip) */

@@ -261,7 +261,7 @@ def test_attention_qkv_of_any_magnitude(kind, T, heads, d):
     ab = torch.zeros((N, 32), dtype=torch.float32, device=DEV)
     st = current_stream_ptr(torch.device(DEV))
     _lib.check(L.eod_act_bound(qd.data_ptr(), _lib.EOD_F32, N, T * 3 * C, 0, 0, 0, 0, 0, 0, ab.data_ptr(), 0, st), "act_bound")
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), 0, _lib.EOD_F32, N, T, C, heads, d, 0, d, 2 * d, hs, ab.data_ptr(), 0, 0, st),
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), 0, _lib.EOD_F32, N, T, C, heads, d, 0, d, 2 * d, hs, ab.data_ptr(), 0, st),
                "attention_fwd_nat")
     torch.cuda.synchronize()
     got = out.cpu()

@@ -507,7 +507,7 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits
     qd = qh.to(DEV)
     out = torch.empty((N * T, C), dtype=torch.float16, device=DEV)
     lse = torch.empty((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0, 0, st),
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0, st),
                "attention_fwd_nat")
     assert rel_l2(out.float().cpu().reshape(N, T, C), O.detach()) < 3e-3
     lse_ref = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) / math.sqrt(d), -1)
@@ -548,7 +548,7 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
     qd = qkv.to(DEV)
     out = torch.full((N, T, C), 9.0, dtype=torch.float16, device=DEV)
     lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
-    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0, 0,
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F16, N, T, C, heads, d, qo, ko, vo, hs, 0, 0,
                                        current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu(), ref) < 3e-3
@@ -581,7 +581,7 @@ def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, boun
     if bound:
         _lib.check(L.eod_act_bound(qd.data_ptr(), _lib.EOD_F32, N, T * 3 * C, 0, 0, 0, 0, 0, 0, ab.data_ptr(), 0, st), "act_bound")
     _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F32, N, T, C, heads, d, qo, ko, vo, hs,
-                                       ab.data_ptr() if bound else 0, 0, 0, st), "attention_fwd_nat")
+                                       ab.data_ptr() if bound else 0, 0, st), "attention_fwd_nat")
     torch.cuda.synchronize()
     if bound:
         assert torch.equal(ab.cpu().max(1).values, qkv.abs().amax((1, 2)))  # the direct pass is the exact max|x| per image
@@ -589,6 +589,36 @@ def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, boun
     f32 = rel_l2((torch.softmax(S.float(), -1) @ v.float()).permute(0, 2, 1, 3).reshape(N, T, C), ref)  # what plain fp32 torch gives
     print(f"T={T} d={d} mag={mag}: fused fp32x3 attention {err:.2e}, torch fp32 {f32:.2e}")
     assert err < 2e-6
+    assert float((lse.cpu().double() - torch.logsumexp(S, -1)).abs().max()) < 2e-5 * max(1.0, float(S.abs().max()))
+
+
+@pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
+                                                 (64, 4, 8, False), (300, 3, 24, False), (256, 1, 40, True), (130, 2, 56, False)])
+@pytest.mark.parametrize("mag", [0.8, 4.0])
+def test_attention_forward_natural_layout_exact_fp32(T, heads, d, new_order, mag):
+    """the exact-fp32 instance of eod_attention_fwd_nat (EOD_ATTN_EXACT_F32: IEEE fp32 products on v_mfma_f32_32x32x2_f32, fp32 online
+    softmax; the fused kernel of the exact `fp32` precision mode, csrc/attn_f32.hip) vs a float64 softmax(q k^T / sqrt(d)) v: every
+    head dim that is a multiple of 8 up to 64, both channel orders, ragged sequence lengths, peaked softmax rows (mag 4)"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import current_stream_ptr
+    L = _lib.lib()
+    N, C = 2, heads * d
+    qkv = synth_input(f"fx32{T}{d}", (N, T, 3 * C), 9, scale=mag)
+    qo, ko, vo, hs = (0, C, 2 * C, d) if new_order else (0, d, 2 * d, 3 * d)
+    pick = lambda off: torch.stack([qkv.double()[:, :, off + h * hs: off + h * hs + d] for h in range(heads)], 1)
+    q, k, v = pick(qo), pick(ko), pick(vo)
+    S = q @ k.transpose(-1, -2) / math.sqrt(d)
+    ref = (torch.softmax(S, -1) @ v).permute(0, 2, 1, 3).reshape(N, T, C)
+    qd = qkv.to(DEV)
+    out = torch.full((N, T, C), 9.0, dtype=torch.float32, device=DEV)
+    lse = torch.zeros((N, heads, T), dtype=torch.float32, device=DEV)
+    _lib.check(L.eod_attention_fwd_nat(qd.data_ptr(), out.data_ptr(), lse.data_ptr(), _lib.EOD_F32, N, T, C, heads, d, qo, ko, vo, hs, 0,
+                                       _lib.ATTN_EXACT_F32, current_stream_ptr(torch.device(DEV))), "attention_fwd_nat")
+    torch.cuda.synchronize()
+    err = rel_l2(out.cpu(), ref)
+    f32 = rel_l2((torch.softmax(S.float(), -1) @ v.float()).permute(0, 2, 1, 3).reshape(N, T, C), ref)  # what plain fp32 torch gives
+    print(f"T={T} d={d} mag={mag}: fused exact-fp32 attention {err:.2e}, torch fp32 {f32:.2e}")
+    assert err < 2e-6 and err < 4 * f32 + 3e-7
     assert float((lse.cpu().double() - torch.logsumexp(S, -1)).abs().max()) < 2e-5 * max(1.0, float(S.abs().max()))
 
 
