@@ -173,19 +173,28 @@ def test_unet_non_square_and_odd_batch(prec, shape):
 
 
 def test_timestep_embedding_standalone_vs_golden():
-    """timestep_embedding (unet_openai.py:81-99) as its own call, against what the reference returned for t in {0, 1, 499, 999}
-    at dims 32 / 128 / 33 (odd: one zero column).  The arguments reach 999 rad, so this also pins the range reduction.
-    Tolerance: the frequency table exp(-ln(1e4) k / half) is evaluated by torch's CPU exp on the HOST, whose last bit depends on
-    the CPU model (SLEEF AVX2 vs AVX-512 paths; the fixture was written on another machine): one ulp of a frequency moves the
-    argument t*f by up to 1.2e-7 * t, and the sinusoid by as much."""
+    """timestep_embedding (unet_openai.py:81-99) as its own call.
+    (1) SAME-MACHINE check, gate 2e-6: the kernel against the oracle's own restatement evaluated on THIS host -- both take their
+        frequency table exp(-ln(1e4) k / half) from this machine's torch CPU exp, so nothing machine-dependent is left between them
+        (arguments reach 999 rad: this pins the range reduction of sin / cos).
+    (2) against what the reference returned on the machine that wrote the fixture (t in {0, 1, 499, 999}, dims 32 / 128 / 33): torch's
+        CPU exp differs in the last bit between CPU models (SLEEF AVX2 vs AVX-512 paths), one ulp of a frequency (6e-8 relative) moves
+        the argument t*f by up to 1.2e-7 * t, and the sinusoid by as much: gate 2e-6 + 1.2e-7 * t, the derived bound."""
     from eo_diffusion_amd.backbones.unet_openai import timestep_embedding
+    from oracle import unet_ref as UR
     g = gt("temb")
     for dim in (32, 128, 33):
         e = timestep_embedding(g["t"].to(DEV), dim).cpu()
         ref = g[f"d{dim}"]
         assert e.shape == ref.shape and e.dtype == torch.float32
-        tol = 2e-6 + 2.5e-7 * g["t"].float()[:, None]  # values are in [-1, 1]: absolute = relative to the scale
+        here = UR.timestep_embedding(g["t"], dim)  # the oracle on this host
+        assert float((e - here).abs().max()) <= 2e-6, (dim, float((e - here).abs().max()))
+        tol = 2e-6 + 1.2e-7 * g["t"].float()[:, None]  # values are in [-1, 1]: absolute = relative to the scale
         assert bool(((e - ref).abs() <= tol).all()), (dim, float((e - ref).abs().max()))
+    tt = torch.tensor([0, 1, 7, 250, 499, 731, 998, 999])
+    for dim in (64, 128):  # more timesteps on the same-machine gate
+        e = timestep_embedding(tt.to(DEV), dim).cpu()
+        assert float((e - UR.timestep_embedding(tt, dim)).abs().max()) <= 2e-6
     frac = timestep_embedding(torch.tensor([0.5, 10.25], device=DEV), 8).cpu()  # fractional timesteps are allowed
     assert bool(torch.isfinite(frac).all()) and float((frac[:, :4] ** 2 + frac[:, 4:] ** 2 - 1).abs().max()) < 1e-6
 
