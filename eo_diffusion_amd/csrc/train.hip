@@ -1019,7 +1019,11 @@ __global__ void nonfinite_blocks_kernel(const float* __restrict__ g, long long n
     __syncthreads();
     if (threadIdx.x == 0) block_flags[blockIdx.x] = sh[0] | sh[1] | sh[2] | sh[3];
 }
-__global__ void nonfinite_fold_kernel(const int* __restrict__ block_flags, int nblocks, int* __restrict__ state) {
+// state = {this step skipped, steps skipped so far, bits(sqrt(1 - beta2^a)), bits(-lr / (1 - beta1^a))} with a = the number of steps
+// APPLIED so far including this one (= calls - skipped): a skipped step never reaches the optimizer (torch.cuda.amp.GradScaler
+// semantics), so the bias corrections follow the count of moment updates, computed here on the device (no host round trip)
+__global__ void nonfinite_fold_kernel(const int* __restrict__ block_flags, int nblocks, int* __restrict__ state, int calls, double lr, double beta1,
+                                      double beta2) {
     int bad = 0;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) bad |= block_flags[i];
     bad = __any(bad);
@@ -1030,12 +1034,16 @@ __global__ void nonfinite_fold_kernel(const int* __restrict__ block_flags, int n
         const int f = sh[0] | sh[1] | sh[2] | sh[3];
         state[0] = f;
         state[1] += f;
+        const int applied = calls - state[1] > 1 ? calls - state[1] : 1;
+        state[2] = __float_as_int((float)sqrt(1.0 - pow(beta2, (double)applied)));
+        state[3] = __float_as_int((float)(-(lr / (1.0 - pow(beta1, (double)applied)))));
     }
 }
 __global__ void adamw_guarded_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                                     float decay_mul, float beta1, float one_m_beta1, float beta2, float one_m_beta2, float bc2_sqrt, float eps,
-                                     float neg_step_size, const int* __restrict__ state) {
+                                     float decay_mul, float beta1, float one_m_beta1, float beta2, float one_m_beta2, float eps,
+                                     const int* __restrict__ state) {
     if (state[0]) return;  // this step's gradients are not finite: skipped (uniform over the grid)
+    const float bc2_sqrt = __int_as_float(state[2]), neg_step_size = __int_as_float(state[3]);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i];
         float pi = p[i] * decay_mul;
@@ -1052,17 +1060,14 @@ __global__ void adamw_guarded_kernel(float* __restrict__ p, const float* __restr
 extern "C" int eod_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                                       double weight_decay, int step, int* state, int* scratch, int scratch_len, void* stream) {
     EOD_REQUIRE(p && g && m && v && n > 0 && step >= 1 && state && scratch && scratch_len >= 1, "adamw_step_guarded: bad args");
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    const double step_size = lr / bc1;
     long long blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     int cb = (int)(blocks < scratch_len ? blocks : scratch_len);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(nonfinite_blocks_kernel, dim3((unsigned)cb), dim3(256), 0, st, g, (long long)n, scratch);
-    hipLaunchKernelGGL(nonfinite_fold_kernel, dim3(1), dim3(256), 0, st, (const int*)scratch, cb, state);
+    hipLaunchKernelGGL(nonfinite_fold_kernel, dim3(1), dim3(256), 0, st, (const int*)scratch, cb, state, step, lr, beta1, beta2);
     hipLaunchKernelGGL(adamw_guarded_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, (float)(1.0 - lr * weight_decay),
-                       (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-step_size),
-                       (const int*)state);
+                       (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (const int*)state);
     EOD_CHECK_LAUNCH("adamw_step_guarded");
     return EOD_OK;
 }

@@ -66,7 +66,7 @@ class AdamW(torch.optim.Optimizer):
             for p, v in zip(ps, views):
                 p.data = v  # same values, now contiguous in one buffer
             st = dict(params=ps, p=flat_p, g=torch.zeros_like(flat_p), m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), step=0,
-                      gviews=[None] * len(ps), guard=torch.zeros((2,), dtype=torch.int32, device=dev),
+                      gviews=[None] * len(ps), guard=torch.zeros((4,), dtype=torch.int32, device=dev),
                       scratch=torch.zeros((8192,), dtype=torch.int32, device=dev))
             off = 0
             for k, p in enumerate(ps):
@@ -99,18 +99,24 @@ class AdamW(torch.optim.Optimizer):
                     base + 4 * st["p"].numel() <= owner.untyped_storage().data_ptr() + owner.untyped_storage().nbytes()
             else:
                 in_place = False
+            def keep(p, o):  # value AND moments of a parameter without a gradient: torch.optim.AdamW leaves all three alone
+                sl = slice(o, o + p.numel())
+                untouched.append((p, p.detach().clone(), sl, st["m"][sl].clone(), st["v"][sl].clone()))
+            off = 0
             if in_place:
                 gptr = base
                 for p in st["params"]:
                     if p.grad is None:  # (its slice of the flat buffer is never written by the backward: zeros)
-                        untouched.append((p, p.detach().clone()))
+                        keep(p, off)
+                    off += (p.numel() + 3) // 4 * 4
             else:
                 for p, gv in zip(st["params"], st["gviews"]):
                     if p.grad is None:
                         gv.zero_()
-                        untouched.append((p, p.detach().clone()))
+                        keep(p, off)
                     elif p.grad.data_ptr() != gv.data_ptr():
                         gv.copy_(p.grad)
+                    off += (p.numel() + 3) // 4 * 4
             st["step"] += 1
             b1, b2 = group["betas"]
             if self.skip_nonfinite:
@@ -122,8 +128,10 @@ class AdamW(torch.optim.Optimizer):
                 check(L.eod_adamw_step(ptr(st["p"]), gptr, ptr(st["m"]), ptr(st["v"]), st["p"].numel(), float(group["lr"]), float(b1),
                                        float(b2), float(group["eps"]), float(group["weight_decay"]), st["step"], current_stream_ptr(st["p"].device)),
                       "eod_adamw_step")
-            for p, keep in untouched:  # (zero gradient -> m, v stay as they were; only the decoupled weight decay has to be undone)
-                p.detach().copy_(keep)
+            for p, val, sl, m0, v0 in untouched:  # undo the weight decay and the moment decay a zero gradient went through
+                p.detach().copy_(val)
+                st["m"][sl].copy_(m0)
+                st["v"][sl].copy_(v0)
             for p in st["params"]:  # written through the flat buffer: advance torch's version counters (the packed-weight
                 torch.autograd.graph.increment_version(p)  # caches of the kernels key on them); no kernel is launched
         return loss

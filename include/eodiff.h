@@ -493,9 +493,10 @@ int eod_mse_loss(const float* pred, const float* target, int64_t n, float* loss,
 int eod_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int step, void* stream);
 /* the same step behind an overflow guard (fp16 training with a static loss scale): if any gradient is inf / NaN the step is SKIPPED
- * (p, m, v untouched).  state (device, 2 ints, zero-initialised by the caller once) = {this step was skipped, steps skipped so far};
- * scratch: scratch_len (>= 1, up to 8192 used) ints.  The caller advances `step` only for steps that were applied, or accepts the
- * slightly early bias correction.  No host synchronisation. */
+ * (p, m, v untouched).  state (device, 4 ints, zero-initialised by the caller once) = {this step was skipped, steps skipped so far,
+ * two floats of the kernel's own}; scratch: scratch_len (>= 1, up to 8192 used) ints.  `step` = the 1-based number of CALLS; the bias
+ * corrections use step - (steps skipped so far), i.e. the number of moment updates, computed on the device: a skipped step never
+ * reaches the optimizer, as with torch.cuda.amp.GradScaler.  No host synchronisation. */
 int eod_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                            double weight_decay, int step, int* state, int* scratch, int scratch_len, void* stream);
 /* EMA of script_utils/utils.py:56-67: avg = decay*avg + (1-decay)*p */
