@@ -48,7 +48,9 @@ PEAK_NOTE = {"fp32x3": "fp32 storage; each product = 3 fp16 MFMAs (v_mfma_f32_16
 DTYPE_NAME = {"fp32": "f32", "fp32x3": "f32", "fp16": "f16"}
 TOLERANCE = {"fp32": "rel-L2 <= 1e-5 per UNet forward vs the fp32 CPU oracle (fp32 storage, exact fp32 MFMA)",
              "fp32x3": "rel-L2 <= 1e-5 per UNet forward vs the fp32 CPU oracle -- the SAME gate as the exact-fp32 mode (fp32 storage; "
-                       "3x3 convs as three fp16 MFMAs per product on hi+lo split operands, ~2^-22 per product, fp32 accumulate)",
+                       "every conv / attention product as three fp16 MFMAs on hi+lo split operands, ~2^-22 per product, fp32 accumulate; "
+                       "operands scaled by a power of two per image, derived on the device from the tensor's bound table: valid for "
+                       "inputs of any magnitude -- tests/test_gpu_fp32x3_domain.py)",
              "fp16": "rel-L2 <= 5e-3 per UNet forward vs the fp32 CPU oracle (fp16 storage, fp16 MFMA, fp32 accumulate)"}
 HBM_PEAK = 8.0e12
 
