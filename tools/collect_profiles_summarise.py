@@ -129,7 +129,7 @@ def per_kernel_frac(stats_csv, ops_json, steps_total, out_name, prec="fp32x3"):
     for key in t:
         fl = fl_gen if key == "igemm_kernel" else flops.get(key, 0.0)
         sec = t[key] * 1e-9
-        steps = n[key] / max(1, launches.get(key, 0) + (launches.get("igemm_kernel<gemm>", 0) if key == "igemm_kernel" else 0)) if fl else 0
+        steps = steps_total if fl else 0  # (an op may be two launches: 384-column convs = 256 + 128 columns)
         res["kernels"][key] = {"calls": n[key], "total_ms": t[key] / 1e6, "avg_us": t[key] / max(1, n[key]) / 1e3, "share_of_gpu_time": t[key] / total,
                                "algorithmic_tflops": (fl * steps / sec / 1e12) if fl and sec else None,
                                "frac_of_mfma_peak": (fl * steps / sec / PEAK[prec]) if fl and sec else None}
