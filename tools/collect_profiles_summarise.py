@@ -53,7 +53,8 @@ def counters(dirname, match=""):
     """kernel -> counter -> [sum, n]; plus kernel -> [ns, n] from the rows of one counter"""
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     dur = defaultdict(lambda: [0.0, 0])
-    for path in glob.glob(os.path.join(OUT, dirname, "**", "*counter_collection.csv"), recursive=True):
+    dur_from = {}
+    for path in sorted(glob.glob(os.path.join(OUT, dirname, "**", "*counter_collection.csv"), recursive=True)):
         for row in csv.DictReader(open(path)):
             k = row["Kernel_Name"]
             if match and match not in k:
@@ -62,8 +63,10 @@ def counters(dirname, match=""):
             c[0] += float(row["Counter_Value"])
             c[1] += 1
             if row["Counter_Name"] in ("GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "FETCH_SIZE"):
-                dur[k][0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
-                dur[k][1] += 1
+                # durations from the rows of ONE counter per kernel (a two-pass input file would count every launch twice)
+                if dur_from.setdefault(k, row["Counter_Name"]) == row["Counter_Name"]:
+                    dur[k][0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                    dur[k][1] += 1
     return acc, dur
 
 
