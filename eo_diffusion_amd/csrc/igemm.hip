@@ -384,10 +384,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                 }
                 if (cb_per_row) {
                     int nrel, ho, wo;
-                    decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo);
+                    // rows behind the last image (M tail of the last tile) are never stored: they must not index the table either -- image
+                    // N of a [N][stride] table lies behind its allocation (found by tests/test_gpu_fuzz_archs.py as an intermittent fault)
+                    const bool rok = decode_row<BM>(p, g, wm * WM + rw, nrel, ho, wo);
                     const float* cbp = p.cbias + (long long)(g.n_first + nrel) * p.cbias_stride;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) cb[j] = cok[j] ? cbp[col[j]] : 0.0f;
+                    for (int j = 0; j < TN; ++j) cb[j] = (rok && cok[j]) ? cbp[col[j]] : 0.0f;
                 }
             } else {
                 if (p.bias && p.bias_mode >= 2) {

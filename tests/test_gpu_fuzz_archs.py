@@ -1,0 +1,97 @@
+"""GPU: seeded random UNet configurations against the CPU oracle, all three precision modes.
+
+The golden fixtures pin eight hand-picked configurations and the BASELINE tests pin A0 / A1; this test walks the constructor space of
+UNetModel (unet_openai.py:553-575) at random -- widths that are not powers of two, 2-4 levels, attention at arbitrary levels with
+heads given either way, FiLM / resblock_updown / new attention order / plain resampling, class and concat conditioning, odd and
+non-square maps, batch 1-3 -- so that every dispatch decision of the engine (halo vs generic vs split-K kernels, 64 / 128 / 256-column
+instances, fused vs separate GroupNorm, fused 1x1 skip, parity-class upsample convs, natural-layout vs GEMM attention, pre-split
+operands and bound tables in fp32x3) is exercised on shapes nobody chose by hand.  Sizes keep the oracle at well under a second per case."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import DEV, TOL
+from tests.helpers import rel_l2
+from tests.synth import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+N_CASES = 28
+
+
+def poison_allocator_cache():
+    """Fill what the caching allocator will hand out next with NaN bit patterns (0xFF bytes are NaN in fp16 and fp32): a kernel that
+    reads beyond the logical extent of a buffer, or a buffer it never wrote, then shows up as NaN in the result even where the stray
+    value only ever meets a zero weight -- and deterministically, instead of as a memory fault on the one layout where the stray read
+    crosses the end of a mapped segment."""
+    small = [torch.full((1 << 18,), float("nan"), device=DEV) for _ in range(192)]   # 1 MiB blocks: the small pool's 2 MiB segments
+    large = [torch.full((1 << 26,), float("nan"), device=DEV) for _ in range(4)]     # 256 MiB blocks: the large pool
+    torch.cuda.synchronize()
+    del small, large
+
+
+def _random_cfg(i):
+    r = np.random.RandomState(1000 + i)
+    levels = int(r.choice([2, 3, 3, 4]))
+    mc = int(r.choice([32, 32, 64, 64, 96]))
+    mult = [1] + [int(r.choice([1, 2, 2, 3, 4])) for _ in range(levels - 1)]
+    # map sizes whose every level stays >= 2 pixels, the deepest one possibly odd, some non-square.  No level may be 3 wide: the
+    # reference's Upsample turns a 3 x 3 map into 7 x 7 (unet_openai.py:236-239, the 28 -> 14 -> 7 -> 3 path), which only fits a 7-wide skip
+    base = 2 ** (levels - 1)
+    H = int(base * r.choice([2, 4, 5, 6, 7, 8]))
+    W = int(base * r.choice([2, 4, 5, 6, 8])) if r.rand() < 0.4 else H
+    if max(H, W) > 64:
+        H, W = min(H, 64), min(W, 64)
+    in_ch = int(r.choice([1, 3, 3, 4, 13]))
+    cond_ch = int(r.choice([0, 0, 0, in_ch]))
+    attn = sorted({int(2 ** k) for k in range(levels) if r.rand() < 0.45})
+    cfg = dict(image_size=H, in_channels=in_ch + cond_ch, out_channels=in_ch, model_channels=mc, channel_mult=mult,
+               num_res_blocks=int(r.choice([1, 1, 2])), attention_resolutions=attn,
+               use_scale_shift_norm=bool(r.rand() < 0.35), resblock_updown=bool(r.rand() < 0.35),
+               use_new_attention_order=bool(r.rand() < 0.5), conv_resample=bool(r.rand() < 0.8))
+    if r.rand() < 0.5:
+        cfg["num_head_channels"] = int(r.choice([16, 32, 32, 64]))
+        # every attention level's width must be a multiple of the head width
+        if any((mc * m) % cfg["num_head_channels"] for m in mult):
+            cfg["num_head_channels"] = 32 if mc % 32 == 0 else 16
+    else:
+        cfg["num_heads"] = int(r.choice([1, 2, 4]))
+        if r.rand() < 0.3:
+            cfg["num_heads_upsample"] = int(r.choice([1, 2]))
+    if r.rand() < 0.25:
+        cfg["num_classes"] = 5
+    N = int(r.choice([1, 2, 3]))
+    return cfg, N, H, W, in_ch, cond_ch
+
+
+def _run_case(i):
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from oracle import unet_ref as UR
+    cfg, N, H, W, in_ch, cond_ch = _random_cfg(i)
+    sd = synth_state_dict(unet_param_shapes(**cfg), 40 + i)
+    x = synth_input(f"fz_x{i}", (N, in_ch, H, W), 41 + i)
+    cond = synth_input(f"fz_c{i}", (N, cond_ch, H, W), 42 + i) if cond_ch else None
+    t = torch.tensor([(37 * (i + 1) * (k + 1)) % 1000 for k in range(N)])
+    y = torch.tensor([(i + k) % 5 for k in range(N)]) if "num_classes" in cfg else None
+    with torch.no_grad():
+        ref = UR.unet_forward(sd, cfg, x, t, cond=cond, y=y)
+    errs = {}
+    for prec in ("fp32", "fp32x3", "fp16"):
+        poison_allocator_cache()
+        u = UNetModel(**cfg).set_precision(prec)
+        u.load_state_dict(sd)
+        u = u.to(DEV).eval()
+        with torch.no_grad():
+            out = u(x.to(DEV), t.to(DEV), cond=cond.to(DEV) if cond is not None else None, y=y.to(DEV) if y is not None else None).cpu()
+            again = u(x.to(DEV), t.to(DEV), cond=cond.to(DEV) if cond is not None else None, y=y.to(DEV) if y is not None else None).cpu()
+        assert out.shape == ref.shape and torch.isfinite(out).all(), (cfg, prec)
+        assert torch.equal(out, again), f"case {i} [{prec}]: two forwards differ"  # no atomics anywhere: bit-identical replays
+        errs[prec] = rel_l2(out, ref)
+    return cfg, (N, H, W), errs
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_unet_configuration_vs_oracle(i):
+    cfg, shape, errs = _run_case(i)
+    print(f"case {i}: N,H,W = {shape}, {cfg} -> " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    for prec, e in errs.items():
+        assert e < TOL[prec], (i, prec, e, cfg, shape)
