@@ -95,3 +95,15 @@ def test_random_unet_configuration_vs_oracle(i):
     print(f"case {i}: N,H,W = {shape}, {cfg} -> " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
     for prec, e in errs.items():
         assert e < TOL[prec], (i, prec, e, cfg, shape)
+
+
+@pytest.mark.parametrize("i", range(0, N_CASES, 2))
+def test_random_unet_configuration_with_every_buffer_at_a_segment_end(i, monkeypatch):
+    """the same walk under EOD_DEBUG_TAIL_ALLOC=1 (engine.Program._empty_at_segment_end): every program buffer ends where its allocator
+    segment ends, so a launch that reads or writes past the logical end of ANY buffer faults here, on every run.  (Round 3: the generic
+    conv's epilogue read the per-sample bias row of image N for the rows behind the last image -- harmless on almost every layout,
+    a memory fault on the one where the table was the last block of its segment.)"""
+    monkeypatch.setenv("EOD_DEBUG_TAIL_ALLOC", "1")
+    cfg, shape, errs = _run_case(i)
+    for prec, e in errs.items():
+        assert e < TOL[prec], (i, prec, e, cfg, shape)
