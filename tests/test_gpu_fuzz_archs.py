@@ -107,3 +107,68 @@ def test_random_unet_configuration_with_every_buffer_at_a_segment_end(i, monkeyp
     cfg, shape, errs = _run_case(i)
     for prec, e in errs.items():
         assert e < TOL[prec], (i, prec, e, cfg, shape)
+
+
+# ------------------------------------------------------------------------------------------------ training step
+N_TRAIN = 14
+
+
+def _train_case(i, prec):
+    """forward + backward of a random configuration through the autograd bridge (train.py:109-118) vs torch autograd through the oracle"""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from oracle import unet_ref as UR
+    cfg, N, H, W, in_ch, cond_ch = _random_cfg(200 + i)
+    if max(H, W) > 32:   # autograd through the CPU oracle: keep a case under a couple of seconds
+        H = W = 32 if max(H, W) % 32 == 0 else 16
+        cfg["image_size"] = H
+        lv = len(cfg["channel_mult"])
+        while H // (2 ** (lv - 1)) < 2 or H // (2 ** (lv - 1)) == 3:
+            lv -= 1
+        cfg["channel_mult"] = cfg["channel_mult"][:lv]
+        cfg["attention_resolutions"] = [a for a in cfg["attention_resolutions"] if a < 2 ** lv]
+    sd = synth_state_dict(unet_param_shapes(**cfg), 60 + i)
+    x = synth_input(f"ft_x{i}", (N, in_ch, H, W), 61 + i)
+    cond = synth_input(f"ft_c{i}", (N, cond_ch, H, W), 62 + i) if cond_ch else None
+    noise = synth_input(f"ft_n{i}", (N, in_ch, H, W), 63 + i)
+    t = torch.tensor([(53 * (i + 1) * (k + 1)) % 1000 for k in range(N)])
+    y = torch.tensor([(i + k) % 5 for k in range(N)]) if "num_classes" in cfg else None
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred_ref = UR.unet_forward(sdg, cfg, x, t, cond=cond, y=y)
+    torch.nn.functional.mse_loss(pred_ref, noise).backward()
+    gref = {k: v.grad for k, v in sdg.items() if v.grad is not None}
+    poison_allocator_cache()
+    u = UNetModel(**cfg).set_precision(prec)
+    u.load_state_dict(sd)
+    u = u.to(DEV).train()
+    pred = u(x.to(DEV), t.to(DEV), cond=cond.to(DEV) if cond is not None else None, y=y.to(DEV) if y is not None else None)
+    loss = torch.nn.functional.mse_loss(pred, noise.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    e_pred = rel_l2(pred.detach().cpu(), pred_ref.detach())
+    gmax = max(float(v.norm()) for v in gref.values())
+    worst, checked = ("", 0.0), 0
+    for name, p in u.named_parameters():
+        if name not in gref:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name   # (the dead nout / conv_out head gets no gradient)
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        if float(gref[name].norm()) < 1e-5 * gmax:
+            assert float(p.grad.norm()) < 1e-3 * gmax, name
+            continue
+        e = rel_l2(p.grad.cpu(), gref[name])
+        checked += 1
+        if e > worst[1]:
+            worst = (name, e)
+    return cfg, (N, H, W), e_pred, worst, checked
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+@pytest.mark.parametrize("i", range(N_TRAIN))
+def test_random_unet_training_step_vs_oracle(i, prec, monkeypatch):
+    """every parameter gradient of a random configuration (odd widths, 2-4 levels, attention anywhere, FiLM / updown / plain resampling,
+    class and concat conditioning, non-square maps) against torch autograd of the oracle; program buffers at segment ends (see above)"""
+    monkeypatch.setenv("EOD_DEBUG_TAIL_ALLOC", "1")
+    cfg, shape, e_pred, worst, checked = _train_case(i, prec)
+    print(f"train case {i} [{prec}]: N,H,W = {shape}, {cfg}: pred {e_pred:.2e}, worst of {checked} gradients {worst[1]:.2e} ({worst[0]})")
+    assert e_pred < (2e-5 if prec == "fp32" else 1e-2)
+    assert checked > 10 and worst[1] < (2e-4 if prec == "fp32" else 1e-2), worst
