@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+if os.environ.get("EOD_TEST_EFENCE", "0") == "1":  # every device tensor ends at an unmapped guard range (tests/efence/efence_alloc.cpp)
+    from tests import efence
+    efence.install()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
