@@ -232,6 +232,24 @@ __device__ __forceinline__ TileGeom make_geom(const IgemmP& p, int tile_m) {
     return g;
 }
 
+#ifdef EOD_STAMP
+// Diagnostic build only (-DEOD_STAMP, tools/debug/halo_stamps.py): wave 0 of every workgroup of conv3x3_halo_kernel stamps the 100 MHz
+// wall counter and the shader clock at entry, after the prologue, after the K loop and at exit.  The values go to a buffer of their own
+// that no kernel reads; the product library is built without this.
+__device__ unsigned long long g_eod_stamp[65536][16];
+#define EOD_STAMP_AT(k)                                                                    \
+    do {                                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x < 65536) {                                      \
+            g_eod_stamp[blockIdx.x][2 * (k)] = __builtin_amdgcn_s_memrealtime();           \
+            g_eod_stamp[blockIdx.x][2 * (k) + 1] = __builtin_amdgcn_s_memtime();           \
+        }                                                                                  \
+    } while (0)
+extern "C" int eod_debug_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_eod_stamp), (size_t)n * 16 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define EOD_STAMP_AT(k) do { } while (0)
+#endif
 // XCD-aware tile mapping (bijective remap, guide T1)
 __device__ __forceinline__ void map_tile(const IgemmP& p, int& tile_m, int& tile_n) {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -260,7 +278,8 @@ template <int MS> struct AccLayout {
 template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, bool OUTF32, int MS = 32>
 __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& g,
                                                typename AccLayout<MS>::vec (&acc)[BM / WAVES_M / MS][BN / WAVES_N / MS], char* smem, int wave,
-                                               int lane, int n0, const float* rowtab = nullptr, int rowtab_n = 0) {
+                                               int lane, int n0, const float* rowtab = nullptr, int rowtab_n = 0,
+                                               const float* pre_bcol = nullptr) {
     constexpr int ES = sizeof(T);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / MS, TN = WN / MS, R = AccLayout<MS>::R;
@@ -276,13 +295,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     for (int j = 0; j < TN; ++j) {
         col[j] = n0 + wn * WN + j * MS + lr;
         cok[j] = col[j] < p.Ncols;
-        bcol[j] = (cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f;
+        // pre_bcol (patch-mode kernels): bias + per-sample bias of the tile's image, loaded at kernel ENTRY -- fetched here, the two
+        // dependent global loads cost every workgroup 3-4 us of memory latency between its last MFMA and its first store
+        // (tools/debug/halo_stamps.py: 5.2 us from the end of the K loop to the end of the LDS transpose, 1-2 us without them)
+        bcol[j] = pre_bcol ? pre_bcol[j] : ((cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f);
     }
     // per-sample (timestep) bias: one value per (image, column).  A tile almost always lies inside one image
     // (always in patch mode); then it is folded into bcol once instead of being fetched per row.
     bool cb_per_row = false;
     if constexpr (CONV) {
-        if (p.cbias) {
+        if (p.cbias && !pre_bcol) {
             const bool one_image = (p.tw_log2 >= 0) || (g.rem_first + BM <= p.HWd);
             if (one_image) {
                 const float* cbp = p.cbias + (long long)g.n_first * p.cbias_stride;
@@ -406,6 +428,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
     __builtin_amdgcn_wave_barrier();
+    EOD_STAMP_AT(4);
 
     // pre-split output: the image's power-of-two scale from the a-priori table of y (one image per tile: checked by the launcher)
     float ps_scale = 1.0f;
@@ -941,6 +964,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 // block input | 128 x 128 B of the 1x1 weight per K-step) and the K loop continues over the input's channels: the skip tensor is never
 // written to or read back from HBM (2 x M x Cout elements per block), and its MFMA work runs at this kernel's rate instead of in an
 // HBM-bound launch of its own.
+// per-column epilogue terms of a patch-mode tile (one image): bias[col] + cbias[image][col], for igemm_epilogue's pre_bcol
+template <int TN, int MS>
+__device__ __forceinline__ void prefetch_bcol(const IgemmP& p, int ncols, int col0, int lane, int n_first, float (&out)[TN]) {
+    const int lr = AccLayout<MS>::col(lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * MS + lr;
+        const bool ok = col < ncols;
+        float v = (ok && p.bias && p.bias_mode == 1) ? p.bias[col] : 0.0f;
+        if (ok && p.cbias) v += p.cbias[(long long)n_first * p.cbias_stride + col];
+        out[j] = v;
+    }
+}
+
 template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void conv3x3_halo_kernel(const IgemmP p) {
     static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M == 2), "fused skip conv: 16x16x32 instances of the 8x16 tile");
@@ -967,6 +1004,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     char* const sA = smem;              // [2][ABUF]
     char* const sB = smem + 2 * ABUF;   // [BSTAGES][BSTAGE]
     char* const sS = sB + BSTAGES * BSTAGE;  // GN only: [2][1024] scale/shift of the 64 channels of a chunk
+    EOD_STAMP_AT(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -975,6 +1013,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     map_tile(p, tile_m, tile_n);
     const int n0 = p.n_base + tile_n * BN;
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode: ty0, tx0, n_first
+    // epilogue operands fetched NOW (their latency passes under the prologue's DMA; older than every DMA, so the counted vmcnt waits of
+    // the loop are unaffected): per-column bias terms and the weights' scale
+    float pre_bcol[TN];
+    prefetch_bcol<TN, MS>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    float wsc1 = 1.0f;
+    if constexpr (SPLIT) wsc1 = p.w_scale[1];
     // split-fp16 product: power-of-two operand scale of this tile's image from the bound table(s) (wave-uniform, common.h); the fused
     // skip conv shares the accumulators, so the launch runs on the smaller of the two tensors' scales
     AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};
@@ -1196,6 +1240,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     }
     // DMA issued AFTER the weights of the step we are about to wait for may stay in flight (vmcnt retires in order):
     //   pp1 / pp2 : a patch piece was issued one / two steps ago;  ww1 : weights were issued one step ago (3-stage ring)
+    EOD_STAMP_AT(1);
     int pp1 = 0, pp2 = 0;
     bool ww1 = BSTAGES == 3 && NSTEP > 1 && !XF;  // (XF: the prologue already drained everything)
     int step = 0;
@@ -1453,13 +1498,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
+    EOD_STAMP_AT(2);
     if constexpr (SPLIT) {
         IgemmP pe = p;
-        pe.alpha = p.alpha * p.w_scale[1] * asc.inv;  // undo the weight and activation scales (exact powers of two)
-        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0);
+        pe.alpha = p.alpha * wsc1 * asc.inv;  // undo the weight and activation scales (exact powers of two)
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     } else {
-        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0);
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     }
+    EOD_STAMP_AT(3);
 }
 
 // =============================================================================================
@@ -1507,6 +1554,10 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     const int cls = BWD ? 0 : tile_nn / tpc, n0 = (tile_nn - cls * tpc) * BN;
     const int par_y = cls >> 1, par_x = cls & 1;        // (forward: the workgroup's class; backward: classes rotate inside the K loop)
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode on the STORED map: ty0, tx0, n_first
+    float pre_bcol[TN];  // epilogue operands fetched at entry (see conv3x3_halo_kernel)
+    prefetch_bcol<TN, MS>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    float wsc1 = 1.0f;
+    if constexpr (SPLIT) wsc1 = p.w_scale[1];
     AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};             // split-fp16 product: operand scale of this tile's image (see conv3x3_halo_kernel)
     if constexpr (SPLIT) {
         if (p.a_bound) asc = ab_scale_of(ab_wave_bound(p.a_bound, g.n_first));
@@ -1731,8 +1782,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         pe.tiles_per_image = p.tiles_pi * 4;  // statistics slots: (tile of the stored map, class)
         ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
     }
-    if constexpr (SPLIT) pe.alpha = p.alpha * p.w_scale[1] * asc.inv;
-    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0);
+    if constexpr (SPLIT) pe.alpha = p.alpha * wsc1 * asc.inv;
+    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
 }
 
 template <typename T, bool SPLIT, bool BWD = false> static int launch_up4(IgemmP& p, hipStream_t st) {
