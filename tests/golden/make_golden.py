@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain]
 
 The reference never travels to the GPU box; only the .npz / .json data written here does.
 Harness-side adaptations (NOT reference behaviour):
@@ -465,8 +465,40 @@ def gen_keyframe_lr():
     save("keyframe_lr", **out)
 
 
+def gen_full_chain():
+    """The reference's COMPLETE sampling() call at its real chain length: T = 1000 DDPM steps (diffusion/model.py:46-92 with
+    _reverse_diffusion_with_clip :126-150 / _reverse_diffusion :101-122), unconditional, u_a0_tiny at 16 x 16, batch 2, clipped and
+    unclipped.  Only the OUTPUT is stored: x_T and the 1000 noise tensors are what torch.randn yields after torch.manual_seed(seed) in
+    the reference's own draw order (checked here against the recorded draws), so the test regenerates them instead of carrying 12 MB."""
+    print("full 1000-step chains")
+    u = R.UNetModel(**UNETS["u_a0_tiny"]).eval()
+    load_synth(u, 7)
+    T = 1000
+    m = EODiffusion(u, timesteps=T, image_size=16, in_channels=3).eval()
+    arrs = {}
+    for clip, seed in ((True, 300), (False, 301)):
+        torch.manual_seed(seed)
+        with Recorder() as r:
+            with torch.no_grad():
+                out = m.sampling(2, clipped_reverse_diffusion=clip, device="cpu")
+        assert len(r.draws) == T + 1 and r.draws[0][0] == "randn"
+        torch.manual_seed(seed)  # the same sequence without the reference: one randn per draw, same shapes, same order
+        for kind, t in r.draws:
+            assert torch.equal(torch.randn(tuple(t.shape)), t), kind
+        tag = "clip" if clip else "noclip"
+        arrs[tag + "_seed"] = np.asarray(seed)
+        arrs[tag + "_out"] = out
+        arrs[tag + "_max_abs_x_t"] = np.asarray(float(out.abs().max()))
+        print(f"  {tag}: max|out| = {float(out.abs().max()):.4g}")
+    save("traj_ddpm_uncond_T1000_full", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 2 and sys.argv[2] == "full_chain":
+        gen_full_chain()
+        print("done")
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] in ("training", "training_13ch", "ldm_tables", "keyframe_lr"):
         # partial runs (new fixtures of a later round) leave the committed ones untouched
         {"training": gen_training, "training_13ch": lambda: gen_training(("u_s2_13ch",)), "ldm_tables": gen_ldm_tables,
@@ -481,4 +513,5 @@ if __name__ == "__main__":
     gen_sampler()
     gen_training()
     gen_keyframe_lr()
+    gen_full_chain()
     print("done")

@@ -34,6 +34,27 @@ def test_ddpm_trajectory_vs_golden(prec, name, clip, masked):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
+@pytest.mark.parametrize("clip", [True, False])
+def test_full_1000_step_sampling_vs_reference_output(prec, clip):
+    """EODiffusion.sampling over the reference's real chain length (T = 1000, diffusion/model.py:46-92) against the output of the
+    reference's own call (tests/golden/make_golden.py gen_full_chain); the noise is what torch.randn yields after the recorded seed.
+    Unclipped, |x_t| reaches 9e4: fp32x3 must follow the reference there (fp32-grade on the whole fp32 domain); fp16 STORAGE cannot
+    hold such values (65504), the reference's own fp16 mode cannot either -- that combination is only required to stay loud."""
+    from tests.test_oracle_golden import _full_chain_inputs
+    g = gt("traj_ddpm_uncond_T1000_full")
+    tag = "clip" if clip else "noclip"
+    xT, noises = _full_chain_inputs(int(g[tag + "_seed"]))
+    m = _model(prec, T=1000)
+    out = m.sampling(2, clipped_reverse_diffusion=clip, device=DEV, x_T=xT, noises=noises, progress=False).cpu()
+    if prec == "fp16" and not clip:
+        assert not torch.isfinite(out).all()   # overflow of the storage type shows up as inf / NaN, never as a plausible image
+        return
+    err = rel_l2(out, g[tag + "_out"])
+    print(f"1000 DDPM steps [{prec}, {tag}], max|out| = {float(g[tag + '_out'].abs().max()):.3g}: rel-L2 vs the reference = {err:.3e}")
+    assert err < TRAJ_TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 def test_training_forward_vs_golden(prec):
     g = gt("train_forward_T20")
     m = _model(prec)

@@ -171,6 +171,23 @@ def test_ddpm_trajectory(name, clip, masked):
     assert rel_l2(out, g["out"]) < 1e-6
 
 
+def _full_chain_inputs(seed, T=1000, shape=(2, 3, 16, 16)):
+    """x_T and the per-step noise of the reference's sampling() call behind traj_ddpm_uncond_T1000_full (one randn per draw, in its
+    order; tests/golden/make_golden.py gen_full_chain checked this equality against the recorded draws)"""
+    torch.manual_seed(seed)
+    xT = torch.randn(shape)
+    return xT, [torch.randn(shape) for _ in range(T)]
+
+
+def test_full_1000_step_clipped_chain_vs_reference_output():
+    """the oracle through the reference's COMPLETE 1000-step sampling() call (diffusion/model.py:46-92), output vs the reference's"""
+    g = gt("traj_ddpm_uncond_T1000_full")
+    xT, noises = _full_chain_inputs(int(g["clip_seed"]))
+    with torch.no_grad():
+        out = SR.ddpm_sampling(SCH.eo_cosine_tables(1000), _tiny_eps(), xT, noises, 1000, clip=True)
+    assert rel_l2(out, g["clip_out"]) < 2e-6
+
+
 def test_train_forward():
     g = gt("train_forward_T20")
     tb = SCH.eo_cosine_tables(20)
