@@ -492,6 +492,37 @@ def gen_full_chain():
         print(f"  {tag}: max|out| = {float(out.abs().max()):.4g}")
     save("traj_ddpm_uncond_T1000_full", **arrs)
 
+    # --- BASELINE config 3's call shape: DDIMSampler.sample with 250 of 1000 steps and the RePaint mask mix (inference.py:112-126,
+    # ddim.py:56-164), on the attention UNet u_a1_tiny; eta = 0 and eta = 0.5 ---
+    print("full DDIM-250 + RePaint calls")
+    u = R.UNetModel(**UNETS["u_a1_tiny"]).eval()
+    load_synth(u, 7)
+    m = EODiffusion(u, timesteps=1000, image_size=16, in_channels=3).eval()
+    m.device = "cpu"
+    gt = synth_input("gt", (2, 3, 16, 16), 11, uniform=True)
+    mask = rect_mask(2, 16, 16, 11)
+    orig_fd = m._forward_diffusion
+    m._forward_diffusion = lambda x0_, ts_, noise=None: orig_fd(x0_, ts_, torch.randn_like(x0_) if noise is None else noise)  # adaptation (3)
+    arrs = dict(x0=gt, mask=mask)
+    for eta, seed in ((0.0, 310), (0.5, 311)):
+        s = DDIMSampler(m)
+        s.register_buffer = lambda name, attr, s=s: setattr(s, name, attr)  # adaptation (2)
+        torch.manual_seed(seed)
+        with Recorder() as r, torch.no_grad():
+            out, inter = s.sample(S=250, batch_size=2, shape=(3, 16, 16), eta=eta, verbose=False, mask=mask, x0=gt, log_every_t=50)
+        nsteps = len(s.ddim_timesteps)
+        assert len(r.draws) == 1 + 3 * nsteps, (len(r.draws), nsteps)  # x_T, then per step: mix noise, unused randn_like, step noise
+        torch.manual_seed(seed)
+        for kind, t in r.draws:
+            assert torch.equal(torch.randn(tuple(t.shape)), t), kind
+        tag = f"eta{eta}_"
+        arrs[tag + "seed"] = np.asarray(seed)
+        arrs[tag + "out"] = out
+        arrs[tag + "pred_x0_last"] = inter["pred_x0"][-1]
+        arrs[tag + "steps"] = np.asarray(s.ddim_timesteps, np.int64)
+        print(f"  eta {eta}: {nsteps} steps, max|out| = {float(out.abs().max()):.4g}")
+    save("traj_ddim_S250_T1000_repaint_full", **arrs)
+
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -55,6 +55,31 @@ def test_full_1000_step_sampling_vs_reference_output(prec, clip):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
+@pytest.mark.parametrize("eta", [0.0, 0.5])
+def test_full_ddim250_repaint_call_vs_reference_output(prec, eta):
+    """BASELINE config 3's call shape at its real length: DDIMSampler.ddim_sampling with 250 of 1000 steps and the RePaint mask mix
+    (inference.py:112-126, ddim.py:56-164) on the attention UNet u_a1_tiny, against the output of the reference's own call"""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from eo_diffusion_amd.diffusion.ddim import DDIMSampler
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    from tests.test_oracle_golden import _full_ddim_inputs
+    g = gt("traj_ddim_S250_T1000_repaint_full")
+    cfg = unet_cfgs()["u_a1_tiny"]
+    u = UNetModel(**cfg).set_precision(prec)
+    u.load_state_dict(synth_state_dict(unet_param_shapes(**cfg), 7))
+    m = EODiffusion(u, timesteps=1000, image_size=16, in_channels=3, device=DEV).to(DEV).eval()
+    s = DDIMSampler(m)
+    s.make_schedule(ddim_num_steps=250, ddim_eta=eta, verbose=False)
+    assert np.array_equal(np.asarray(s.ddim_timesteps, np.int64), g[f"eta{eta}_steps"].numpy())
+    xT, stp, mix = _full_ddim_inputs(int(g[f"eta{eta}_seed"]), 250)
+    out, inter = s.ddim_sampling(None, (2, 3, 16, 16), x_T=xT, mask=g["mask"], x0=g["x0"], log_every_t=50, step_noises=stp, mix_noises=mix,
+                                 progress=False)
+    e_out, e_p0 = rel_l2(out.cpu(), g[f"eta{eta}_out"]), rel_l2(inter["pred_x0"][-1].cpu(), g[f"eta{eta}_pred_x0_last"])
+    print(f"DDIM 250 of 1000 + RePaint [{prec}, eta {eta}]: rel-L2 vs the reference: out {e_out:.3e}, last pred_x0 {e_p0:.3e}")
+    assert e_out < TRAJ_TOL[prec] and e_p0 < TRAJ_TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 def test_training_forward_vs_golden(prec):
     g = gt("train_forward_T20")
     m = _model(prec)

@@ -209,6 +209,42 @@ def test_ddim_trajectory(tag, S, eta, masked):
     assert rel_l2(p0, g["pred_x0_last"]) < 1e-6
 
 
+def _full_ddim_inputs(seed, nsteps, shape=(2, 3, 16, 16)):
+    """x_T, per-step mix noise and per-step DDIM noise of the reference's DDIMSampler.sample call behind
+    traj_ddim_S250_T1000_repaint_full: after the seed, x_T, then per step [mix noise, an unused randn_like (ddim.py:171), step noise]"""
+    torch.manual_seed(seed)
+    xT = torch.randn(shape)
+    mix, stp = [], []
+    for _ in range(nsteps):
+        mix.append(torch.randn(shape))
+        torch.randn(shape)
+        stp.append(torch.randn(shape))
+    return xT, torch.stack(stp), torch.stack(mix)
+
+
+def _a1_tiny_eps():
+    cfg = unet_cfgs()["u_a1_tiny"]
+    from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
+    sd = synth_state_dict(unet_param_shapes(**cfg), 7)
+    return lambda x, t: UR.unet_forward(sd, cfg, x, t)
+
+
+@pytest.mark.parametrize("eta", [0.0, 0.5])
+def test_full_ddim250_repaint_call_vs_reference_output(eta):
+    """the oracle through BASELINE config 3's call shape -- DDIMSampler.sample with 250 of 1000 steps and the RePaint mask mix
+    (inference.py:112-126, ddim.py:56-164) on an attention UNet -- against the output of the reference's own call"""
+    g = gt("traj_ddim_S250_T1000_repaint_full")
+    tb = SCH.eo_cosine_tables(1000)
+    steps = SCH.ddim_timesteps("uniform", 250, 1000)
+    assert np.array_equal(steps, g[f"eta{eta}_steps"].numpy())
+    dd = SCH.ddim_tables(tb["alphas_cumprod"], steps, eta)
+    xT, stp, mix = _full_ddim_inputs(int(g[f"eta{eta}_seed"]), len(steps))
+    with torch.no_grad():
+        out, p0 = SR.ddim_sampling(tb, dd, steps, _a1_tiny_eps(), xT, stp, x0=g["x0"], mask=g["mask"], mix_noises=mix)
+    assert rel_l2(out, g[f"eta{eta}_out"]) < 5e-6
+    assert rel_l2(p0, g[f"eta{eta}_pred_x0_last"]) < 5e-6
+
+
 @pytest.mark.parametrize("eta", [0.0, 0.7])
 def test_ddim_single_steps_vs_golden(eta):
     g = gt("ddim_steps_S250_T1000")
