@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain | train_loop]
 
 The reference never travels to the GPU box; only the .npz / .json data written here does.
 Harness-side adaptations (NOT reference behaviour):
@@ -524,8 +524,70 @@ def gen_full_chain():
     save("traj_ddim_S250_T1000_repaint_full", **arrs)
 
 
+def gen_train_loop(steps=12, lr=1e-3, posmax=4, decay=0.9):
+    """The reference's training loop (train.py:70-124) run by the reference for `steps` steps on CPU: UNetModel + EODiffusion.forward
+    (randint t, q_sample, model.py:38-44), nn.MSELoss, torch AdamW, KeyframeLR with train.py's own frames (cos warm-up from lr / 100, then
+    lr * exp(-3 * progress)), ExponentialMovingAverage (script_utils/utils.py:56-67) updated every step.  Stored: the loss and the
+    learning rate of every step, the timesteps the reference drew, and -- after the last step -- the predictions of the trained model
+    and of its EMA copy on a fixed probe.  The noise is torch.randn_like(image) after torch.manual_seed(seed), drawn as train.py:112
+    draws it (on the CPU, before the image moves to the device), so the test re-creates it."""
+    import math
+    print("training loop")
+    for name, mods in (("pytorch_lightning", ("Callback",)), ("pytorch_lightning.callbacks", ("ModelCheckpoint",)), ("timm", ()),
+                       ("timm.utils", ()), ("timm.utils.model", ("get_state_dict", "unwrap_model"))):
+        mm = types.ModuleType(name)
+        for attr in mods:
+            setattr(mm, attr, type(attr, (), {}))
+        sys.modules.setdefault(name, mm)
+    sys.path.insert(1, os.path.join(REF, "script_utils"))
+    import utils as RUT  # the reference's script_utils/utils.py (ExponentialMovingAverage)
+    import train_utils as RT
+    assert RUT.__file__.startswith(REF) and RT.__file__.startswith(REF), (RUT.__file__, RT.__file__)
+    u = R.UNetModel(**UNETS["u_a1_tiny"])
+    load_synth(u, 7)
+    m = EODiffusion(u, timesteps=1000, image_size=16, in_channels=3)
+    ema = RUT.ExponentialMovingAverage(m, device="cpu", decay=decay)
+    opt = torch.optim.AdamW(m.parameters(), lr=lr)
+    sched = RT.KeyframeLR(optimizer=opt, units="steps", frames=[
+        {"position": 0, "lr": lr / 100}, {"transition": "cos"}, {"position": posmax, "lr": lr},
+        {"transition": lambda last_lr, sf, ef, pos, *_: lr * math.exp(-3 * (pos - posmax) / (steps - posmax))}], end=steps)
+    loss_fn = torch.nn.MSELoss(reduction="mean")
+    seed = 320
+    torch.manual_seed(seed)
+    m.train()
+    losses, lrs, ts = [], [], []
+    with Recorder() as r:
+        for j in range(steps):
+            image = synth_input(f"tl_img{j}", (4, 3, 16, 16), 20 + j, uniform=True)
+            lrs.append(opt.param_groups[0]["lr"])
+            noise = torch.randn_like(image)
+            pred = m(image, noise)
+            loss = loss_fn(pred, noise)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            sched.step()
+            ema.update_parameters(m)
+            losses.append(float(loss.detach()))
+    assert [k for k, _ in r.draws] == ["randn_like", "randint"] * steps
+    ts = torch.stack([r.draws[2 * j + 1][1] for j in range(steps)])
+    m.eval()
+    ema.eval()
+    xp = synth_input("tl_probe_x", (2, 3, 16, 16), 40)
+    tp = torch.tensor([900, 40])
+    with torch.no_grad():
+        pm, pe = m.model(xp, tp), ema.module.model(xp, tp)
+    print("  losses", " ".join(f"{v:.5f}" for v in losses))
+    save("train_loop_12steps_u_a1_tiny", seed=np.asarray(seed), losses=np.asarray(losses, np.float64), lrs=np.asarray(lrs, np.float64), t=ts,
+         probe_x=xp, probe_t=tp, probe_pred_model=pm, probe_pred_ema=pe, hyper=np.asarray([steps, lr, posmax, decay], np.float64))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 2 and sys.argv[2] == "train_loop":
+        gen_train_loop()
+        print("done")
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "full_chain":
         gen_full_chain()
         print("done")
@@ -545,4 +607,5 @@ if __name__ == "__main__":
     gen_training()
     gen_keyframe_lr()
     gen_full_chain()
+    gen_train_loop()
     print("done")

@@ -503,3 +503,64 @@ def test_factory_presets_train_as_is(factory, size):
         opt.zero_grad()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("variant", ["fp32-torch", "fp32-fused", "fp16-fused"])
+def test_training_loop_vs_reference_run(variant):
+    """12 steps of the reference's training loop (train.py:70-124) run HERE with the drop-in classes -- UNetModel / EODiffusion.forward on
+    the HIP path, nn.MSELoss, AdamW (torch's or the fused one), KeyframeLR with train.py's frames, the EMA copy -- against the losses,
+    learning rates and final predictions (model and EMA) of the reference's own CPU run of the same loop (tests/golden/make_golden.py
+    gen_train_loop).  t and the noise come from the same torch generator calls in the same order as in train.py."""
+    import numpy as np
+    import torch.nn as nn
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from eo_diffusion_amd import optim as EO
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    from eo_diffusion_amd.train_utils import KeyframeLR
+    from tests.helpers import gt, unet_cfgs
+    prec, opt_kind = variant.split("-")
+    g = gt("train_loop_12steps_u_a1_tiny")
+    steps, lr, posmax, decay = (float(v) for v in g["hyper"])
+    steps, posmax = int(steps), int(posmax)
+    cfg = unet_cfgs()["u_a1_tiny"]
+    unet = U.UNetModel(**cfg).set_precision(prec)
+    unet.load_state_dict(synth_state_dict(U.unet_param_shapes(**cfg), 7))
+    model = EODiffusion(unet, timesteps=1000, image_size=16, in_channels=3).to(DEV)
+    if opt_kind == "fused":
+        ema = EO.ExponentialMovingAverage(model, decay=decay, device=DEV)
+        opt = EO.AdamW(model.parameters(), lr=lr)
+    else:
+        from torch.optim.swa_utils import AveragedModel
+        ema = AveragedModel(model, DEV, lambda avg, p, n: decay * avg + (1 - decay) * p, use_buffers=True)   # script_utils/utils.py:56-67
+        opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    sched = KeyframeLR(optimizer=opt, units="steps", frames=[
+        {"position": 0, "lr": lr / 100}, {"transition": "cos"}, {"position": posmax, "lr": lr},
+        {"transition": lambda last_lr, sf, ef, pos, *_: lr * math.exp(-3 * (pos - posmax) / (steps - posmax))}], end=steps)
+    loss_fn = nn.MSELoss(reduction="mean")
+    torch.manual_seed(int(g["seed"]))
+    model.train()
+    losses = []
+    for j in range(steps):
+        image = synth_input(f"tl_img{j}", (4, 3, 16, 16), 20 + j, uniform=True)
+        assert abs(opt.param_groups[0]["lr"] - float(g["lrs"][j])) <= 1e-12 * max(1.0, lr)
+        noise = torch.randn_like(image).to(DEV)   # train.py:112: drawn on the CPU
+        image = image.to(DEV)
+        pred = model(image, noise)                # (EODiffusion.forward draws t with torch.randint, model.py:40)
+        loss = loss_fn(pred, noise)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        ema.update_parameters(model)
+        losses.append(float(loss.detach()))
+    ref = g["losses"].numpy()
+    worst = float(np.max(np.abs(np.asarray(losses) - ref) / ref))
+    model.eval()
+    ema.eval()
+    with torch.no_grad():
+        pm = model.model(g["probe_x"].to(DEV), g["probe_t"].to(DEV)).cpu()
+        pe = ema.module.model(g["probe_x"].to(DEV), g["probe_t"].to(DEV)).cpu()
+    e_m, e_e = rel_l2(pm, g["probe_pred_model"]), rel_l2(pe, g["probe_pred_ema"])
+    print(f"training loop [{variant}]: worst relative loss difference {worst:.2e}; trained model on the probe {e_m:.2e}, EMA copy {e_e:.2e}")
+    tol_loss, tol_probe = (1e-5, 2e-5) if prec == "fp32" else (2e-3, 1e-2)   # measured: 2.6e-7 / 1.1e-6 and 9.6e-5 / 1.7e-3
+    assert worst < tol_loss and e_m < tol_probe and e_e < tol_probe

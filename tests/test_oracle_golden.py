@@ -9,7 +9,7 @@ from oracle import sampler_ref as SR
 from oracle import schedule as SCH
 from oracle import unet_ref as UR
 from tests.helpers import bits_equal, close_ulp, gload, gt, key_contracts, rel_l2, unet_cfgs
-from tests.synth import synth_state_dict
+from tests.synth import synth_input, synth_state_dict
 
 torch.set_num_threads(8)
 
@@ -425,3 +425,57 @@ def test_keyframe_lr_rejects_what_the_reference_rejects():
     with pytest.raises(ValueError):       # unknown transition name (:144)
         s = KeyframeLR(mk(), frames=[(0, 1.0), "cubic", (1.0, 0.5)], end=10)
         s.get_lr_at_pos(0.5)
+
+
+def test_training_loop_vs_reference_run():
+    """12 steps of the reference's training loop (train.py:70-124: EODiffusion.forward, MSELoss, AdamW, KeyframeLR, EMA), re-created from
+    oracle pieces -- autograd through oracle/unet_ref.py, oracle/train_ref.py's AdamW / EMA arithmetic, the product's host-side
+    KeyframeLR -- against the losses, learning rates and final predictions of the reference's own run (tests/golden/make_golden.py
+    gen_train_loop)"""
+    import math
+    import torch.nn.functional as F
+    from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
+    from eo_diffusion_amd.train_utils import KeyframeLR
+    from oracle import train_ref as TR
+    g = gt("train_loop_12steps_u_a1_tiny")
+    steps, lr, posmax, decay = (float(v) for v in g["hyper"])
+    steps, posmax = int(steps), int(posmax)
+    cfg = unet_cfgs()["u_a1_tiny"]
+    sd = {k: v.clone() for k, v in synth_state_dict(unet_param_shapes(**cfg), 7).items()}
+    dummy = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=lr)  # carries the learning rate KeyframeLR drives
+    sched = KeyframeLR(optimizer=dummy, units="steps", frames=[
+        {"position": 0, "lr": lr / 100}, {"transition": "cos"}, {"position": posmax, "lr": lr},
+        {"transition": lambda last_lr, sf, ef, pos, *_: lr * math.exp(-3 * (pos - posmax) / (steps - posmax))}], end=steps)
+    tb = SCH.eo_cosine_tables(1000)
+    mom = {}
+    ema = None
+    torch.manual_seed(int(g["seed"]))
+    losses = []
+    for j in range(steps):
+        image = synth_input(f"tl_img{j}", (4, 3, 16, 16), 20 + j, uniform=True)
+        cur_lr = dummy.param_groups[0]["lr"]
+        assert abs(cur_lr - float(g["lrs"][j])) <= 1e-12 * max(1.0, cur_lr)
+        noise = torch.randn_like(image)
+        t = torch.randint(0, 1000, (4,))
+        assert torch.equal(t, g["t"][j])
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        pred = UR.unet_forward(sdg, cfg, SR.q_sample(tb, image, t, noise), t)
+        loss = F.mse_loss(pred, noise)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        for k, p in sdg.items():
+            if p.grad is None:   # the dead nout / conv_out head: AdamW skips parameters without a gradient
+                continue
+            m_, v_ = mom.setdefault(k, (np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)))
+            newp, m2, v2 = TR.adamw_step(sd[k].numpy(), p.grad.numpy(), m_, v_, lr=cur_lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01,
+                                         step=j + 1)
+            sd[k], mom[k] = torch.from_numpy(np.asarray(newp)), (m2, v2)
+        dummy.step()
+        sched.step()
+        ema = {k: v.clone() for k, v in sd.items()} if ema is None else {k: torch.from_numpy(np.asarray(TR.ema_update(ema[k].numpy(), sd[k].numpy(), decay)))
+                                                                       for k in sd}
+    ref = g["losses"].numpy()
+    assert np.max(np.abs(np.asarray(losses) - ref) / ref) < 1e-4, (losses, ref.tolist())
+    with torch.no_grad():
+        pm, pe = UR.unet_forward(sd, cfg, g["probe_x"], g["probe_t"]), UR.unet_forward(ema, cfg, g["probe_x"], g["probe_t"])
+    assert rel_l2(pm, g["probe_pred_model"]) < 1e-3 and rel_l2(pe, g["probe_pred_ema"]) < 1e-3
