@@ -523,6 +523,33 @@ def gen_full_chain():
         print(f"  eta {eta}: {nsteps} steps, max|out| = {float(out.abs().max()):.4g}")
     save("traj_ddim_S250_T1000_repaint_full", **arrs)
 
+    # --- classifier-free guidance through the whole call (ddim.py:177-181: doubled batch, e_u + s (e_c - e_u)): concat conditioning,
+    # 50 of 1000 steps, eta 0.3, guidance scale 2.5 ---
+    print("full DDIM-50 call with classifier-free guidance")
+    cfgc = dict(image_size=16, in_channels=7, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[2],
+                channel_mult=[1, 2], num_heads=2)
+    u = R.UNetModel(**cfgc).eval()
+    load_synth(u, 7)
+    m = EODiffusion(u, timesteps=1000, image_size=16, in_channels=3).eval()
+    m.device = "cpu"
+    c = synth_input("cfg_c", (2, 4, 16, 16), 51, uniform=True)
+    uc = torch.zeros_like(c)
+    s = DDIMSampler(m)
+    s.register_buffer = lambda name, attr, s=s: setattr(s, name, attr)  # adaptation (2)
+    seed = 312
+    torch.manual_seed(seed)
+    with Recorder() as r, torch.no_grad():
+        out, inter = s.sample(S=50, batch_size=2, shape=(3, 16, 16), conditioning=c, eta=0.3, verbose=False, log_every_t=10,
+                              unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
+    nsteps = len(s.ddim_timesteps)
+    assert len(r.draws) == 1 + 2 * nsteps, (len(r.draws), nsteps)  # x_T, then per step: unused randn_like (ddim.py:171), step noise
+    torch.manual_seed(seed)
+    for kind, t in r.draws:
+        assert torch.equal(torch.randn(tuple(t.shape)), t), kind
+    print(f"  {nsteps} steps, max|out| = {float(out.abs().max()):.4g}")
+    save("traj_ddim_S50_T1000_cfg_full", seed=np.asarray(seed), cond=c, out=out, pred_x0_last=inter["pred_x0"][-1],
+         steps=np.asarray(s.ddim_timesteps, np.int64), hyper=np.asarray([50, 0.3, 2.5], np.float64))
+
 
 def gen_train_loop(steps=12, lr=1e-3, posmax=4, decay=0.9):
     """The reference's training loop (train.py:70-124) run by the reference for `steps` steps on CPU: UNetModel + EODiffusion.forward

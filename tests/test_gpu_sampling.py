@@ -149,6 +149,31 @@ def test_ddim_classifier_free_guidance_branch():
     assert rel_l2(xp.cpu(), rxp) < 2e-5 and rel_l2(p0.cpu(), rp0) < 2e-5
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
+def test_full_guided_ddim_call_vs_reference_output(prec):
+    """classifier-free guidance through a whole call (ddim.py:177-181): DDIMSampler.ddim_sampling with 50 of 1000 steps, eta 0.3, guidance
+    scale 2.5 and concat conditioning, against the output of the reference's own DDIMSampler.sample call"""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from eo_diffusion_amd.diffusion.ddim import DDIMSampler
+    from eo_diffusion_amd.diffusion.model import EODiffusion
+    from tests.test_oracle_golden import CFG_CFG, _full_cfg_inputs
+    g = gt("traj_ddim_S50_T1000_cfg_full")
+    S, eta, scale = (float(v) for v in g["hyper"])
+    u = UNetModel(**CFG_CFG).set_precision(prec)
+    u.load_state_dict(synth_state_dict(unet_param_shapes(**CFG_CFG), 7))
+    m = EODiffusion(u, timesteps=1000, image_size=16, in_channels=3, device=DEV).to(DEV).eval()
+    s = DDIMSampler(m)
+    s.make_schedule(ddim_num_steps=int(S), ddim_eta=eta, verbose=False)
+    assert np.array_equal(np.asarray(s.ddim_timesteps, np.int64), g["steps"].numpy())
+    xT, stp = _full_cfg_inputs(int(g["seed"]), int(S))
+    c = g["cond"].to(DEV)
+    out, inter = s.ddim_sampling(c, (2, 3, 16, 16), x_T=xT, log_every_t=10, unconditional_guidance_scale=scale,
+                                 unconditional_conditioning=torch.zeros_like(c), step_noises=stp, progress=False)
+    e_out, e_p0 = rel_l2(out.cpu(), g["out"]), rel_l2(inter["pred_x0"][-1].cpu(), g["pred_x0_last"])
+    print(f"guided DDIM 50 of 1000 [{prec}]: rel-L2 vs the reference: out {e_out:.3e}, last pred_x0 {e_p0:.3e}")
+    assert e_out < TRAJ_TOL[prec] and e_p0 < TRAJ_TOL[prec]
+
+
 def test_ldm_ddpm_loop_with_mask_vs_oracle():
     """DDPM.p_sample_loop (ddpm.py:1296-1345): mask mix AFTER the step with fresh noise."""
     from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes

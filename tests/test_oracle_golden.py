@@ -245,6 +245,45 @@ def test_full_ddim250_repaint_call_vs_reference_output(eta):
     assert rel_l2(p0, g[f"eta{eta}_pred_x0_last"]) < 5e-6
 
 
+CFG_CFG = dict(image_size=16, in_channels=7, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=[2], channel_mult=[1, 2],
+               num_heads=2)
+
+
+def _full_cfg_inputs(seed, nsteps, shape=(2, 3, 16, 16)):
+    """x_T and the step noise of the reference's guided DDIMSampler.sample call: after the seed, x_T, then per step [unused, step noise]"""
+    torch.manual_seed(seed)
+    xT = torch.randn(shape)
+    stp = []
+    for _ in range(nsteps):
+        torch.randn(shape)
+        stp.append(torch.randn(shape))
+    return xT, torch.stack(stp)
+
+
+def test_full_guided_ddim_call_vs_reference_output():
+    """classifier-free guidance through a whole DDIMSampler.sample call (ddim.py:177-181: the doubled batch, e_u + s (e_c - e_u)), 50 of
+    1000 steps, eta 0.3, scale 2.5, concat conditioning: the oracle against the output of the reference's own call"""
+    from eo_diffusion_amd.backbones.unet_openai import unet_param_shapes
+    g = gt("traj_ddim_S50_T1000_cfg_full")
+    S, eta, scale = (float(v) for v in g["hyper"])
+    sd = synth_state_dict(unet_param_shapes(**CFG_CFG), 7)
+    c = g["cond"]
+    uc = torch.zeros_like(c)
+
+    def eps(x, t):
+        e_u, e_c = UR.unet_forward(sd, CFG_CFG, x, t, cond=uc), UR.unet_forward(sd, CFG_CFG, x, t, cond=c)
+        return e_u + scale * (e_c - e_u)
+
+    tb = SCH.eo_cosine_tables(1000)
+    steps = SCH.ddim_timesteps("uniform", int(S), 1000)
+    assert np.array_equal(steps, g["steps"].numpy())
+    dd = SCH.ddim_tables(tb["alphas_cumprod"], steps, eta)
+    xT, stp = _full_cfg_inputs(int(g["seed"]), len(steps))
+    with torch.no_grad():
+        out, p0 = SR.ddim_sampling(tb, dd, steps, eps, xT, stp)
+    assert rel_l2(out, g["out"]) < 5e-6 and rel_l2(p0, g["pred_x0_last"]) < 5e-6
+
+
 @pytest.mark.parametrize("eta", [0.0, 0.7])
 def test_ddim_single_steps_vs_golden(eta):
     g = gt("ddim_steps_S250_T1000")
