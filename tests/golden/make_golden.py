@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain | train_loop]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain | train_loop | make_label]
 
 The reference never travels to the GPU box; only the .npz / .json data written here does.
 Harness-side adaptations (NOT reference behaviour):
@@ -609,8 +609,30 @@ def gen_train_loop(steps=12, lr=1e-3, posmax=4, decay=0.9):
          probe_x=xp, probe_t=tp, probe_pred_model=pm, probe_pred_ema=pe, hyper=np.asarray([steps, lr, posmax, decay], np.float64))
 
 
+def gen_make_label():
+    """script_utils/utils.py:17-37 make_label (the random rectangle mask inference.py:96-99 / train.py draw) run by the reference under
+    np.random.seed(seed): the rectangle it returns, as (x, y, ws, hs) bounding boxes plus the array sums (the arrays are 0 / 1)"""
+    sys.path.insert(1, os.path.join(REF, "script_utils"))
+    import utils as RUT
+    assert RUT.__file__.startswith(REF), RUT.__file__
+    cases = [((64, 48), 10, 10, 40, 40), ((256, 256), 10, 10, 50, 50), ((28, 28), 20, 15, 45, 35), ((16, 32), 25, 25, 50, 50)]
+    boxes = []
+    for ci, (shape, mnw, mnh, mxw, mxh) in enumerate(cases):
+        for seed in range(8):
+            np.random.seed(1000 * ci + seed)
+            lab = np.asarray(RUT.make_label(shape, mnw, mnh, mxw, mxh))
+            assert set(np.unique(lab)) <= {0.0, 1.0} and lab.shape == tuple(shape)
+            xs, ys = np.nonzero(lab.any(1))[0], np.nonzero(lab.any(0))[0]
+            boxes.append([ci, seed, xs[0], ys[0], xs[-1] - xs[0] + 1, ys[-1] - ys[0] + 1, int(lab.sum())])
+    save("make_label_boxes", cases=np.asarray([[c[0][0], c[0][1], *c[1:]] for c in cases], np.int64), boxes=np.asarray(boxes, np.int64))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 2 and sys.argv[2] == "make_label":
+        gen_make_label()
+        print("done")
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "train_loop":
         gen_train_loop()
         print("done")
@@ -635,4 +657,5 @@ if __name__ == "__main__":
     gen_keyframe_lr()
     gen_full_chain()
     gen_train_loop()
+    gen_make_label()
     print("done")

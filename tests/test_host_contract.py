@@ -214,3 +214,20 @@ def test_make_label_matches_reference_semantics():
         ref = np.zeros((64, 48))
         ref[x:x + ws, y:y + hs] = 1
         assert np.array_equal(lab, ref) and lab.sum() == ws * hs
+
+
+def test_make_label_vs_reference_outputs():
+    """the rectangles the reference's own make_label returned under np.random.seed(seed) (tests/golden/make_golden.py gen_make_label;
+    make_label_boxes.npz): same seeds, same global numpy generator -> the same arrays"""
+    import numpy as np
+    from eo_diffusion_amd.harness import make_label
+    from tests.helpers import gt
+    g = gt("make_label_boxes")
+    cases, boxes = g["cases"].numpy(), g["boxes"].numpy()
+    for ci, seed, x, y, ws, hs, total in boxes:
+        w, h, mnw, mnh, mxw, mxh = (int(v) for v in cases[ci])
+        np.random.seed(1000 * int(ci) + int(seed))
+        lab = make_label((w, h), mnw, mnh, mxw, mxh)
+        ref = np.zeros((w, h))
+        ref[x:x + ws, y:y + hs] = 1.0
+        assert lab.sum() == total and np.array_equal(lab, ref), (ci, seed)
