@@ -604,9 +604,14 @@ def gen_train_loop(steps=12, lr=1e-3, posmax=4, decay=0.9):
     tp = torch.tensor([900, 40])
     with torch.no_grad():
         pm, pe = m.model(xp, tp), ema.module.model(xp, tp)
+    # the checkpoint train.py:137-138 would write at this point: its key layout (names, shapes, dtypes) and the EMA's update counter
+    ckpt = {"model": m.state_dict(), "model_ema": ema.state_dict()}
+    with open(os.path.join(HERE, "checkpoint_layout_u_a1_tiny.json"), "w") as f:
+        json.dump({part: {k: [list(v.shape), str(v.dtype)] for k, v in sdict.items()} for part, sdict in ckpt.items()}, f)
+    n_avg = int(ckpt["model_ema"]["n_averaged"])
     print("  losses", " ".join(f"{v:.5f}" for v in losses))
     save("train_loop_12steps_u_a1_tiny", seed=np.asarray(seed), losses=np.asarray(losses, np.float64), lrs=np.asarray(lrs, np.float64), t=ts,
-         probe_x=xp, probe_t=tp, probe_pred_model=pm, probe_pred_ema=pe, hyper=np.asarray([steps, lr, posmax, decay], np.float64))
+         probe_x=xp, probe_t=tp, probe_pred_model=pm, probe_pred_ema=pe, n_averaged=np.asarray(n_avg), hyper=np.asarray([steps, lr, posmax, decay], np.float64))
 
 
 def gen_make_label():

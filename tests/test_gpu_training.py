@@ -561,6 +561,18 @@ def test_training_loop_vs_reference_run(variant):
         pm = model.model(g["probe_x"].to(DEV), g["probe_t"].to(DEV)).cpu()
         pe = ema.module.model(g["probe_x"].to(DEV), g["probe_t"].to(DEV)).cpu()
     e_m, e_e = rel_l2(pm, g["probe_pred_model"]), rel_l2(pe, g["probe_pred_ema"])
+    # the checkpoint train.py:137-138 writes at this point has the reference's layout: same keys, shapes and dtypes in both halves,
+    # and the EMA's update counter stands where the reference's does
+    import json
+    import os
+    from tests.helpers import GOLDEN
+    layout = json.load(open(os.path.join(GOLDEN, "checkpoint_layout_u_a1_tiny.json")))
+    ckpt = {"model": model.state_dict(), "model_ema": ema.state_dict()}
+    for part in ("model", "model_ema"):
+        mine = {k: [list(v.shape), str(v.dtype)] for k, v in ckpt[part].items()}
+        assert list(mine.keys()) == list(layout[part].keys()), (part, set(mine) ^ set(layout[part]))
+        assert mine == layout[part], [k for k in mine if mine[k] != layout[part][k]][:5]
+    assert int(ckpt["model_ema"]["n_averaged"]) == int(g["n_averaged"])
     print(f"training loop [{variant}]: worst relative loss difference {worst:.2e}; trained model on the probe {e_m:.2e}, EMA copy {e_e:.2e}")
     tol_loss, tol_probe = (1e-5, 2e-5) if prec == "fp32" else (2e-3, 1e-2)   # measured: 2.6e-7 / 1.1e-6 and 9.6e-5 / 1.7e-3
     assert worst < tol_loss and e_m < tol_probe and e_e < tol_probe
