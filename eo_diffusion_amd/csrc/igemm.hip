@@ -978,12 +978,100 @@ __device__ __forceinline__ void prefetch_bcol(const IgemmP& p, int ncols, int co
     }
 }
 
+// ---- direct epilogue of the fp32-storage patch-mode kernels (conv3x3_halo_kernel<SPLIT>) ----------------------------------------
+// The split product's MFMAs are issued with their operands SWAPPED (D = W X^T instead of X W^T; both operands of a 16x16x32 MFMA have
+// the same register layout, so the swap is free): a lane then holds FOUR CONSECUTIVE CHANNELS of ONE pixel per accumulator tile
+// (channel = 16 j + 4 (lane >> 4) + r, pixel = 16 i + (lane & 15)), i.e. a 16-byte piece of an NHWC row.  The epilogue stores straight
+// from the accumulators: no LDS transpose (2.8 us of VALU per workgroup on the transposed path, tools/debug/halo_stamps.py), no LDS at
+// all -- the operand ring is free while it runs.  Per-channel terms (bias + per-sample bias) come as 4 x TN values fetched at entry.
+template <int TN>
+__device__ __forceinline__ void prefetch_bcol4(const IgemmP& p, int ncols, int col0, int lane, int n_first, f32x4 (&out)[TN]) {
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = col0 + j * 16 + 4 * lg;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < ncols) {  // (Cout is a multiple of the 16-byte chunk: a quad is inside or outside as a whole)
+            if (p.bias && p.bias_mode == 1) v = *reinterpret_cast<const f32x4*>(p.bias + c);
+            if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (long long)n_first * p.cbias_stride + c);
+        }
+        out[j] = v;
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const TileGeom& g, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16], int wave,
+                                                     int lane, int n0, const f32x4 (&bq)[BN / WAVES_N / 16], float alpha) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lp = lane & 15, lg = lane >> 4;
+    float* const y = reinterpret_cast<float*>(p.y);
+    const float* const res = reinterpret_cast<const float*>(p.res);
+    const bool want_stats = p.stats != nullptr;
+    const int c0 = n0 + wn * WN + 4 * lg;
+    // channel tile by channel tile (16 channels: this lane's quad c0 + 16 j .. + 3 of the TM pixels 16 i + lp), so that only ONE tile's
+    // statistics accumulators and two tiles' residuals are live next to the accumulators (all TN at once: 76 spilled registers)
+    long long off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int nrel, ho, wo;
+        decode_row<BM>(p, g, wm * WM + i * 16 + lp, nrel, ho, wo);  // patch mode: every row of the tile exists
+        off[i] = (((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo) * p.Cout;
+    }
+    const int slot = (g.tile_m - g.n_first * p.tiles_per_image) * WAVES_M + wm;
+    f32x4 rv[2][TM];
+    if (res && c0 < p.Ncols) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rv[0][i] = *reinterpret_cast<const f32x4*>(res + off[i] + c0);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + j * 16;
+        if (res && j + 1 < TN && c + 16 < p.Ncols) {  // the next tile's residual is in flight while this tile is stored
+#pragma unroll
+            for (int i = 0; i < TM; ++i) rv[(j + 1) & 1][i] = *reinterpret_cast<const f32x4*>(res + off[i] + c + 16);
+        }
+        if (c < p.Ncols) {
+            f32x4 ss = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x4 v = acc[i][j] * alpha + bq[j];
+                if (res) v += rv[j & 1][i];
+                *reinterpret_cast<f32x4*>(y + off[i] + c) = v;
+                ss += v;
+                sq += v * v;
+            }
+            if (want_stats) {
+                // per-channel sums over the wave's WM pixels: the TM pixel tiles in-lane (above), then the 16 lanes that share lg
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int o = 8; o >= 1; o >>= 1) {
+                        ss[r] += __shfl_xor(ss[r], o);
+                        sq[r] += __shfl_xor(sq[r], o);
+                    }
+                }
+                if (lp == 0) {
+                    float* dst = p.stats + (((long long)g.n_first * p.stats_P + slot) * p.Cout + c) * 2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dst[2 * r] = ss[r];
+                        dst[2 * r + 1] = sq[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void conv3x3_halo_kernel(const IgemmP p) {
     static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M == 2), "fused skip conv: 16x16x32 instances of the 8x16 tile");
     static_assert(!SPLIT || (sizeof(T) == 4 && MS == 16), "the split-fp16 product is a mode of fp32 storage, on 16x16x32 MFMAs");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only");
     constexpr bool XF = GN || SPLIT;  // the staged patch pieces are rewritten in place by the wave that DMA'd them
+    // fp32-storage split instances (not the 32-column NCHW head): swapped MFMA operands + stores straight from the accumulators
+    constexpr bool DIRECT = SPLIT && MS == 16 && BN >= 64;
     constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
     // WAVES_N = 4 (BN = 256): the 8x16 pixel tile with EIGHT waves, 2 x 4, each still 64 x 64 -- one workgroup covers the two N-tiles of a
     // 256-column conv, so the patch is fetched from HBM and normalised / split ONCE for both (one 8-wave workgroup per CU instead of two
@@ -1015,8 +1103,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode: ty0, tx0, n_first
     // epilogue operands fetched NOW (their latency passes under the prologue's DMA; older than every DMA, so the counted vmcnt waits of
     // the loop are unaffected): per-column bias terms and the weights' scale
-    float pre_bcol[TN];
-    prefetch_bcol<TN, MS>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    float pre_bcol[DIRECT ? 1 : TN];
+    f32x4 pre_bq[DIRECT ? TN : 1];
+    if constexpr (DIRECT) prefetch_bcol4<TN>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bq);
+    else prefetch_bcol<TN, MS>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bcol);
     float wsc1 = 1.0f;
     if constexpr (SPLIT) wsc1 = p.w_scale[1];
     // split-fp16 product: power-of-two operand scale of this tile's image from the bound table(s) (wave-uniform, common.h); the fused
@@ -1311,19 +1401,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, al[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(bst + b_rd + j * MS * BKB + (((ch + 1) ^ bsw) << 4));
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bl[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
             } else if constexpr (MS == 16) {
                 // fp16 storage: the K-step's 64 k are two 16x16x32 sub-steps; lane quarter lh of sub-step s reads chunk 4 s + lh
 #pragma unroll
@@ -1465,19 +1558,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, al[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(stg + b_rd2 + j * MS * BKB + olo);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bl[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1502,7 +1598,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     if constexpr (SPLIT) {
         IgemmP pe = p;
         pe.alpha = p.alpha * wsc1 * asc.inv;  // undo the weight and activation scales (exact powers of two)
-        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
+        if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(p, g, acc, wave, lane, n0, pre_bq, pe.alpha);
+        else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     } else {
         igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     }

@@ -40,7 +40,7 @@ for name in a.shapes.split(","):
     rc = L.eod_debug_read_stamps(buf.ctypes.data, nwg)
     assert rc == 0, rc
     buf = buf[buf[:, 0] > 0].astype(np.float64)
-    slab = (buf[:, 8] - buf[:, 4]) * 0.01   # K-loop end -> accumulators transposed into the LDS slab (stamp 4)
+    slab = (buf[:, 8] - buf[:, 4]) * 0.01 if (buf[:, 8] > 0).all() else np.zeros(len(buf))   # K-loop end -> LDS transpose done (stamp 4; the direct epilogue has none)
     wall = buf[:, 0:8:2] * 0.01   # us
     clk = buf[:, 1:8:2]
     ph = np.diff(wall, axis=1)
