@@ -1642,6 +1642,7 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     char* const sA = smem;             // [2][ABUF]
     char* const sB = smem + 2 * ABUF;  // [2][BSTAGE]
 
+    constexpr bool DIRECT = SPLIT && !BWD;  // swapped MFMA operands + stores straight from the accumulators (see halo_epilogue_direct)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -1651,8 +1652,10 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     const int cls = BWD ? 0 : tile_nn / tpc, n0 = (tile_nn - cls * tpc) * BN;
     const int par_y = cls >> 1, par_x = cls & 1;        // (forward: the workgroup's class; backward: classes rotate inside the K loop)
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode on the STORED map: ty0, tx0, n_first
-    float pre_bcol[TN];  // epilogue operands fetched at entry (see conv3x3_halo_kernel)
-    prefetch_bcol<TN, MS>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    float pre_bcol[DIRECT ? 1 : TN];  // epilogue operands fetched at entry (see conv3x3_halo_kernel)
+    f32x4 pre_bq[DIRECT ? TN : 1];
+    if constexpr (DIRECT) prefetch_bcol4<TN>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bq);
+    else prefetch_bcol<TN, MS>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bcol);
     float wsc1 = 1.0f;
     if constexpr (SPLIT) wsc1 = p.w_scale[1];
     AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};             // split-fp16 product: operand scale of this tile's image (see conv3x3_halo_kernel)
@@ -1817,19 +1820,22 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, al[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(bst + boff1 + j * MS * BKB);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bl[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int v = 0; v < 2; ++v) {  // fp16 storage: two 32-k sub-steps per 64-channel chunk
@@ -1880,7 +1886,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
     }
     if constexpr (SPLIT) pe.alpha = p.alpha * wsc1 * asc.inv;
-    igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
+    if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, ge, acc, wave, lane, n0, pre_bq, pe.alpha);
+    else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
 }
 
 template <typename T, bool SPLIT, bool BWD = false> static int launch_up4(IgemmP& p, hipStream_t st) {
