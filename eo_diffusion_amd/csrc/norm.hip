@@ -297,16 +297,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int tx = threadIdx.x, ty = threadIdx.y, RY = blockDim.y;
     const int n = blockIdx.y;
     float osc = 1.0f;
-    if constexpr (SPLIT) {  // (before any thread leaves: the table maximum is a wave-wide reduction)
-        const int lin = ty * blockDim.x + tx;
+    if constexpr (SPLIT) {
+        // the image's table maximum, read by every thread itself (a block-uniform address: scalar loads).  NOT a wave reduction: the
+        // block is (C / EPC) x ry threads, and its last wave is partial whenever that is no multiple of 64 (C = 288: 72 x 3 = 216) -- a
+        // 24-lane wave then missed the entries 24..31 and scaled ITS pixels by another power of two than the consumer un-scales by
+        // (found by tests/test_gpu_fuzz_archs.py case 83: 1e-2 on a whole UNet whenever the maximum sat in one of those entries)
         float b = 0.0f;
-        if ((lin & 63) < EOD_AB) {
-            b = ab[(long long)n * EOD_AB + (lin & 63)];
-            b = (b == b) ? b : __uint_as_float(0x7f800000u);
-        }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o));
-        osc = ab_scale_of(__shfl(b, 0)).s;
+        for (int j = 0; j < EOD_AB; ++j) {
+            const float v = ab[(long long)n * EOD_AB + j];
+            b = fmaxf(b, (v == v) ? v : __uint_as_float(0x7f800000u));
+        }
+        osc = ab_scale_of(b).s;
     }
     const int col = blockIdx.z * blockDim.x + tx;  // chunk column of this thread (channel blocks along z for wide layers)
     if (col >= C / EPC) return;

@@ -39,6 +39,14 @@ def adversarial(kind, tag, shape, seed=71):
         return x * 1e-6
     if kind == "huge":       # everything far beyond 4094 (what --no_clip sampling produces)
         return x * 1e5
+    if kind == "outlier_image":  # ONE image carries a few elements 50 times larger: after a GroupNorm the images still need DIFFERENT scales
+        m = torch.zeros(shape)
+        m[1 % shape[0]].view(-1)[::97] = 1.0
+        return x * (1.0 + 49.0 * m)
+    if kind == "outlier_last_group":  # the largest values of ONE image sit in its last channels: the maximum of its bound table is entry 31
+        m = torch.zeros(shape)
+        m[1 % shape[0], -(shape[1] // 32):].view(-1)[::7] = 1.0
+        return x * (1.0 + 5.0 * m)
     if kind == "per_image":  # images of one batch ten orders of magnitude apart: the scale is per image
         mag = torch.tensor([10.0 ** (5 - 10 * (i % 2)) for i in range(shape[0])]).view(-1, 1, 1, 1)
         return x * mag
@@ -367,8 +375,10 @@ def test_no_clip_sampling_whose_x_t_exceeds_4094():
 
 
 # ------------------------------------------------------------------------------------------------ pre-split producers
-@pytest.mark.parametrize("kind", ["heavy", "mixed", "huge", "per_image"])
-@pytest.mark.parametrize("case", [(2, 128, 16, 16, 384), (1, 384, 64, 64, 1152), (3, 96, 7, 9, 40)])
+@pytest.mark.parametrize("kind", ["heavy", "mixed", "huge", "per_image", "outlier_image", "outlier_last_group"])
+@pytest.mark.parametrize("case", [(2, 128, 16, 16, 384), (1, 384, 64, 64, 1152), (3, 96, 7, 9, 40),
+                                  (3, 288, 6, 6, 864), (3, 288, 6, 6, 288), (2, 192, 12, 12, 576),   # (small maps, K >= 8 steps: split-K, tiles across images)
+                                  (2, 288, 16, 16, 96), (2, 96, 8, 8, 96), (1, 160, 16, 32, 64)])   # (channel counts whose pass runs in blocks of a partial last wave)
 def test_groupnorm_written_presplit_feeds_a_1x1_conv(kind, case):
     """AttentionBlock.norm -> qkv (unet_openai.py:427-428, 414): the normalising pass writes its output PRE-SPLIT ([8 x hi | 8 x lo] per
     8 channels, scaled per image from the finalize's bound table) and the 1x1 conv DMAs those rows straight into its LDS image

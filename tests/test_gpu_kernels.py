@@ -531,7 +531,7 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits
 
 
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
-                                                 (64, 4, 8, False)])
+                                                 (64, 4, 8, False), (144, 6, 32, True), (36, 9, 32, True), (2304, 3, 32, True), (300, 2, 24, True)])
 def test_attention_forward_natural_layout(T, heads, d, new_order):
     """eod_attention_fwd_nat: fused attention straight on the qkv conv output (both channel orders), ragged sequence lengths,
     with the log-sum-exp output -- vs torch softmax(q k^T / sqrt(d)) v"""
@@ -556,7 +556,8 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
 
 
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
-                                                 (64, 4, 8, False), (4096, 2, 64, False)])
+                                                 (64, 4, 8, False), (4096, 2, 64, False),
+                                                 (144, 6, 32, True), (36, 9, 32, True), (2304, 3, 32, True), (300, 2, 24, True)])
 @pytest.mark.parametrize("mag", [0.8, 4.0])
 @pytest.mark.parametrize("bound", [False, True])
 def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, bound):
@@ -593,7 +594,8 @@ def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, boun
 
 
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
-                                                 (64, 4, 8, False), (300, 3, 24, False), (256, 1, 40, True), (130, 2, 56, False)])
+                                                 (64, 4, 8, False), (300, 3, 24, False), (256, 1, 40, True), (130, 2, 56, False),
+                                                 (144, 6, 32, True), (36, 9, 32, True), (2304, 3, 32, True), (300, 2, 24, True)])
 @pytest.mark.parametrize("mag", [0.8, 4.0])
 def test_attention_forward_natural_layout_exact_fp32(T, heads, d, new_order, mag):
     """the exact-fp32 instance of eod_attention_fwd_nat (EOD_ATTN_EXACT_F32: IEEE fp32 products on v_mfma_f32_32x32x2_f32, fp32 online
