@@ -25,17 +25,17 @@ typedef __attribute__((address_space(3))) void lds_void_b;
 // 2e-4 and 1e-6 and below -- the fp16 SUBNORMAL range (min normal 6.1e-5), where every halving of the value costs a mantissa bit
 // (measured at 512 x 512 x 13, T = 4096 / 16384: 6.6 % error on the qkv weight gradients against the exact-fp32 mode).  Both are
 // therefore multiplied by an exact power of two before the conversion and the accumulators divided by it once at the end:
-// P x 2^8 (P <= 1 -> at most 256), dS x 2^12 (overflows fp16 only if P |dP - D| > 16, i.e. with a loss scale far too large -- and an
-// inf there is caught by the guarded optimizer step like any other fp16 overflow).
+// P x 2^8 (P <= 1 -> at most 256), dS x 2^min(12, floor(log2 T)): the 2^12 that T >= 4096 needs overflows fp16 once P |dP - D| > 16, which
+// a SHORT sequence reaches at an ordinary loss scale (T = 4: P ~ 1/4, and the mean-reduced loss of a tiny prediction tensor makes dP
+// large; found by tests/test_gpu_fuzz_archs.py, training case 15: NaN gradients at the default loss scale of 1024) -- P ~ 1/T is what
+// the scale compensates, so it follows T (AttnBwdP::ds_log2; unchanged for T >= 4096).  An inf that still occurs is caught by the
+// guarded optimizer step like any other fp16 overflow.
 #define AB_P_SCALE 256.0f
-#define AB_DS_SCALE 4096.0f
 // The softmax work per score element is what bounds these kernels at small head dims (d = 32: ~8 VALU slots per element against 2 x 32
 // MACs), so the scales cost nothing: they ride in the exponent.  P x 2^8 = exp2(s * alpha*log2(e) - (lse*log2(e) - 8)) is ONE fma + one
-// v_exp_f32 with the per-row constant prepared where lse is staged; dS x 2^12 = (P x 2^8) * (16 dP - 16 D) is one fma + one multiply.
+// v_exp_f32 with the per-row constant prepared where lse is staged; dS x 2^k = (P x 2^8) * (2^(k-8) dP - 2^(k-8) D) is one fma + one multiply.
 #define AB_LOG2E 1.4426950408889634f
 #define AB_P_LOG2 8.0f                                  // log2(AB_P_SCALE)
-#define AB_DS_LOG2 12.0f                                // log2(AB_DS_SCALE)
-#define AB_DS_OVER_P (AB_DS_SCALE / AB_P_SCALE)         // 16
 
 struct AttnBwdP {
     const char* qkv;
@@ -45,6 +45,7 @@ struct AttnBwdP {
     char* dqkv;
     int N, T, C, heads, d, q_off, k_off, v_off, hs;
     float alpha;
+    float ds_log2;   // log2 of the scale dS is carried on: min(12, floor(log2 T))
 };
 
 constexpr int AB_ROWB = 128;  // LDS row = 64 halves (head dim padded with zeros)
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
     float* sL = reinterpret_cast<float*>(sO + 2 * 64 * AB_ROWB);  // [2][64] lse, then [2][64] D
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float ds_over_p = exp2f(p.ds_log2 - AB_P_LOG2), ds_inv = exp2f(-p.ds_log2);  // exact powers of two
     const int lr = lane & 31, lh = lane >> 5;
     const int b = blockIdx.y, n = b / p.heads, h = b - n * p.heads;
     const int s0 = blockIdx.x * 128;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
         if (tid < 64) {  // rows beyond T: lse = +inf makes their P exactly 0
             const bool in = qt * 64 + tid < p.T;
             sL[buf * 64 + tid] = in ? lse[qt * 64 + tid] * AB_LOG2E - AB_P_LOG2 : INFINITY;   // exponent offset of P x 2^8 (log2 domain)
-            sL[128 + buf * 64 + tid] = in ? Dv[qt * 64 + tid] * AB_DS_OVER_P : 0.0f;         // 16 D
+            sL[128 + buf * 64 + tid] = in ? Dv[qt * 64 + tid] * ds_over_p : 0.0f;            // 2^(k-8) D
         }
     };
     stage_q(0, 0);
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
                 for (int e = 0; e < 4; ++e) {
                     const float pe = __builtin_amdgcn_exp2f(fmaf(s[mt][4 * g4 + e], a2, -l4[e]));  // P x 2^8 (0 for rows beyond T: l4 = +inf)
                     s[mt][4 * g4 + e] = pe;
-                    dp[mt][4 * g4 + e] = pe * fmaf(dp[mt][4 * g4 + e], AB_DS_OVER_P, -d4[e]);  // dS x 2^12
+                    dp[mt][4 * g4 + e] = pe * fmaf(dp[mt][4 * g4 + e], ds_over_p, -d4[e]);  // dS x 2^k
                 }
             }
         // ---- dV += P^T dO,  dK += dS^T Q   (contraction over the 64 queries, permuted order) ----
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnBwdP p) {
                 if (srow >= p.T) continue;
                 half_t* row = out + (long long)srow * 3 * p.C;
                 row[p.v_off + h * p.hs + j] = (half_t)(dv[t][r] * (1.0f / AB_P_SCALE));
-                row[p.k_off + h * p.hs + j] = (half_t)(dk[t][r] * (p.alpha * (1.0f / AB_DS_SCALE)));
+                row[p.k_off + h * p.hs + j] = (half_t)(dk[t][r] * (p.alpha * ds_inv));
             }
         }
     }
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
     const long long ob = (long long)h * p.d * 2;
     const int myq = q0 + wave * 32 + lr;
     // exponent offset of P x 2^12 in the log2 domain (+inf: P = 0 for rows beyond T)
-    const float my_l2 = myq < p.T ? p.lse[((long long)n * p.heads + h) * p.T + myq] * AB_LOG2E - AB_DS_LOG2 : INFINITY;
+    const float my_l2 = myq < p.T ? p.lse[((long long)n * p.heads + h) * p.T + myq] * AB_LOG2E - p.ds_log2 : INFINITY;
     const float my_D = myq < p.T ? p.D[((long long)n * p.heads + h) * p.T + myq] : 0.0f;
     const float a2 = p.alpha * AB_LOG2E;
 
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdP p) {
             for (int r = 0; r < 16; ++r) {
                 const int qrow = q0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (qrow >= p.T) continue;
-                out[(long long)qrow * 3 * p.C + p.q_off + h * p.hs + j] = (half_t)(dq[t][r] * (p.alpha * (1.0f / AB_DS_SCALE)));
+                out[(long long)qrow * 3 * p.C + p.q_off + h * p.hs + j] = (half_t)(dq[t][r] * (p.alpha * exp2f(-p.ds_log2)));
             }
         }
     }
@@ -521,6 +523,11 @@ extern "C" int eod_attention_bwd(const void* qkv, const void* dO, const float* l
     p.qkv = (const char*)qkv; p.dO = (const char*)dO; p.lse = lse; p.D = D; p.dqkv = (char*)dqkv;
     p.N = N; p.T = T; p.C = C; p.heads = heads; p.d = d; p.q_off = q_off; p.k_off = k_off; p.v_off = v_off; p.hs = head_stride;
     p.alpha = 1.0f / sqrtf((float)d);
+    {
+        int l2 = 0;
+        while ((2 << l2) <= T && l2 < 12) ++l2;  // min(12, floor(log2 T))
+        p.ds_log2 = (float)l2;
+    }
     const dim3 grid((T + 127) / 128, N * heads);
     const size_t lds_kv = (size_t)(256 + 256) * AB_ROWB + 4 * 64 * sizeof(float);
     const size_t lds_q = (size_t)(256 + 256) * AB_ROWB;

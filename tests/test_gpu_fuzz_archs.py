@@ -25,6 +25,8 @@ def poison_allocator_cache():
     reads beyond the logical extent of a buffer, or a buffer it never wrote, then shows up as NaN in the result even where the stray
     value only ever meets a zero weight -- and deterministically, instead of as a memory fault on the one layout where the stray read
     crosses the end of a mapped segment."""
+    if os.environ.get("EOD_FUZZ_NO_POISON", "0") == "1":   # (debugging aid: tells an uninitialised read from an arithmetic overflow)
+        return
     small = [torch.full((1 << 18,), float("nan"), device=DEV) for _ in range(192)]   # 1 MiB blocks: the small pool's 2 MiB segments
     large = [torch.full((1 << 26,), float("nan"), device=DEV) for _ in range(4)]     # 256 MiB blocks: the large pool
     torch.cuda.synchronize()

@@ -473,7 +473,7 @@ def test_softmax_long_rows_forward_and_backward(prec, n, ld):
 @pytest.mark.parametrize("T,heads,d,new_order", [(128, 2, 16, False), (256, 2, 32, True), (256, 1, 48, False), (384, 2, 64, False), (128, 3, 8, True),
                                                  (49, 2, 16, False), (196, 1, 32, True), (200, 2, 48, False), (64, 2, 64, False)])
 @pytest.mark.parametrize("neg_logits", [False, True])
-def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits):
+def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits, dO_scale=0.5):
     """eod_attention_fwd (with log-sum-exp) + eod_rowdot + eod_attention_bwd against torch autograd of
     softmax(q k^T / sqrt(d)) v on the natural qkv layout (legacy [h][q|k|v][d] and new [q|k|v][h][d] orders).
     neg_logits: every logit of every row is around -35 (q and k carry opposite offsets, as a negative b_q . b_k bias term gives):
@@ -484,7 +484,7 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits
     L = _lib.lib()
     N, C = 2, heads * d
     qkv = synth_input(f"fa{T}{d}", (N, T, 3 * C), 7, scale=0.7)
-    dO = synth_input(f"fd{T}{d}", (N, T, C), 8, scale=0.5)
+    dO = synth_input(f"fd{T}{d}", (N, T, C), 8, scale=dO_scale)
     qo, ko, vo, hs = (0, C, 2 * C, d) if new_order else (0, d, 2 * d, 3 * d)
     if neg_logits:
         off = math.sqrt(35.0 / math.sqrt(d))  # q . k / sqrt(d) = -off^2 d / sqrt(d) + O(1) = -35
@@ -528,6 +528,14 @@ def test_flash_attention_backward_vs_autograd(T, heads, d, new_order, neg_logits
             # (neg_logits: q and k carry a common offset of +-off that cancels in dQ = sum_s dS_s k_s because sum_s dS_s = 0 -- the
             #  fp16 rounding of dS is amplified by |off| / spread = ~10x against the result; 1.5e-2 there)
             assert rel_l2(a, b_) < (1.5e-2 if neg_logits else 6e-3), (name, h, rel_l2(a, b_))
+
+
+@pytest.mark.parametrize("T,heads,d", [(4, 4, 16), (16, 6, 16), (36, 2, 32), (64, 2, 16)])
+def test_flash_attention_backward_short_sequence_with_loss_scaled_gradient(T, heads, d):
+    """a short sequence (P ~ 1/T is NOT small) with an output gradient as large as a loss scale of 1024 makes it on a tiny prediction
+    tensor (|dO| ~ 50): dS = P (dP - D) carried on 2^12, the scale T >= 4096 needs, overflowed fp16 here (NaN gradients, training
+    fuzz case 15); the scale now follows T (attn_bwd.hip: AttnBwdP::ds_log2)"""
+    test_flash_attention_backward_vs_autograd(T, heads, d, False, False, dO_scale=50.0)
 
 
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
