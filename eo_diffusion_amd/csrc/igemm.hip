@@ -657,7 +657,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     if constexpr (CONV) {
         rsA0 = make_rsrc(p.a0 + (long long)n_first * p.H * p.W * p.C0 * ES);
         rsA1 = make_rsrc(p.a1 ? p.a1 + (long long)n_first * p.H * p.W * p.C1 * ES : p.a0);
-        rsB = make_rsrc(p.b + (long long)n0 * p.Cin * ES);
+        // (row pitch of the packed weights: Cin, or the padded [tap][C0] row of the thin-input first conv -- with Cin here the SECOND
+        //  N-tile of a tap-major conv, i.e. model_channels > 128, read its weights from the wrong rows: found by the fuzz hunt, round 3)
+        rsB = make_rsrc(p.b + (long long)n0 * (p.tapmajor_log2 >= 0 ? p.ldk : p.Cin) * ES);
     } else {
         rsA0 = make_rsrc(p.a0 + (offA + (long long)tile_m * BM * p.lda) * ES);
         rsA1 = rsA0;

@@ -36,15 +36,19 @@ def poison_allocator_cache():
 def _random_cfg(i):
     r = np.random.RandomState(1000 + i)
     levels = int(r.choice([2, 3, 3, 4]))
-    mc = int(r.choice([32, 32, 64, 64, 96]))
+    big = os.environ.get("EOD_FUZZ_BIG", "0") == "1"   # (hunt mode: BASELINE-like widths on larger maps -- the halo / 8-wave / parity-class kernels)
+    mc = int(r.choice([96, 128, 128, 160])) if big else int(r.choice([32, 32, 64, 64, 96]))
     mult = [1] + [int(r.choice([1, 2, 2, 3, 4])) for _ in range(levels - 1)]
     # map sizes whose every level stays >= 2 pixels, the deepest one possibly odd, some non-square.  No level may be 3 wide: the
     # reference's Upsample turns a 3 x 3 map into 7 x 7 (unet_openai.py:236-239, the 28 -> 14 -> 7 -> 3 path), which only fits a 7-wide skip
     base = 2 ** (levels - 1)
     H = int(base * r.choice([2, 4, 5, 6, 7, 8]))
     W = int(base * r.choice([2, 4, 5, 6, 8])) if r.rand() < 0.4 else H
-    if max(H, W) > 64:
-        H, W = min(H, 64), min(W, 64)
+    if big:
+        H = int(base * r.choice([4, 8, 8, 12, 16]))
+        W = int(base * r.choice([4, 8, 16])) if r.rand() < 0.4 else H
+    if max(H, W) > (128 if big else 64):
+        H, W = min(H, 128 if big else 64), min(W, 128 if big else 64)
     in_ch = int(r.choice([1, 3, 3, 4, 13]))
     cond_ch = int(r.choice([0, 0, 0, in_ch]))
     attn = sorted({int(2 ** k) for k in range(levels) if r.rand() < 0.45})

@@ -390,7 +390,8 @@ def test_fp32x3_product_is_fp32_grade_at_any_magnitude(mag, wmag):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
-@pytest.mark.parametrize("dims", [(2, 3, 16, 16, 128), (1, 7, 32, 16, 128), (2, 13, 8, 24, 64), (1, 4, 7, 9, 32), (1, 3, 64, 64, 128)])
+@pytest.mark.parametrize("dims", [(2, 3, 16, 16, 128), (1, 7, 32, 16, 128), (2, 13, 8, 24, 64), (1, 4, 7, 9, 32), (1, 3, 64, 64, 128),
+                                  (2, 3, 16, 16, 192), (1, 13, 16, 16, 320), (2, 1, 8, 8, 160)])   # (more than one 128-column tile: UNetBig's base width is 192)
 def test_first_conv_tapmajor(prec, dims):
     """thin-input 3x3 conv (UNet input conv, unet_openai.py:609): K over the flattened [tap][channel] axis
     (eod_conv_desc.w_tapmajor); image channels zero-padded to whole 16-byte chunks; borders, ragged maps, N tails"""
