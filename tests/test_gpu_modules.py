@@ -126,7 +126,7 @@ def test_flash_attention_longer_sequences(C, heads, hw, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
-@pytest.mark.parametrize("factory,size", [("UNetSmall", 32), ("UNet", 28)])
+@pytest.mark.parametrize("factory,size", [("UNetSmall", 32), ("UNet", 28), ("UNetBig", 32)])   # (UNetBig: base width 192 -- the first conv spans two N-tiles)
 def test_factory_presets_vs_oracle(prec, factory, size):
     """UNetBig/UNet/UNetSmall presets (unet_openai.py:783-922): FiLM, resblock_updown, new attention order,
     num_head_channels, class conditioning, 3 attention resolutions; 28x28 exercises ragged maps (14x14, 7x7, T=49)."""
@@ -151,7 +151,7 @@ def test_factory_presets_vs_oracle(prec, factory, size):
     with torch.no_grad():
         out = m(x.to(DEV), t.to(DEV), y=y.to(DEV)).cpu()
     ref = UR.unet_forward(sd, cfg, x, t, y=y)
-    assert rel_l2(out, ref) < (2e-5 if prec == "fp32" else 1e-2)
+    assert rel_l2(out, ref) < (1e-2 if prec == "fp16" else 2e-5)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
