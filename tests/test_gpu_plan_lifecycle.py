@@ -1,0 +1,69 @@
+"""GPU: the cached launch plan of a UNetModel through the things a caller does to a module between forwards -- other batch sizes and
+map sizes, new weights (load_state_dict, in-place optimizer-style updates, parameter re-pointing), precision switches, train / eval,
+deepcopy (what AveragedModel does, utils.py:56-67) -- every forward checked against the oracle ON THE WEIGHTS OF THAT MOMENT.  One
+live plan per model is kept; a stale plan would show up as the previous call's result."""
+import copy
+
+import pytest
+import torch
+
+from tests.gpu_util import DEV, TOL
+from tests.helpers import rel_l2
+from tests.synth import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+CFG = dict(image_size=16, in_channels=3, out_channels=3, model_channels=32, channel_mult=[1, 2], num_res_blocks=1, attention_resolutions=[2],
+           num_heads=2)
+
+
+def _check(u, sd, shape, prec, tag, seed):
+    from oracle import unet_ref as UR
+    N, _, H, W = shape
+    x = synth_input(f"lc{tag}", shape, seed)
+    t = torch.tensor([(97 * seed + 211 * k) % 1000 for k in range(N)])
+    with torch.no_grad():
+        out = u(x.to(DEV), t.to(DEV)).cpu()
+        ref = UR.unet_forward({k: v.detach().cpu() for k, v in sd.items()}, CFG, x, t)
+    e = rel_l2(out, ref)
+    assert e < TOL[prec], (tag, prec, e)
+
+
+@pytest.mark.parametrize("prec", ["fp32x3", "fp16"])
+def test_plan_follows_the_module_through_its_life(prec):
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    shapes = unet_param_shapes(**CFG)
+    sd = synth_state_dict(shapes, 7)
+    u = UNetModel(**CFG).set_precision(prec)
+    u.load_state_dict(sd)
+    u = u.to(DEV).eval()
+    live = lambda: {k: v for k, v in u.state_dict().items()}
+    _check(u, live(), (2, 3, 16, 16), prec, "first", 1)
+    _check(u, live(), (3, 3, 16, 16), prec, "other batch", 2)
+    _check(u, live(), (1, 3, 32, 16), prec, "other map", 3)
+    _check(u, live(), (2, 3, 16, 16), prec, "back to the first shape", 4)
+    u.load_state_dict(synth_state_dict(shapes, 8))                      # new weights into the same parameter tensors
+    _check(u, live(), (2, 3, 16, 16), prec, "after load_state_dict", 5)
+    with torch.no_grad():                                               # in-place updates, as an optimizer makes them
+        for p in u.parameters():
+            p.mul_(0.9).add_(0.01)
+    _check(u, live(), (2, 3, 16, 16), prec, "after in-place updates", 6)
+    with torch.no_grad():                                               # a parameter re-pointed to new storage (p.data = ...)
+        w = u.input_blocks[0][0].weight
+        w.data = (w.data * 1.5).clone()
+    _check(u, live(), (2, 3, 16, 16), prec, "after re-pointing a parameter", 7)
+    other = "fp32" if prec != "fp32" else "fp16"
+    u.set_precision(other)
+    _check(u, live(), (2, 3, 16, 16), other, "after a precision switch", 8)
+    u.set_precision(prec)
+    _check(u, live(), (2, 3, 16, 16), prec, "and back", 9)
+    u.train()
+    _check(u, live(), (2, 3, 16, 16), prec, "train mode without autograd (dropout 0)", 10)
+    u.eval()
+    c = copy.deepcopy(u)                                                # AveragedModel's deep copy
+    with torch.no_grad():
+        for p in c.parameters():
+            p.mul_(1.1)
+    _check(c, {k: v for k, v in c.state_dict().items()}, (2, 3, 16, 16), prec, "deep copy with its own weights", 11)
+    _check(u, live(), (2, 3, 16, 16), prec, "the original after the copy changed", 12)
+    u2 = u.to("cpu").to(DEV)                                            # a round trip through the host moves every parameter
+    _check(u2, {k: v for k, v in u2.state_dict().items()}, (2, 3, 16, 16), prec, "after .to(cpu).to(gpu)", 13)
