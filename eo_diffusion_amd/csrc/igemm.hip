@@ -525,8 +525,118 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
     }
 }
 
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32>
+// ---- direct epilogue of the fp32-storage patch-mode kernels (conv3x3_halo_kernel<SPLIT>) ----------------------------------------
+// The split product's MFMAs are issued with their operands SWAPPED (D = W X^T instead of X W^T; both operands of a 16x16x32 MFMA have
+// the same register layout, so the swap is free): a lane then holds FOUR CONSECUTIVE CHANNELS of ONE pixel per accumulator tile
+// (channel = 16 j + 4 (lane >> 4) + r, pixel = 16 i + (lane & 15)), i.e. a 16-byte piece of an NHWC row.  The epilogue stores straight
+// from the accumulators: no LDS transpose (2.8 us of VALU per workgroup on the transposed path, tools/debug/halo_stamps.py), no LDS at
+// all -- the operand ring is free while it runs.  Per-channel terms (bias + per-sample bias) come as 4 x TN values fetched at entry.
+template <int TN>
+__device__ __forceinline__ void prefetch_bcol4(const IgemmP& p, int ncols, int col0, int lane, int n_first, f32x4 (&out)[TN]) {
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = col0 + j * 16 + 4 * lg;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < ncols) {  // (Cout is a multiple of the 16-byte chunk: a quad is inside or outside as a whole)
+            if (p.bias && p.bias_mode == 1) v = *reinterpret_cast<const f32x4*>(p.bias + c);
+            if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (long long)n_first * p.cbias_stride + c);
+        }
+        out[j] = v;
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const TileGeom& g, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16], int wave,
+                                                     int lane, int n0, const f32x4 (&bq)[BN / WAVES_N / 16], float alpha) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lp = lane & 15, lg = lane >> 4;
+    float* const y = reinterpret_cast<float*>(p.y);
+    const float* const res = reinterpret_cast<const float*>(p.res);
+    const bool want_stats = p.stats != nullptr;
+    const int c0 = n0 + wn * WN + 4 * lg;
+    // channel tile by channel tile (16 channels: this lane's quad c0 + 16 j .. + 3 of the TM pixels 16 i + lp), so that only ONE tile's
+    // statistics accumulators and two tiles' residuals are live next to the accumulators (all TN at once: 76 spilled registers)
+    long long off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int nrel, ho, wo;
+        decode_row<BM>(p, g, wm * WM + i * 16 + lp, nrel, ho, wo);  // patch mode: every row of the tile exists
+        off[i] = (((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo) * p.Cout;
+    }
+    const int slot = ((p.tw_log2 >= 0) ? (g.tile_m - g.n_first * p.tiles_per_image) : (g.rem_first / BM)) * WAVES_M + wm;
+    // pre-split output (the qkv conv in front of the fused attention): [8 x fp16 hi | 8 x fp16 lo] per 8 channels of s_n * y; the lanes
+    // lg (even: channels 0-3 of the group) and lg + 1 (4-7) exchange halves: the even lane stores the 16 hi bytes, the odd one the lo bytes
+    float ps_scale = 0.0f;
+    if (p.y_ps_bound) ps_scale = ab_scale_of(ab_wave_bound(p.y_ps_bound, g.n_first), EOD_AB_KMIN_ATTN).s;
+    f32x4 rv[2][TM];
+    if (res && c0 < p.Ncols) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rv[0][i] = *reinterpret_cast<const f32x4*>(res + off[i] + c0);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + j * 16;
+        if (res && j + 1 < TN && c + 16 < p.Ncols) {  // the next tile's residual is in flight while this tile is stored
+#pragma unroll
+            for (int i = 0; i < TM; ++i) rv[(j + 1) & 1][i] = *reinterpret_cast<const f32x4*>(res + off[i] + c + 16);
+        }
+        if (c < p.Ncols) {
+            f32x4 ss = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x4 v = acc[i][j] * alpha + bq[j];
+                if (res) v += rv[j & 1][i];
+                if (ps_scale != 0.0f) {
+                    typedef int i32x2 __attribute__((ext_vector_type(2)));
+                    half4 h4, l4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sv = v[e] * ps_scale;
+                        const half_t hi = (half_t)sv;
+                        h4[e] = hi;
+                        l4[e] = (half_t)(sv - (float)hi);
+                    }
+                    const i32x2 hb = __builtin_bit_cast(i32x2, h4), lb = __builtin_bit_cast(i32x2, l4);
+                    const bool odd = (lg & 1) != 0;
+                    const int s0 = odd ? hb[0] : lb[0], s1 = odd ? hb[1] : lb[1];   // what the partner needs: my hi (I am odd) / my lo (even)
+                    const int r0 = __shfl_xor(s0, 16), r1 = __shfl_xor(s1, 16);
+                    const i32x4 w = odd ? i32x4{r0, r1, lb[0], lb[1]} : i32x4{hb[0], hb[1], r0, r1};
+                    *reinterpret_cast<i32x4*>(y + off[i] + (c & ~7) + (odd ? 4 : 0)) = w;
+                } else {
+                    *reinterpret_cast<f32x4*>(y + off[i] + c) = v;
+                }
+                ss += v;
+                sq += v * v;
+            }
+            if (want_stats) {
+                // per-channel sums over the wave's WM pixels: the TM pixel tiles in-lane (above), then the 16 lanes that share lg
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int o = 8; o >= 1; o >>= 1) {
+                        ss[r] += __shfl_xor(ss[r], o);
+                        sq[r] += __shfl_xor(sq[r], o);
+                    }
+                }
+                if (lp == 0) {
+                    float* dst = p.stats + (((long long)g.n_first * p.stats_P + slot) * p.Cout + c) * 2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dst[2 * r] = ss[r];
+                        dst[2 * r + 1] = sq[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32, bool DIRECT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const IgemmP p) {
+    static_assert(!DIRECT || (CONV && SPLIT && MS == 16 && sizeof(T) == 4 && BN >= 64), "direct epilogue: fp32-storage split conv instances");
+
     static_assert(!SPLIT || (sizeof(T) == 4 && STAGES == 2 && MS == 16), "split-fp16 product: fp32 storage, 2-stage ring, 16x16x32 MFMAs");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only (see conv3x3_halo_kernel)");
     constexpr int ES = sizeof(T);
@@ -559,6 +669,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     if constexpr (CONV) {
         if (p.splitk > 1) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;
     }
+    // direct-epilogue instances: the per-column epilogue terms are fetched at entry (their latency passes under the first DMA round
+    // trip instead of standing between the last MFMA and the first store)
+    constexpr int TNQ = DIRECT ? BN / WAVES_N / 16 : 1;
+    f32x4 pre_bq[TNQ];
+    if constexpr (DIRECT) prefetch_bcol4<TNQ>(p, p.Ncols, n0 + (wave % WAVES_N) * (BN / WAVES_N), threadIdx.x & 63, g.n_first, pre_bq);
     // split-fp16 product: operand scales of the activation operand(s) from their bound tables (common.h).  conv: one scale per image;
     // a tile normally lies inside one image (always in patch mode) -> wave-uniform as0; a tile that straddles images (maps smaller
     // than or not a multiple of the 128-row tile) keeps a table of its images' scales in LDS: rows are scaled and un-scaled one by one.
@@ -865,19 +980,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, al[i]), acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, al[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bl[j] = *reinterpret_cast<const i32x4*>(sb + b_rd + j * MS * BKB + olo);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bl[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bl[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, bh[j]), __builtin_bit_cast(half8, ah[i]), acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, ah[i]), __builtin_bit_cast(half8, bh[j]), acc[i][j], 0, 0, 0);
             continue;
         } else if constexpr (MS == 16) {
             // fp16: two 16x16x32 sub-steps per K-step, lane quarter lh of sub-step s reads chunk 4 s + lh
@@ -927,7 +1045,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my fragment reads are done ...
     __builtin_amdgcn_s_barrier();        // ... and so are everybody else's: the ring can be reused by the epilogue
 
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (DIRECT) {
+        // one image per tile, no split-K, NHWC output (the launcher checked): stores straight from the (transposed) accumulators
+        halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, g, acc, wave, lane, n0, pre_bq, pe.alpha);
+    } else if constexpr (sizeof(T) == 4) {
         igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, rowtab, rowtab_n);
     } else {
         if (CONV ? p.splitk > 1 : p.c_f32 != 0)
@@ -977,92 +1098,6 @@ __device__ __forceinline__ void prefetch_bcol(const IgemmP& p, int ncols, int co
         float v = (ok && p.bias && p.bias_mode == 1) ? p.bias[col] : 0.0f;
         if (ok && p.cbias) v += p.cbias[(long long)n_first * p.cbias_stride + col];
         out[j] = v;
-    }
-}
-
-// ---- direct epilogue of the fp32-storage patch-mode kernels (conv3x3_halo_kernel<SPLIT>) ----------------------------------------
-// The split product's MFMAs are issued with their operands SWAPPED (D = W X^T instead of X W^T; both operands of a 16x16x32 MFMA have
-// the same register layout, so the swap is free): a lane then holds FOUR CONSECUTIVE CHANNELS of ONE pixel per accumulator tile
-// (channel = 16 j + 4 (lane >> 4) + r, pixel = 16 i + (lane & 15)), i.e. a 16-byte piece of an NHWC row.  The epilogue stores straight
-// from the accumulators: no LDS transpose (2.8 us of VALU per workgroup on the transposed path, tools/debug/halo_stamps.py), no LDS at
-// all -- the operand ring is free while it runs.  Per-channel terms (bias + per-sample bias) come as 4 x TN values fetched at entry.
-template <int TN>
-__device__ __forceinline__ void prefetch_bcol4(const IgemmP& p, int ncols, int col0, int lane, int n_first, f32x4 (&out)[TN]) {
-    const int lg = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int c = col0 + j * 16 + 4 * lg;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c < ncols) {  // (Cout is a multiple of the 16-byte chunk: a quad is inside or outside as a whole)
-            if (p.bias && p.bias_mode == 1) v = *reinterpret_cast<const f32x4*>(p.bias + c);
-            if (p.cbias) v += *reinterpret_cast<const f32x4*>(p.cbias + (long long)n_first * p.cbias_stride + c);
-        }
-        out[j] = v;
-    }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const TileGeom& g, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16], int wave,
-                                                     int lane, int n0, const f32x4 (&bq)[BN / WAVES_N / 16], float alpha) {
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int lp = lane & 15, lg = lane >> 4;
-    float* const y = reinterpret_cast<float*>(p.y);
-    const float* const res = reinterpret_cast<const float*>(p.res);
-    const bool want_stats = p.stats != nullptr;
-    const int c0 = n0 + wn * WN + 4 * lg;
-    // channel tile by channel tile (16 channels: this lane's quad c0 + 16 j .. + 3 of the TM pixels 16 i + lp), so that only ONE tile's
-    // statistics accumulators and two tiles' residuals are live next to the accumulators (all TN at once: 76 spilled registers)
-    long long off[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int nrel, ho, wo;
-        decode_row<BM>(p, g, wm * WM + i * 16 + lp, nrel, ho, wo);  // patch mode: every row of the tile exists
-        off[i] = (((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo) * p.Cout;
-    }
-    const int slot = (g.tile_m - g.n_first * p.tiles_per_image) * WAVES_M + wm;
-    f32x4 rv[2][TM];
-    if (res && c0 < p.Ncols) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) rv[0][i] = *reinterpret_cast<const f32x4*>(res + off[i] + c0);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int c = c0 + j * 16;
-        if (res && j + 1 < TN && c + 16 < p.Ncols) {  // the next tile's residual is in flight while this tile is stored
-#pragma unroll
-            for (int i = 0; i < TM; ++i) rv[(j + 1) & 1][i] = *reinterpret_cast<const f32x4*>(res + off[i] + c + 16);
-        }
-        if (c < p.Ncols) {
-            f32x4 ss = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                f32x4 v = acc[i][j] * alpha + bq[j];
-                if (res) v += rv[j & 1][i];
-                *reinterpret_cast<f32x4*>(y + off[i] + c) = v;
-                ss += v;
-                sq += v * v;
-            }
-            if (want_stats) {
-                // per-channel sums over the wave's WM pixels: the TM pixel tiles in-lane (above), then the 16 lanes that share lg
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int o = 8; o >= 1; o >>= 1) {
-                        ss[r] += __shfl_xor(ss[r], o);
-                        sq[r] += __shfl_xor(sq[r], o);
-                    }
-                }
-                if (lp == 0) {
-                    float* dst = p.stats + (((long long)g.n_first * p.stats_P + slot) * p.Cout + c) * 2;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dst[2 * r] = ss[r];
-                        dst[2 * r + 1] = sq[r];
-                    }
-                }
-            }
-        }
     }
 }
 
@@ -2281,7 +2316,7 @@ extern "C" int eod_get_option(const char* name) {
     return EOD_EINVAL;
 }
 
-template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32>
+template <typename T, bool CONV, int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool SPLIT = false, int MS = 32, bool DIRECT = false>
 static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, NW = WAVES_M * WAVES_N;
@@ -2293,7 +2328,7 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
         p.ab_tab_off = (int)lds;
         lds += (BM + 2) * 2 * sizeof(float);
     }
-    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES, SPLIT, MS>;
+    auto kern = igemm_kernel<T, CONV, BM, BN, WAVES_M, WAVES_N, STAGES, SPLIT, MS, DIRECT>;
     static bool attr_done = false;  // >64 KiB dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2394,9 +2429,14 @@ static int launch_conv_split(IgemmP& p, int batch, hipStream_t st) {
     if (p.Ncols <= 64) return launch_cfg<float, true, 128, 64, 4, 1, 2, true, 16>(p, batch, st);
     // 256 columns per 8-wave workgroup: the pixel rows of a K-step are fetched and split once for two N-tiles (these launches are
     // bound by that in-place split: four pieces per wave against 48 MFMAs) -- the qkv / proj 1x1 convs of the attention blocks
+    // whole tiles inside one image, no split-K, NHWC output: the instances with swapped MFMA operands and the direct epilogue
+    // (halo_epilogue_direct: no LDS transpose; fp32 or pre-split output)
+    const bool direct = p.splitk <= 1 && !p.out_nchw && p.HWd % 128 == 0 && p.M % 128 == 0 && !p.par && p.Ncols % 4 == 0;
     if (p.Ncols % 256 == 0 && batch == 1 && ((p.M + 127) / 128) * (p.Ncols / 256) >= 256 && opt(OPT_HALO_BN256))
-        return launch_cfg<float, true, 128, 256, 2, 4, 2, true, 16>(p, batch, st);
-    return launch_cfg<float, true, 128, 128, 2, 2, 2, true, 16>(p, batch, st);
+        return direct ? launch_cfg<float, true, 128, 256, 2, 4, 2, true, 16, true>(p, batch, st)
+                      : launch_cfg<float, true, 128, 256, 2, 4, 2, true, 16>(p, batch, st);
+    return direct ? launch_cfg<float, true, 128, 128, 2, 2, 2, true, 16, true>(p, batch, st)
+                  : launch_cfg<float, true, 128, 128, 2, 2, 2, true, 16>(p, batch, st);
 }
 
 // row length (elements) of tap-major packed weights: 9*C0 rounded up to whole 128-byte K-steps
