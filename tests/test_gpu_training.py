@@ -576,3 +576,19 @@ def test_training_loop_vs_reference_run(variant):
     print(f"training loop [{variant}]: worst relative loss difference {worst:.2e}; trained model on the probe {e_m:.2e}, EMA copy {e_e:.2e}")
     tol_loss, tol_probe = (1e-5, 2e-5) if prec == "fp32" else (2e-3, 1e-2)   # measured: 2.6e-7 / 1.1e-6 and 9.6e-5 / 1.7e-3
     assert worst < tol_loss and e_m < tol_probe and e_e < tol_probe
+
+
+@pytest.mark.parametrize("prec,heads", [("fp16", 8), ("fp32", 16)])
+def test_training_refuses_unaligned_head_dims_loudly(prec, heads):
+    """the training path needs head rows of whole 16-byte chunks (fp16: d % 8 == 0, fp32: d % 4 == 0); 96 channels in 8 / 16 heads
+    (d = 12 / 6) is refused with an error that names the head dim -- never a silent wrong gradient.  (Inference takes any head dim.)"""
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from eo_diffusion_amd._lib import EodError
+    m = U.UNetModel(16, in_channels=3, model_channels=96, out_channels=3, num_res_blocks=1, attention_resolutions=[1], channel_mult=(1,),
+                    num_heads=heads).set_precision(prec).to(DEV).train()
+    x = synth_input("uhx", (1, 3, 16, 16), 3).to(DEV)
+    with pytest.raises(EodError, match="head dim"):
+        m(x, torch.tensor([5]).to(DEV)).sum().backward()
+    m.eval()
+    with torch.no_grad():
+        assert torch.isfinite(m(x, torch.tensor([5]).to(DEV))).all()
