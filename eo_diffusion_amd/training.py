@@ -75,6 +75,47 @@ class _AttnRec:
         self.lay = lay  # (q offset, k offset, v offset, head stride) in channels of the 3C-wide qkv tensor
 
 
+class _VirtConv:
+    """A 1x1 conv whose weight / bias are re-indexed copies of a real conv's: `weight` [Co'][Ci'][1][1] and `bias` [Co'] are fp32 tensors
+    owned here, rows / columns of the real parameters scattered to `rows` / `cols` (everything else zero), rows scaled by `rscale`.
+    Re-formed from the live parameters before every forward (UNetTrainer.virt); its gradients land in buffers of the same shape and are
+    gathered back into the real parameters' gradients right after the conv's backward launches (`gather`).  Used by attention blocks
+    whose head rows are not whole 16-byte chunks: every head is zero-padded to one (UNetTrainer._attention)."""
+
+    def __init__(self, real, cout, cin, rows=None, cols=None, rscale=None, own_bias=True):
+        dev = real.weight.device
+        self.real, self.out_channels = real, cout
+        self.rows, self.cols, self.rscale = rows, cols, rscale
+        self.weight = torch.zeros((cout, cin, 1, 1), dtype=torch.float32, device=dev)
+        self.bias = torch.zeros((cout,), dtype=torch.float32, device=dev) if own_bias else real.bias
+        self.gw = torch.zeros_like(self.weight)
+        self.gb = torch.zeros_like(self.bias) if own_bias else None
+
+    def refresh(self):
+        w = self.real.weight.detach().reshape(self.real.weight.shape[0], -1).float()
+        b = self.real.bias.detach().float()
+        if self.rscale is not None:
+            w, b = w * self.rscale[:, None], b * self.rscale
+        wp = self.weight.view(self.weight.shape[0], self.weight.shape[1])
+        if self.rows is not None:
+            wp.index_copy_(0, self.rows, w)
+            self.bias.index_copy_(0, self.rows, b)
+        else:
+            wp.index_copy_(1, self.cols, w)
+
+    def gather(self, dW, db):
+        """padded gradients -> the real parameters' fp32 gradient views"""
+        g = self.gw.view(self.gw.shape[0], self.gw.shape[1])
+        if self.rows is not None:
+            gw, gb = g.index_select(0, self.rows), self.gb.index_select(0, self.rows)
+            if self.rscale is not None:
+                gw, gb = gw * self.rscale[:, None], gb * self.rscale
+            dW.view(gw.shape).copy_(gw)
+            db.copy_(gb)
+        else:
+            dW.view(dW.shape[0], -1).copy_(g.index_select(1, self.cols))
+
+
 class UNetTrainer:
     """Forward + backward of one UNetModel for a fixed input shape.  Usage:
         tr = UNetTrainer(unet, N, H, W, device, loss_scale=1024.)
@@ -103,6 +144,8 @@ class UNetTrainer:
         self.repack = []     # closures refreshing derived tensors from the (updated) parameters (timestep-MLP concatenations)
         self.pack_jobs = []  # weight re-packs (forward and backward-data layouts of every conv): ONE launch per forward
         self.up4_sums = []   # (conv, fp32 class-kernel tensor) of the parity-class upsample convs: re-formed before the re-packs
+        self.virt = []       # _VirtConv objects: re-formed from the live parameters before the re-packs
+        self.vgrad = {}      # their weight / bias tensors -> fp32 gradient buffers
         self.recs = []
         self._keep = []
         self._scratch, self._scratch_all = {}, []
@@ -136,6 +179,8 @@ class UNetTrainer:
     def _param_grad(self, p):
         """fp32 gradient of `p`: a view into ONE flat buffer (`flat_grad`), so that data-parallel training reduces all
         gradients with a single RCCL all-reduce (allreduce_grads) and a fused optimizer can walk them in one launch"""
+        if p in self.vgrad:  # weight / bias of a _VirtConv: a buffer of its own, gathered into the real gradient afterwards
+            return self.vgrad[p]
         if p not in self.pgrad:
             off = self._grad_offsets[p]
             self.pgrad[p] = self.flat_grad[off:off + p.numel()].view(p.shape)
@@ -169,7 +214,7 @@ class UNetTrainer:
         bounds = list(zip(cuts[:-1], cuts[1:]))
         ready = [-1] * len(bounds)
         for i, item in enumerate(self.bwd):
-            if item[0] != "call":
+            if item[0] != "call" and not (item[0] == "dyn" and len(item) > 2):  # (a "dyn" item may name the pointers it writes)
                 continue
             for a in item[2]:
                 if isinstance(a, int) and base <= a < base + total * 4:
@@ -389,16 +434,39 @@ class UNetTrainer:
         prog = self.prog
         if isinstance(x, tuple):
             raise EodError("training: AttentionBlock over a virtual concat is not supported")
-        Cc, nh = blk.channels, blk.num_heads
-        d = Cc // nh
+        C0, nh = blk.channels, blk.num_heads
+        d0 = C0 // nh
         N, T = x.N, x.H * x.W
-        if d % prog.epc:
-            raise EodError(f"training: attention needs the head dim {d} to be a multiple of {prog.epc}")
+        qkv_conv, proj_conv, d = blk.qkv, blk.proj_out, d0
+        if d0 % prog.epc:
+            # head rows that are not whole 16-byte chunks (96 channels in 8 heads: d = 12): every head is zero-padded to d' = the next
+            # multiple of one chunk.  qkv / proj_out run as _VirtConv copies whose extra rows / columns are zero -- the pad channels of
+            # q, k, v, a and of every gradient are exact zeros, so they drop out of each contraction -- and the q rows carry
+            # sqrt(d' / d): the kernels below scale the scores by 1 / sqrt(d'), which then is the reference's 1 / sqrt(d)
+            # (unet_openai.py:475-478, 507-512).  The gradients of the padded copies are gathered back into the real parameters'.
+            d = round_up(d0, prog.epc)
+            new = blk.attention.new_order
+            ridx = [(w * nh * d + h * d + j) if new else (h * 3 * d + w * d + j)
+                    for r in range(3 * C0)
+                    for (w, h, j) in [((r // C0, (r % C0) // d0, r % d0) if new else ((r % (3 * d0)) // d0, r // (3 * d0), r % d0))]]
+            rsc = [math.sqrt(d / d0) if ((r // C0) if new else ((r % (3 * d0)) // d0)) == 0 else 1.0 for r in range(3 * C0)]
+            cidx = [(c // d0) * d + c % d0 for c in range(C0)]
+            dev = self.device
+            qkv_conv = _VirtConv(blk.qkv, 3 * nh * d, C0, rows=torch.tensor(ridx, device=dev),
+                                 rscale=torch.tensor(rsc, dtype=torch.float32, device=dev))
+            proj_conv = _VirtConv(blk.proj_out, C0, nh * d, cols=torch.tensor(cidx, device=dev), own_bias=False)
+            for vc in (qkv_conv, proj_conv):
+                vc.refresh()
+                self.virt.append(vc)
+                self.vgrad[vc.weight] = vc.gw
+                if vc.gb is not None:
+                    self.vgrad[vc.bias] = vc.gb
+        Cc = nh * d
         Tp = round_up(T, prog.epc)
         # channel layout of qkv: legacy [h][q|k|v][d] (unet_openai.py:474), new order [q|k|v][h][d] (:506-514)
         qo, ko, vo, hs = (0, Cc, 2 * Cc, d) if blk.attention.new_order else (0, d, 2 * d, 3 * d)
         xn = self._gn_fwd([x], blk.norm, silu=False)
-        qkv = self._conv_fwd([xn], blk.qkv, ksize=1, stats=False)          # [N][T][3C]
+        qkv = self._conv_fwd([xn], qkv_conv, ksize=1, stats=False)          # [N][T][3C]
         BK = 128 // self.es
         ldT = round_up(N * Tp, BK)
         qkvT = prog.empty((3 * Cc * ldT,), zero=True)                        # [3C][n*Tp + t]
@@ -411,7 +479,7 @@ class UNetTrainer:
             a = prog.act(N, x.H, x.W, Cc)
             prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d, qo, ko, vo, hs, lse=lse)
             self.recs.append(_AttnRec(qkv, qkvT, ldT, None, a, nh, d, (qo, ko, vo, hs), lse))
-            return self._conv_fwd([a], blk.proj_out, ksize=1, res=x, stats=True)
+            return self._conv_fwd([a], proj_conv, ksize=1, res=x, stats=True)
         S = self._shared("attn_S", N * nh * T * Tp, torch.float32)  # only P is kept for the backward
         prog.gemm(qkv.t, qkv.t, S, T, T, d, 3 * Cc, 3 * Cc, Tp, alpha=1.0 / math.sqrt(d), c_f32=True, nb0=N, nb1=nh,
                   sa=(T * 3 * Cc, hs), sb=(T * 3 * Cc, hs), sc=(nh * T * Tp, T * Tp), a_off=qo, b_off=ko)
@@ -422,7 +490,7 @@ class UNetTrainer:
         prog.gemm(P, qkvT, a.t, T, d, Tp, Tp, ldT, Cc, nb0=N, nb1=nh, sa=(nh * T * Tp, T * Tp), sb=(Tp, hs * ldT),
                   sc=(T * Cc, d), b_off=vo * ldT)
         self.recs.append(_AttnRec(qkv, qkvT, ldT, P, a, nh, d, (qo, ko, vo, hs)))
-        return self._conv_fwd([a], blk.proj_out, ksize=1, res=x, stats=True)
+        return self._conv_fwd([a], proj_conv, ksize=1, res=x, stats=True)
 
     def _attn_bwd(self, rec):
         L, bp, dt, es = self.L, self.bprog, self.dt, self.es
@@ -751,6 +819,9 @@ class UNetTrainer:
             self._emb_layer_wgrad(off, rec.emb[3])
         if not direct:
             self._wgrad(rec, dy, dYt, ld, Kper, S, rp, cout, shift_dy, Wp)
+        if isinstance(conv, _VirtConv):  # padded copies of an attention block's projections: gradients back to the real parameters
+            dWr, dbr = self._param_grad(conv.real.weight), self._param_grad(conv.real.bias)
+            self.bwd.append(("dyn", lambda st, c=conv, a=dWr, b=dbr: c.gather(a, b), (dWr.data_ptr(), dbr.data_ptr())))
         if rec.res is not None:
             self._add_grad(rec.res, dy)
         if not rec.src_needs_grad:
@@ -884,6 +955,8 @@ class UNetTrainer:
         for conv, wc in self.up4_sums:  # class kernels of the parity-class upsample convs from the live weights
             w = conv.weight.detach()
             check(self.L.eod_conv_up4_weights(ptr(w), ptr(wc), w.shape[0], w.shape[1], current_stream_ptr(self.device)), "eod_conv_up4_weights")
+        for vc in self.virt:
+            vc.refresh()
         self._run_pack_jobs()
         for fn in self.repack:
             fn()

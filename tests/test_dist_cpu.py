@@ -11,6 +11,33 @@ import torch.multiprocessing as mp
 from eo_diffusion_amd.dist import gather_samples, shard_bounds
 
 
+def _free_port():
+    """a port nobody listens on right now (a pid-derived number can collide with another process of the machine: the rendezvous
+    then waits for its full timeout)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run_ranks(target, args_of_rank, q, world=2):
+    """start `world` daemon ranks, collect one queue item per rank, never leave a rank behind (a failed rendezvous must not outlive the test)"""
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=target, args=args_of_rank(r), daemon=True) for r in range(world)]
+    try:
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return res
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+
+
 def test_shard_bounds_cover_and_disjoint():
     for n in (0, 1, 7, 16, 128, 129):
         for w in (1, 2, 3, 8):
@@ -41,16 +68,9 @@ def _worker(rank, world, port, n_total, q):
 @pytest.mark.parametrize("n_total", [4, 5])
 def test_gloo_world2_gather_matches_single_rank(n_total):
     from oracle.philox_ref import philox_randn
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_total
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    q = mp.get_context("spawn").Queue()
+    port = _free_port()
+    res = _run_ranks(_worker, lambda r: (r, 2, port, n_total, q), q)
     ref = philox_randn(n_total, 48, 11, 0, 5, 1).reshape(n_total, 3, 4, 4)  # what ONE rank would have produced
     for r in range(2):
         assert np.array_equal(res[r], ref)
@@ -70,16 +90,9 @@ def _grad_worker(rank, world, port, q):
 
 def test_gloo_world2_gradient_bucket_is_averaged():
     """data-parallel training (config 5): every rank ends with the MEAN of the ranks' flat gradient buckets"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    q = mp.get_context("spawn").Queue()
+    port = _free_port()
+    res = _run_ranks(_grad_worker, lambda r: (r, 2, port, q), q)
     ref = np.arange(1000, dtype=np.float32) * 1.5
     for r in range(2):
         assert np.array_equal(res[r], ref)
