@@ -62,7 +62,7 @@ def _random_cfg(i):
         if any((mc * m) % cfg["num_head_channels"] for m in mult):
             cfg["num_head_channels"] = 32 if mc % 32 == 0 else 16
     else:
-        cfg["num_heads"] = int(r.choice([1, 2, 4]))
+        cfg["num_heads"] = int(r.choice([1, 2, 4, 8]))   # (8 heads: head dims 4, 12, 20, ... -- not whole 16-byte chunks)
         if r.rand() < 0.3:
             cfg["num_heads_upsample"] = int(r.choice([1, 2]))
     if r.rand() < 0.25:
