@@ -100,7 +100,9 @@ class DDIMSampler(object):
         total_steps = timesteps.shape[0]
         it = tqdm(time_range, desc="DDIM Sampler", total=total_steps) if progress else time_range
         if mask is not None:
-            mask = mask.to(device).float().contiguous()
+            mask = self.model._broadcast_mask(mask, img)
+        if x0 is not None:
+            x0 = torch.as_tensor(x0).to(device).float().contiguous()  # (the mix noise below is then drawn on the device, too)
         for i, step in enumerate(it):
             index = total_steps - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
@@ -108,10 +110,7 @@ class DDIMSampler(object):
                 assert x0 is not None
                 # RePaint mix (ddim.py:145-148); the q_sample noise is drawn here (upstream intent)
                 nz = mix_noises[i].to(device) if mix_noises is not None else torch.randn_like(x0)
-                if mask.shape[1] == 1 and tuple(mask.shape[2:]) == tuple(img.shape[2:]) and mask.shape[0] == b:
-                    img = self.model._repaint_mix(img, x0.to(device), mask, ts, nz)
-                else:
-                    raise _lib.EodError(f"DDIM mask must be [N,1,H,W], got {tuple(mask.shape)}")
+                img = self.model._repaint_mix(img, x0, mask, ts, nz)
             img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, quantize_denoised=quantize_denoised,
                                               temperature=temperature, noise_dropout=noise_dropout,
                                               score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,

@@ -101,13 +101,33 @@ class EODiffusion(nn.Module):
         """x_t <- mask*q_sample(gt,t,noise) + (1-mask)*x_t  (model.py:58-60), one fused pass."""
         n, c, h, w = x_t.shape
         x, g, m, z = _f32c(x_t), _f32c(gt), _f32c(mask), _f32c(noise)
-        assert g.shape == x.shape and m.shape == (n, 1, h, w), (g.shape, m.shape)
+        assert g.shape == x.shape and m.shape in ((n, 1, h, w), (n, c, h, w)), (g.shape, m.shape)
         out = torch.empty_like(x)
+        if m.shape[1] != 1:  # a mask per channel: every (sample, channel) plane is a one-channel sample of the same kernel
+            t = t.repeat_interleave(c)
+            n, c = n * c, 1
         _lib.check(_lib.lib().eod_repaint_mix(x.data_ptr(), g.data_ptr(), m.data_ptr(), z.data_ptr(), t.data_ptr(),
                                               self.sqrt_alphas_cumprod.data_ptr(),
                                               self.sqrt_one_minus_alphas_cumprod.data_ptr(), out.data_ptr(), n, c,
                                               h * w, self.timesteps, current_stream_ptr(x.device)), "eod_repaint_mix")
         return out
+
+    @staticmethod
+    def _broadcast_mask(mask, like):
+        """`mask` as the reference's `img_orig * mask + (1. - mask) * img` (ddim.py:147-148) would broadcast it against `like` [N,C,H,W]:
+        anything broadcastable -- [H,W], [1,1,H,W], [N,1,H,W], [N,C,H,W] ... -- becomes [N,1,H,W] (one plane per sample) or, when it
+        differs between channels, [N,C,H,W]"""
+        n, c, h, w = like.shape
+        m = torch.as_tensor(mask, device=like.device).float()
+        try:
+            shape = torch.broadcast_shapes(tuple(m.shape), (n, c, h, w))
+        except RuntimeError:
+            shape = None
+        if shape != (n, c, h, w):
+            raise _lib.EodError(f"mask of shape {tuple(m.shape)} does not broadcast against {(n, c, h, w)}")
+        while m.dim() < 4:
+            m = m[None]
+        return m.expand(n, m.shape[1], h, w).contiguous()
 
     def _ddpm_update(self, x_t, pred, noise, t, clip):
         x, e, z = _f32c(x_t), _f32c(pred), _f32c(noise)

@@ -88,6 +88,50 @@ def test_repaint_mix_bit_exact():
     assert bits_equal(out, SR.repaint_mix(tb, x, g0, mask, t, nz))
 
 
+def test_repaint_mix_with_a_mask_per_channel_bit_exact():
+    """`img_orig * mask + (1. - mask) * img` (ddim.py:147-148) broadcasts: a mask that differs between channels is legal upstream"""
+    tb = SCH.eo_cosine_tables(1000)
+    m = _with_tables(_model(1000, size=16, cond_type="sum"), tb)
+    x = synth_input("rx", (3, 3, 16, 16), 22)
+    g0 = synth_input("rg", (3, 3, 16, 16), 22, uniform=True)
+    nz = synth_input("rn", (3, 3, 16, 16), 22)
+    mask = (synth_input("rm", (3, 3, 16, 16), 23) > 0.3).float()
+    t = torch.tensor([0, 400, 999])
+    out = m._repaint_mix(x.to(DEV), g0.to(DEV), mask.to(DEV), t.to(DEV), nz.to(DEV)).cpu()
+    assert bits_equal(out, SR.repaint_mix(tb, x, g0, mask, t, nz))
+
+
+def test_ddim_mask_shapes_broadcast_like_the_reference():
+    """DDIMSampler.ddim_sampling takes every mask the reference's broadcast takes -- [H,W] (also a numpy array: make_label's output),
+    [1,1,H,W], [N,1,H,W], [N,C,H,W] -- with bit-identical results where they describe the same mask; a shape that does not broadcast is
+    an EodError naming it"""
+    from eo_diffusion_amd._lib import EodError
+    from eo_diffusion_amd.diffusion.ddim import DDIMSampler
+    from tests.synth import rect_mask
+    m = _model(1000, size=16)
+    m.model.pred = synth_input("dp", (2, 3, 16, 16), 5).to(DEV)
+    s = DDIMSampler(m)
+    s.make_schedule(ddim_num_steps=5, ddim_eta=0.5, verbose=False)
+    xT, x0 = synth_input("dx", (2, 3, 16, 16), 6), synth_input("d0", (2, 3, 16, 16), 7, uniform=True)
+    sn = [synth_input(f"ds{i}", (2, 3, 16, 16), 8 + i) for i in range(5)]
+    mn = [synth_input(f"dm{i}", (2, 3, 16, 16), 18 + i) for i in range(5)]
+    one = rect_mask(1, 16, 16, 3)  # [1,1,16,16]
+
+    def run(mask, x0_=x0):
+        out, _ = s.ddim_sampling(None, (2, 3, 16, 16), x_T=xT, mask=mask, x0=x0_, step_noises=sn, mix_noises=mn, progress=False)
+        return out.cpu()
+
+    ref = run(one.expand(2, 1, 16, 16).contiguous())
+    for mk in (one, one[0, 0], one[0, 0].numpy(), one[0], one.expand(2, 3, 16, 16), one.to(DEV)):
+        assert bits_equal(run(mk), ref)
+    assert bits_equal(run(one, x0.numpy()), ref)  # (x0 from the host: moved once, the mix noise is drawn on the device)
+    assert not bits_equal(run(1.0 - one), ref)
+    with pytest.raises(EodError, match="broadcast"):
+        run(torch.ones(2, 1, 8, 8))
+    with pytest.raises(EodError, match="broadcast"):
+        run(torch.ones(3, 1, 16, 16))
+
+
 @pytest.mark.parametrize("eta", [0.0, 0.7])
 def test_ddim_steps_vs_golden(eta):
     from eo_diffusion_amd.diffusion.ddim import DDIMSampler
