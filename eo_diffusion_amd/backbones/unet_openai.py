@@ -127,6 +127,31 @@ def checkpoint(func, inputs, params, flag):
     return func(*inputs)
 
 
+class CheckpointFunction(th.autograd.Function):
+    """Name kept for scripts that import it (unet_openai.py:120-148).  The reference re-runs `run_function` in its backward to save
+    activation memory; here the training step keeps what its own backward needs and the flash backward recomputes P (training.py), so
+    this node only evaluates the function -- under autograd, UNetModel.forward goes through training._UNetTrainFn instead."""
+
+    @staticmethod
+    def forward(ctx, run_function, length, *args):
+        with th.no_grad():
+            return run_function(*args[:length])
+
+    @staticmethod
+    def backward(ctx, *output_grads):
+        raise NotImplementedError("CheckpointFunction: gradients of the HIP path come from UNetModel's own training step (training.py)")
+
+
+def count_flops_attn(model, _x, y):
+    """`thop` hook (unet_openai.py:436-455): the two batched matmuls of an attention op on an output of shape [b, c, *spatial] cost
+    b * T^2 * c multiply-adds each, T = prod(spatial); used as thop.profile(..., custom_ops={QKVAttention: QKVAttention.count_flops})"""
+    b, c, *spatial = y[0].shape
+    T = 1
+    for d in spatial:
+        T *= int(d)
+    model.total_ops += th.DoubleTensor([2 * b * T * T * c])
+
+
 # ------------------------------------------------------------------------------------------------
 # standalone execution helper: NCHW fp32 in -> program -> NCHW fp32 out
 # ------------------------------------------------------------------------------------------------
@@ -414,6 +439,10 @@ class QKVAttentionLegacy(nn.Module):
     def forward(self, qkv):
         return _qkv_attention_standalone(self, qkv)
 
+    @staticmethod
+    def count_flops(model, _x, y):
+        return count_flops_attn(model, _x, y)
+
 
 class QKVAttention(nn.Module):
     """qkv layout [q|k|v][h][d] (unet_openai.py:488-515)."""
@@ -425,6 +454,28 @@ class QKVAttention(nn.Module):
 
     def forward(self, qkv):
         return _qkv_attention_standalone(self, qkv)
+
+    @staticmethod
+    def count_flops(model, _x, y):
+        return count_flops_attn(model, _x, y)
+
+
+class AttentionPool2d(nn.Module):
+    """CLIP-style attention pooling (unet_openai.py:151-181): defined upstream, instantiated by nothing on the EODiffusion path (only
+    backbones/unet.py's EncoderUNetModel uses its twin).  Kept as a parameter container with the reference's constructor and state_dict
+    keys (`positional_embedding`, `qkv_proj.*`, `c_proj.*`) so that the name imports and checkpoints holding one load; calling it
+    raises -- there is no HIP path for dead code."""
+
+    def __init__(self, spacial_dim: int, embed_dim: int, num_heads_channels: int, output_dim: int = None):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(th.randn(embed_dim, spacial_dim ** 2 + 1) / embed_dim ** 0.5)
+        self.qkv_proj = conv_nd(1, embed_dim, 3 * embed_dim, 1)
+        self.c_proj = conv_nd(1, embed_dim, output_dim or embed_dim, 1)
+        self.num_heads = embed_dim // num_heads_channels
+        self.attention = QKVAttention(self.num_heads)
+
+    def forward(self, x):
+        raise NotImplementedError("AttentionPool2d is not on the EODiffusion path (SURVEY.md section 8: out of scope); no HIP kernel path exists for it")
 
 
 class AttentionBlock(_Emitter):

@@ -65,3 +65,71 @@ def noise_like(shape, device, repeat=False):
     if repeat:
         return torch.randn((1, *shape[1:]), device=device).repeat(shape[0], *((1,) * (len(shape) - 1)))
     return torch.randn(shape, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# The rest of the reference's diffusion/util.py: latent-diffusion helpers nothing on the EODiffusion path calls (util.py:20-36, 94-279).
+# They are here so that `from diffusion.util import X` keeps working for every X the reference defines: the layer helpers are the ones
+# of backbones/unet_openai.py (same classes: parameter containers of the HIP path), the others small host-side functions.
+# ------------------------------------------------------------------------------------------------
+from ..backbones.unet_openai import (CheckpointFunction, GroupNorm32, avg_pool_nd, checkpoint, conv_nd, linear,  # noqa: E402,F401
+                                     normalization, zero_module)
+from ..backbones.unet_openai import timestep_embedding as _timestep_embedding  # noqa: E402
+
+SiLU = torch.nn.SiLU  # (util.py:226-228 spells x * sigmoid(x) as a module)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
+    """util.py:168-188: the sinusoidal table of the UNet (HIP kernel), or with repeat_only the timestep copied into every column"""
+    if repeat_only:
+        return timesteps[:, None].repeat(1, dim)
+    return _timestep_embedding(timesteps, dim, max_period)
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """util.py:94-110: beta_i = min(1 - alpha_bar((i+1)/N) / alpha_bar(i/N), max_beta) as a float64 numpy array"""
+    n = num_diffusion_timesteps
+    return np.array([min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), max_beta) for i in range(n)])
+
+
+def scale_module(module, scale):
+    """util.py:200-206: multiply every parameter in place, return the module"""
+    for p in module.parameters():
+        p.detach().mul_(scale)
+    return module
+
+
+def mean_flat(tensor):
+    """util.py:209-213: mean over every dimension but the first"""
+    return tensor.mean(dim=list(range(1, len(tensor.shape))))
+
+
+def get_obj_from_str(string, reload=False):
+    """util.py:30-35: "pkg.mod.Name" -> the object"""
+    import importlib
+    module, name = string.rsplit(".", 1)
+    mod = importlib.import_module(module)
+    if reload:
+        mod = importlib.reload(mod)
+    return getattr(mod, name)
+
+
+def instantiate_from_config(config):
+    """util.py:20-27: {"target": "pkg.mod.Class", "params": {...}} -> Class(**params); the two LDM marker strings give None"""
+    if "target" not in config:
+        if config in ("__is_first_stage__", "__is_unconditional__"):
+            return None
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(config["target"])(**config.get("params", dict()))
+
+
+class HybridConditioner(torch.nn.Module):
+    """util.py:268-278: {"c_concat": [encoder(c_concat)], "c_crossattn": [encoder(c_crossattn)]} from two configured encoders"""
+
+    def __init__(self, c_concat_config, c_crossattn_config):
+        super().__init__()
+        self.concat_conditioner = instantiate_from_config(c_concat_config)
+        self.crossattn_conditioner = instantiate_from_config(c_crossattn_config)
+
+    def forward(self, c_concat, c_crossattn):
+        return {"c_concat": [self.concat_conditioner(c_concat)], "c_crossattn": [self.crossattn_conditioner(c_crossattn)]}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain | train_loop | make_label]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain | train_loop | make_label | api_names]
 
 The reference never travels to the GPU box; only the .npz / .json data written here does.
 Harness-side adaptations (NOT reference behaviour):
@@ -632,8 +632,31 @@ def gen_make_label():
     save("make_label_boxes", cases=np.asarray([[c[0][0], c[0][1], *c[1:]] for c in cases], np.int64), boxes=np.asarray(boxes, np.int64))
 
 
+def gen_api_names():
+    """the names a script can import from the reference's modules on the path -- top-level classes / functions and `Class.method` -- read
+    from the syntax tree (names only, no source text): tests/test_host_contract.py checks that the drop-in modules define every one"""
+    import ast
+    out = {}
+    for rel in ("backbones/unet_openai.py", "diffusion/model.py", "diffusion/ddim.py", "diffusion/util.py"):
+        with open(os.path.join(REF, rel)) as f:
+            tree = ast.parse(f.read())
+        names = []
+        for node in tree.body:
+            if isinstance(node, (ast.ClassDef, ast.FunctionDef)):
+                names.append(node.name)
+                if isinstance(node, ast.ClassDef):
+                    names += [f"{node.name}.{b.name}" for b in node.body if isinstance(b, ast.FunctionDef)]
+        out[rel] = names
+    with open(os.path.join(HERE, "api_names.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 2 and sys.argv[2] == "api_names":
+        gen_api_names()
+        print("done")
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "make_label":
         gen_make_label()
         print("done")
@@ -663,4 +686,5 @@ if __name__ == "__main__":
     gen_full_chain()
     gen_train_loop()
     gen_make_label()
+    gen_api_names()
     print("done")
