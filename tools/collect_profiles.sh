@@ -17,6 +17,7 @@ python3 bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 --dump-o
 python3 bench.py --arch A1 --batch 8 --no-cpu-baseline --steps 10 --warmup 3 > $OUT/${TAG}_bench_A1_256_bs8.json
 python3 bench.py --arch A1 --batch 8 --no-cpu-baseline --no-secondary --steps 10 --warmup 3 --dump-ops $OUT/${TAG}_bench_A1_256_bs8_fp32x3_per_op_hip_events.json > /dev/null
 python3 bench.py --size 64 --no-cpu-baseline --steps 200 --warmup 10 --no-op-timing > $OUT/${TAG}_bench_A0_64_bs16.json
+python3 bench.py --size 64 --no-cpu-baseline --no-secondary --steps 100 --warmup 10 --dump-ops $OUT/${TAG}_bench_A0_64_bs16_fp32x3_per_op_hip_events.json > /dev/null
 python3 bench.py --train --precision fp16 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_train_fp16.json
 python3 bench.py --train --precision fp16 --arch A1 --size 512 --batch 2 --in-ch 13 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_train_config5_bs2_fp16.json
 echo "[2] end-to-end calls"; date

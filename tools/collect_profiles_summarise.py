@@ -81,6 +81,7 @@ for src, dst in [(f"{tag}_bench_default.json", f"{tag}_bench_default.json"),
                  (f"{tag}_bench_A1_256_bs8.json", f"{tag}_bench_A1_256_bs8.json"),
                  (f"{tag}_bench_A1_256_bs8_fp32x3_per_op_hip_events.json", f"{tag}_bench_A1_256_bs8_fp32x3_per_op_hip_events.json"),
                  (f"{tag}_bench_A0_64_bs16.json", f"{tag}_bench_A0_64_bs16.json"),
+                 (f"{tag}_bench_A0_64_bs16_fp32x3_per_op_hip_events.json", f"{tag}_bench_A0_64_bs16_fp32x3_per_op_hip_events.json"),
                  (f"{tag}_bench_train_fp16.json", f"{tag}_bench_train_fp16.json"),
                  (f"{tag}_bench_train_config5_bs2_fp16.json", f"{tag}_bench_train_config5_bs2_fp16.json"),
                  (f"{tag}_full_1000step_sampling.txt", f"{tag}_full_1000step_sampling.txt"),
