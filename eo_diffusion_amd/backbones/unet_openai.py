@@ -121,6 +121,16 @@ def timestep_embedding(timesteps, dim, max_period=10000):
     return out
 
 
+def int_timesteps(timesteps, device):
+    """timesteps as the int64 device tensor the timestep-MLP kernel reads.  The reference's timestep_embedding (unet_openai.py:81-99) also
+    takes fractional values; every caller on the path passes integers (model.py:40, 52; ddim.py:143), the kernel indexes nothing with them
+    but converts int64 -> float, so a floating tensor is accepted when its values are whole numbers and refused LOUDLY otherwise (the
+    check costs one host synchronisation, paid only by callers that pass a floating dtype)."""
+    if timesteps.is_floating_point() and bool((timesteps != timesteps.round()).any()):
+        raise _lib.EodError("UNetModel: fractional timesteps are not supported on the HIP path (the timestep kernel takes int64)")
+    return timesteps.to(device=device, dtype=th.int64).contiguous()
+
+
 def checkpoint(func, inputs, params, flag):
     """Activation checkpointing is a training-memory device (unet_openai.py:102-148); inference path
     simply evaluates the function."""
@@ -840,7 +850,7 @@ class UNetModel(_Emitter):
         if use_graph and not prog.drop_ops:  # (a captured graph would replay ONE dropout mask: train-mode dropout runs un-captured)
             return self._forward_graph(prog, x, timesteps, cond, y)
         xin = x if (x.dtype == th.float32 and x.is_contiguous()) else x.float().contiguous()
-        t64 = timesteps.to(device=x.device, dtype=th.int64).contiguous()
+        t64 = int_timesteps(timesteps, x.device)
         assert t64.shape == (N,)
         out = th.empty(prog.out_shape, dtype=th.float32, device=x.device)
         prog.set_binding("x", xin.data_ptr())
@@ -877,7 +887,7 @@ def _forward_graph(self, prog, x, timesteps, cond, y):
             st["y"] = th.zeros((x.shape[0],), dtype=th.int64, device=dev)
             prog.set_binding("y", st["y"].data_ptr())
         st["x"].copy_(x)
-        st["t"].copy_(timesteps)
+        st["t"].copy_(int_timesteps(timesteps, x.device))
         if cond is not None:
             st["cond"].copy_(cond)
         if y is not None:
@@ -890,7 +900,7 @@ def _forward_graph(self, prog, x, timesteps, cond, y):
         st["graph"] = g
         prog._graph_state = st
     st["x"].copy_(x)
-    st["t"].copy_(timesteps)
+    st["t"].copy_(int_timesteps(timesteps, x.device))
     if cond is not None:
         st["cond"].copy_(cond)
     if y is not None:

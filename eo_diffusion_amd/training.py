@@ -961,7 +961,7 @@ class UNetTrainer:
         for fn in self.repack:
             fn()
         self._x = x.contiguous().float()
-        self._t = timesteps.to(torch.int64).contiguous()
+        self._t = self.U.int_timesteps(timesteps, self.device)
         self._t_slot.copy_(self._t)
         self.prog.ops[self.i_in].u.small.p[0] = self._x.data_ptr()
         if cond is not None:

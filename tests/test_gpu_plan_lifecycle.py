@@ -67,3 +67,45 @@ def test_plan_follows_the_module_through_its_life(prec):
     _check(u, live(), (2, 3, 16, 16), prec, "the original after the copy changed", 12)
     u2 = u.to("cpu").to(DEV)                                            # a round trip through the host moves every parameter
     _check(u2, {k: v for k, v in u2.state_dict().items()}, (2, 3, 16, 16), prec, "after .to(cpu).to(gpu)", 13)
+
+
+def test_forward_accepts_the_input_forms_torch_modules_accept():
+    """what the reference's nn.Module forward takes without complaint: non-contiguous / channels_last / fp64 / fp16 images, timesteps as
+    int32, on the host, or as whole-number floats, cond in another dtype -- all give the bits of the plain call (fp16 / fp64 inputs are
+    converted to fp32 first, as `h = x.type(self.dtype)` does, unet_openai.py:762); fractional timesteps are refused loudly"""
+    from eo_diffusion_amd._lib import EodError
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from oracle import unet_ref as UR
+    cfg = dict(CFG, in_channels=6)
+    sd = synth_state_dict(unet_param_shapes(**cfg), 5)
+    u = UNetModel(**cfg).set_precision("fp32x3")
+    u.load_state_dict(sd)
+    u = u.to(DEV).eval()
+    N, H = 2, cfg["image_size"]
+    x = synth_input("ifx", (N, 3, H, H), 1)
+    c = synth_input("ifc", (N, 3, H, H), 2)
+    t = torch.tensor([3, 977])
+    with torch.no_grad():
+        base = u(x.to(DEV), t.to(DEV), cond=c.to(DEV))
+        assert rel_l2(base.cpu(), UR.unet_forward(sd, cfg, x, t, cond=c)) < TOL["fp32x3"]
+        wide = torch.zeros(N, 3, H, 2 * H)
+        wide[..., ::2] = x
+        forms = {
+            "strided": (wide.to(DEV)[..., ::2], t.to(DEV), c.to(DEV)),
+            "channels_last": (x.to(DEV).contiguous(memory_format=torch.channels_last), t.to(DEV), c.to(DEV)),
+            "fp64": (x.double().to(DEV), t.to(DEV), c.to(DEV)),
+            "t_int32": (x.to(DEV), t.int().to(DEV), c.to(DEV)),
+            "t_host": (x.to(DEV), t, c.to(DEV)),
+            "t_float": (x.to(DEV), t.float().to(DEV), c.to(DEV)),
+            "cond_fp64_host": (x.to(DEV), t.to(DEV), c.double()),
+        }
+        for name, (xi, ti, ci) in forms.items():
+            out = u(xi, ti, cond=ci)
+            assert out.dtype == xi.dtype and torch.equal(out.float(), base), name
+        xh = x.half().float()  # (an fp16 image is an fp32 image whose values are fp16 numbers)
+        out16 = u(x.half().to(DEV), t.to(DEV), cond=c.to(DEV))
+        assert out16.dtype == torch.float16 and torch.equal(out16, u(xh.to(DEV), t.to(DEV), cond=c.to(DEV)).half())
+        with pytest.raises(EodError, match="fractional"):
+            u(x.to(DEV), torch.tensor([3.5, 10.0]).to(DEV), cond=c.to(DEV))
+    with pytest.raises(EodError, match="fractional"):
+        u.train()(x.to(DEV), torch.tensor([3.5, 10.0]).to(DEV), cond=c.to(DEV))
