@@ -38,7 +38,7 @@ class GemmDesc(C.Structure):
 class TembDesc(C.Structure):
     _fields_ = [("t", vp), ("freqs", vp), ("w1", vp), ("b1", vp), ("w2", vp), ("b2", vp), ("label_emb", vp), ("y", vp),
                 ("wcat", vp), ("bcat", vp), ("h1", vp), ("emb", vp), ("out", vp), ("N", i32), ("D", i32), ("E", i32),
-                ("J", i32)]
+                ("J", i32), ("t_f32", i32), ("_pad", i32)]
 
 
 class AttnDesc(C.Structure):

@@ -121,14 +121,13 @@ def timestep_embedding(timesteps, dim, max_period=10000):
     return out
 
 
-def int_timesteps(timesteps, device):
-    """timesteps as the int64 device tensor the timestep-MLP kernel reads.  The reference's timestep_embedding (unet_openai.py:81-99) also
-    takes fractional values; every caller on the path passes integers (model.py:40, 52; ddim.py:143), the kernel indexes nothing with them
-    but converts int64 -> float, so a floating tensor is accepted when its values are whole numbers and refused LOUDLY otherwise (the
-    check costs one host synchronisation, paid only by callers that pass a floating dtype)."""
-    if timesteps.is_floating_point() and bool((timesteps != timesteps.round()).any()):
-        raise _lib.EodError("UNetModel: fractional timesteps are not supported on the HIP path (the timestep kernel takes int64)")
-    return timesteps.to(device=device, dtype=th.int64).contiguous()
+def device_timesteps(timesteps, device):
+    """(tensor, is_fp32): timesteps as the timestep-MLP kernel reads them -- int64 [N] for every integer dtype (what each caller on the path
+    passes: model.py:40, 52; ddim.py:143), fp32 [N] for a floating tensor: the reference's timestep_embedding forms
+    `timesteps[:, None].float() * freqs` (unet_openai.py:95) and so also takes fractional values; eod_temb_desc.t_f32 selects the type"""
+    if timesteps.is_floating_point():
+        return timesteps.to(device=device, dtype=th.float32).contiguous(), 1
+    return timesteps.to(device=device, dtype=th.int64).contiguous(), 0
 
 
 def checkpoint(func, inputs, params, flag):
@@ -786,6 +785,7 @@ class UNetModel(_Emitter):
             wcat=_lib.ptr(wcat), bcat=_lib.ptr(bcat), h1=_lib.ptr(h1), emb=_lib.ptr(emb), out=_lib.ptr(ctx.out),
             N=N, D=D, E=E, J=ctx.J))
         prog.bind("t", i_t, lambda op, v: setattr(op.u.temb, "t", v))
+        prog.bind("t_f32", i_t, lambda op, v: setattr(op.u.temb, "t_f32", v))
         if with_y:
             prog.bind("y", i_t, lambda op, v: setattr(op.u.temb, "y", v))
 
@@ -847,10 +847,12 @@ class UNetModel(_Emitter):
             assert y.shape == (N,), (y.shape, x.shape)
         prog = self.program_for(N, cx, ccond, H, W, x.device, y is not None)
         use_graph = self._use_graph if getattr(self, "_use_graph", None) is not None else os.environ.get("EOD_GRAPH", "0") == "1"
-        if use_graph and not prog.drop_ops:  # (a captured graph would replay ONE dropout mask: train-mode dropout runs un-captured)
+        if use_graph and not prog.drop_ops and not timesteps.is_floating_point():
+            # (a captured graph would replay ONE dropout mask: train-mode dropout runs un-captured; so do fractional timesteps -- the
+            #  captured program reads the int64 slot)
             return self._forward_graph(prog, x, timesteps, cond, y)
         xin = x if (x.dtype == th.float32 and x.is_contiguous()) else x.float().contiguous()
-        t64 = int_timesteps(timesteps, x.device)
+        t64, t_f32 = device_timesteps(timesteps, x.device)
         assert t64.shape == (N,)
         out = th.empty(prog.out_shape, dtype=th.float32, device=x.device)
         prog.set_binding("x", xin.data_ptr())
@@ -861,6 +863,7 @@ class UNetModel(_Emitter):
             y64 = y.to(device=x.device, dtype=th.int64).contiguous()
             prog.set_binding("y", y64.data_ptr())
         prog.set_binding("t", t64.data_ptr())
+        prog.set_binding("t_f32", t_f32)
         prog.set_binding("out", out.data_ptr())
         prog.next_dropout_step()
         prog.run()
@@ -887,7 +890,7 @@ def _forward_graph(self, prog, x, timesteps, cond, y):
             st["y"] = th.zeros((x.shape[0],), dtype=th.int64, device=dev)
             prog.set_binding("y", st["y"].data_ptr())
         st["x"].copy_(x)
-        st["t"].copy_(int_timesteps(timesteps, x.device))
+        st["t"].copy_(timesteps)
         if cond is not None:
             st["cond"].copy_(cond)
         if y is not None:
@@ -900,7 +903,7 @@ def _forward_graph(self, prog, x, timesteps, cond, y):
         st["graph"] = g
         prog._graph_state = st
     st["x"].copy_(x)
-    st["t"].copy_(int_timesteps(timesteps, x.device))
+    st["t"].copy_(timesteps)
     if cond is not None:
         st["cond"].copy_(cond)
     if y is not None:

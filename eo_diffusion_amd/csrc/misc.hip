@@ -380,7 +380,7 @@ template <int MODE>
 __global__ void temb_linear_kernel(const float* __restrict__ in, const long long* __restrict__ t, const float* __restrict__ freqs,
                                    const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ label_emb,
                                    const long long* __restrict__ y, float* __restrict__ out, float* __restrict__ out2, int N, int K,
-                                   int J) {
+                                   int J, int t_f32 = 0) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= J) return;
@@ -390,7 +390,7 @@ __global__ void temb_linear_kernel(const float* __restrict__ in, const long long
         if (MODE == 0) {
             // timestep_embedding (unet_openai.py:91-99): [cos(t*f) | sin(t*f)] (+ one zero if K is odd)
             const int half = K / 2;
-            const float tf = (float)t[n];
+            const float tf = t_f32 ? reinterpret_cast<const float*>(t)[n] : (float)t[n];
             for (int k = lane; k < K; k += 64) {
                 float e = 0.0f;
                 if (k < half)
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void temb_table_linear_kernel(const float* __r
                                                                 const float* __restrict__ freqs, const float* __restrict__ w,
                                                                 const float* __restrict__ b, const float* __restrict__ label_emb,
                                                                 const long long* __restrict__ y, float* __restrict__ out, int N,
-                                                                int K, int J) {
+                                                                int K, int J, int t_f32 = 0) {
     extern __shared__ float tab[];  // [TEMB_NB][K]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = K / 2;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void temb_table_linear_kernel(const float* __r
             float e = 0.0f;
             if (n < nb) {
                 if (STAGE == 1) {
-                    const float tf = (float)t[n0 + n];
+                    const float tf = t_f32 ? reinterpret_cast<const float*>(t)[n0 + n] : (float)t[n0 + n];
                     if (k < half)
                         e = cosf(mul_rn(tf, freqs[k]));
                     else if (k < 2 * half)
@@ -534,9 +534,9 @@ extern "C" int eod_time_embed(const eod_temb_desc* d, void* stream) {
         const unsigned be = (unsigned)((d->E + 3) / 4);
         if (d->D <= 64 * TEMB_KI) {
             const unsigned b1 = (unsigned)((d->E + 4 * TEMB_OPW - 1) / (4 * TEMB_OPW));
-            hipLaunchKernelGGL(temb_table_linear_kernel<1>, dim3(b1), dim3(256), (size_t)TEMB_NB * d->D * sizeof(float), st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, d->N, d->D, d->E);
+            hipLaunchKernelGGL(temb_table_linear_kernel<1>, dim3(b1), dim3(256), (size_t)TEMB_NB * d->D * sizeof(float), st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, d->N, d->D, d->E, d->t_f32);
         } else {
-            hipLaunchKernelGGL(temb_linear_kernel<0>, dim3(be), dim3(256), 0, st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, nullptr, d->N, d->D, d->E);
+            hipLaunchKernelGGL(temb_linear_kernel<0>, dim3(be), dim3(256), 0, st, nullptr, (const long long*)d->t, d->freqs, d->w1, d->b1, nullptr, nullptr, d->h1, nullptr, d->N, d->D, d->E, d->t_f32);
         }
         if (d->E <= 64 * TEMB_KI) {
             const unsigned b2 = (unsigned)((d->E + 4 * TEMB_OPW - 1) / (4 * TEMB_OPW));

@@ -961,7 +961,10 @@ class UNetTrainer:
         for fn in self.repack:
             fn()
         self._x = x.contiguous().float()
-        self._t = self.U.int_timesteps(timesteps, self.device)
+        if timesteps.is_floating_point() and bool((timesteps != timesteps.round()).any()):
+            # (inference takes fractional timesteps, eod_temb_desc.t_f32; the backward's recomputation of the sinusoid reads int64)
+            raise EodError("training: fractional timesteps are not supported (train.py / model.py:40 draw integers)")
+        self._t = timesteps.to(device=self.device, dtype=torch.int64).contiguous()
         self._t_slot.copy_(self._t)
         self.prog.ops[self.i_in].u.small.p[0] = self._x.data_ptr()
         if cond is not None:

@@ -259,7 +259,8 @@ int eod_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int dtyp
  * k6: timestep embedding MLP (unet_openai.py:81-99, 597-602, 604-605, 329-335, 763-766).
  *   emb   = W2 * silu(W1 * [cos(t f) | sin(t f)] + b1) + b2 (+ label_emb[y])
  *   out   = Wcat * silu(emb) + bcat             (all ResBlock emb_layers batched into one GEMV)
- * all fp32.  freqs[half] is the host-computed fp32 table of :92-94.  t is int64 [N].
+ * all fp32.  freqs[half] is the host-computed fp32 table of :92-94.  t is int64 [N]; with t_f32 != 0 it points at fp32 [N] instead
+ * (`timesteps[:, None].float()`, :95: the reference's embedding also takes fractional timesteps).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     const int64_t* t;
@@ -273,6 +274,7 @@ typedef struct {
     float* emb;  /* out [N][E] (pre-SiLU, as the reference's emb) */
     float* out;  /* out [N][J] */
     int32_t N, D, E, J;
+    int32_t t_f32, _pad;
 } eod_temb_desc;
 int eod_time_embed(const eod_temb_desc* d, void* stream);
 /* the sinusoid alone (timestep_embedding, unet_openai.py:81-99; the reference's standalone helper): out [N][dim] fp32 =

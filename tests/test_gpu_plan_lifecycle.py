@@ -72,7 +72,8 @@ def test_plan_follows_the_module_through_its_life(prec):
 def test_forward_accepts_the_input_forms_torch_modules_accept():
     """what the reference's nn.Module forward takes without complaint: non-contiguous / channels_last / fp64 / fp16 images, timesteps as
     int32, on the host, or as whole-number floats, cond in another dtype -- all give the bits of the plain call (fp16 / fp64 inputs are
-    converted to fp32 first, as `h = x.type(self.dtype)` does, unet_openai.py:762); fractional timesteps are refused loudly"""
+    converted to fp32 first, as `h = x.type(self.dtype)` does, unet_openai.py:762); fractional timesteps follow the reference's
+    `timesteps.float()` embedding in inference and are refused loudly by the training step"""
     from eo_diffusion_amd._lib import EodError
     from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
     from oracle import unet_ref as UR
@@ -105,7 +106,9 @@ def test_forward_accepts_the_input_forms_torch_modules_accept():
         xh = x.half().float()  # (an fp16 image is an fp32 image whose values are fp16 numbers)
         out16 = u(x.half().to(DEV), t.to(DEV), cond=c.to(DEV))
         assert out16.dtype == torch.float16 and torch.equal(out16, u(xh.to(DEV), t.to(DEV), cond=c.to(DEV)).half())
-        with pytest.raises(EodError, match="fractional"):
-            u(x.to(DEV), torch.tensor([3.5, 10.0]).to(DEV), cond=c.to(DEV))
-    with pytest.raises(EodError, match="fractional"):
+        tfrac = torch.tensor([3.5, 976.25])   # fractional timesteps: `timesteps[:, None].float() * freqs` (unet_openai.py:95)
+        for tf in (tfrac.to(DEV), tfrac.double()):
+            assert rel_l2(u(x.to(DEV), tf, cond=c.to(DEV)).cpu(), UR.unet_forward(sd, cfg, x, tfrac, cond=c)) < TOL["fp32x3"]
+        assert rel_l2(u(x.to(DEV), tfrac.to(DEV), cond=c.to(DEV)), base) > 1e-4
+    with pytest.raises(EodError, match="fractional"):   # (the training step's backward recomputes the sinusoid from int64)
         u.train()(x.to(DEV), torch.tensor([3.5, 10.0]).to(DEV), cond=c.to(DEV))
