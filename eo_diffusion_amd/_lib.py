@@ -52,6 +52,7 @@ class PackJob(C.Structure):
 
 
 PACK_CHUNK = 4096
+WSCALE_ROWS = 4  # float slots of a split-fp16 weight scale buffer in front of its per-row exponents (csrc/misc.hip: EOD_WSCALE_ROWS)
 
 
 class SmallDesc(C.Structure):

@@ -69,6 +69,8 @@ struct IgemmP {
     int splitk;    // conv: K-steps are split over gridDim.y workgroups; raw fp32 partial tiles go to `y` (= workspace)
     float alpha;
     const float* w_scale;  // split-fp16 mode: device {s, 1/(s*A_SCALE)} of the packed weights (eod_pack_conv_weight_split)
+    const int* w_rexp;     // ... and its per-row exponents d_j (csrc/misc.hip: row_exp_kernel): column j is multiplied by 2^-d_j on top
+    int w_row0;            // weight row of output column 0 (the parity-class upsample conv: class * Cout)
     // row-decode grid: the M axis enumerates (image, Hd x Wd) positions.  Normally that is the output map (Hd = Ho, Wd = Wo).  Parity
     // mode (par = 1; zero-insertion upsampling = the backward-data of a stride-2 conv): one launch per output parity class (par_y,
     // par_x), rows enumerate the (Ho/2) x (Wo/2) positions of that class, output pixel = (2 hd + par_y, 2 wd + par_x), and the K loop
@@ -300,6 +302,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
         // (tools/debug/halo_stamps.py: 5.2 us from the end of the K loop to the end of the LDS transpose, 1-2 us without them)
         bcol[j] = pre_bcol ? pre_bcol[j] : ((cok[j] && p.bias && p.bias_mode == 1) ? p.bias[col[j]] : 0.0f);
     }
+    float cmul[TN];  // split-fp16 weights: 2^-d_j of the column's weight row (1 elsewhere)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cmul[j] = (CONV && p.w_rexp && cok[j]) ? ldexpf(1.0f, -p.w_rexp[p.w_row0 + col[j]]) : 1.0f;
     // per-sample (timestep) bias: one value per (image, column).  A tile almost always lies inside one image
     // (always in patch mode); then it is folded into bcol once instead of being fetched per row.
     bool cb_per_row = false;
@@ -331,7 +336,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (!cok[j]) continue;
-                    float v = acc[i][j][r] * ralpha + bcol[j];
+                    float v = acc[i][j][r] * (ralpha * cmul[j]) + bcol[j];
                     if (cb_per_row) v += p.cbias[(long long)n * p.cbias_stride + col[j]];
                     reinterpret_cast<float*>(p.y)[((long long)n * p.Cout + col[j]) * p.HoWo + (long long)ho * p.Wo + wo] = v;
                 }
@@ -424,7 +429,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                 }
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * MS + lr] = acc[i][j][r] * ralpha + bcol[j] + cb[j];
+            for (int j = 0; j < TN; ++j) slab[rw * EP_LD + j * MS + lr] = acc[i][j][r] * (ralpha * cmul[j]) + bcol[j] + cb[j];
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes are done (the slab is wave-private)
     __builtin_amdgcn_wave_barrier();
@@ -546,9 +551,26 @@ __device__ __forceinline__ void prefetch_bcol4(const IgemmP& p, int ncols, int c
     }
 }
 
+// row exponents of the split weights for the same quads, four bytes per quad (d_j <= 100): one register per channel tile through the K loop
+template <int TN>
+__device__ __forceinline__ void prefetch_wexp4(const IgemmP& p, int ncols, int col0, int wrow0, int lane, int (&out)[TN]) {
+    const int lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = col0 + j * 16 + 4 * lg;
+        int pk = 0;
+        if (p.w_rexp && c < ncols) {
+            const i32x4 e = *reinterpret_cast<const i32x4*>(p.w_rexp + wrow0 + c);
+            pk = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+        }
+        out[j] = pk;
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const TileGeom& g, f32x4 (&acc)[BM / WAVES_M / 16][BN / WAVES_N / 16], int wave,
-                                                     int lane, int n0, const f32x4 (&bq)[BN / WAVES_N / 16], float alpha) {
+                                                     int lane, int n0, const f32x4 (&bq)[BN / WAVES_N / 16], float alpha,
+                                                     const int (&we)[BN / WAVES_N / 16]) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int lp = lane & 15, lg = lane >> 4;
@@ -584,9 +606,12 @@ __device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const Tile
         }
         if (c < p.Ncols) {
             f32x4 ss = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+            // alpha (operand scales of the tensor / image) times the column's 2^-d_j (row scale of the split weights): exact powers of two
+            const f32x4 am = {ldexpf(alpha, -(we[j] & 255)), ldexpf(alpha, -((we[j] >> 8) & 255)), ldexpf(alpha, -((we[j] >> 16) & 255)),
+                              ldexpf(alpha, -((we[j] >> 24) & 255))};
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                f32x4 v = acc[i][j] * alpha + bq[j];
+                f32x4 v = acc[i][j] * am + bq[j];
                 if (res) v += rv[j & 1][i];
                 if (ps_scale != 0.0f) {
                     typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -673,7 +698,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
     // trip instead of standing between the last MFMA and the first store)
     constexpr int TNQ = DIRECT ? BN / WAVES_N / 16 : 1;
     f32x4 pre_bq[TNQ];
-    if constexpr (DIRECT) prefetch_bcol4<TNQ>(p, p.Ncols, n0 + (wave % WAVES_N) * (BN / WAVES_N), threadIdx.x & 63, g.n_first, pre_bq);
+    int pre_we[TNQ];
+    if constexpr (DIRECT) {
+        prefetch_bcol4<TNQ>(p, p.Ncols, n0 + (wave % WAVES_N) * (BN / WAVES_N), threadIdx.x & 63, g.n_first, pre_bq);
+        prefetch_wexp4<TNQ>(p, p.Ncols, n0 + (wave % WAVES_N) * (BN / WAVES_N), p.w_row0, threadIdx.x & 63, pre_we);
+    }
     // split-fp16 product: operand scales of the activation operand(s) from their bound tables (common.h).  conv: one scale per image;
     // a tile normally lies inside one image (always in patch mode) -> wave-uniform as0; a tile that straddles images (maps smaller
     // than or not a multiple of the 128-row tile) keeps a table of its images' scales in LDS: rows are scaled and un-scaled one by one.
@@ -1047,7 +1076,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 
     if constexpr (DIRECT) {
         // one image per tile, no split-K, NHWC output (the launcher checked): stores straight from the (transposed) accumulators
-        halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, g, acc, wave, lane, n0, pre_bq, pe.alpha);
+        halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, g, acc, wave, lane, n0, pre_bq, pe.alpha, pre_we);
     } else if constexpr (sizeof(T) == 4) {
         igemm_epilogue<T, CONV, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, rowtab, rowtab_n);
     } else {
@@ -1142,8 +1171,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     // the loop are unaffected): per-column bias terms and the weights' scale
     float pre_bcol[DIRECT ? 1 : TN];
     f32x4 pre_bq[DIRECT ? TN : 1];
-    if constexpr (DIRECT) prefetch_bcol4<TN>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bq);
-    else prefetch_bcol<TN, MS>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    int pre_we[DIRECT ? TN : 1];
+    if constexpr (DIRECT) {
+        prefetch_bcol4<TN>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bq);
+        prefetch_wexp4<TN>(p, p.Ncols, n0 + wn * WN, p.w_row0, lane, pre_we);
+    } else {
+        prefetch_bcol<TN, MS>(p, p.Ncols, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    }
     float wsc1 = 1.0f;
     if constexpr (SPLIT) wsc1 = p.w_scale[1];
     // split-fp16 product: power-of-two operand scale of this tile's image from the bound table(s) (wave-uniform, common.h); the fused
@@ -1635,7 +1669,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     if constexpr (SPLIT) {
         IgemmP pe = p;
         pe.alpha = p.alpha * wsc1 * asc.inv;  // undo the weight and activation scales (exact powers of two)
-        if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(p, g, acc, wave, lane, n0, pre_bq, pe.alpha);
+        if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(p, g, acc, wave, lane, n0, pre_bq, pe.alpha, pre_we);
         else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     } else {
         igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
@@ -1691,8 +1725,13 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode on the STORED map: ty0, tx0, n_first
     float pre_bcol[DIRECT ? 1 : TN];  // epilogue operands fetched at entry (see conv3x3_halo_kernel)
     f32x4 pre_bq[DIRECT ? TN : 1];
-    if constexpr (DIRECT) prefetch_bcol4<TN>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bq);
-    else prefetch_bcol<TN, MS>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    int pre_we[DIRECT ? TN : 1];
+    if constexpr (DIRECT) {
+        prefetch_bcol4<TN>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bq);
+        prefetch_wexp4<TN>(p, p.Cout, n0 + wn * WN, cls * p.Cout, lane, pre_we);  // (class kernels: weight row = class * Cout + column)
+    } else {
+        prefetch_bcol<TN, MS>(p, p.Cout, n0 + wn * WN, lane, g.n_first, pre_bcol);
+    }
     float wsc1 = 1.0f;
     if constexpr (SPLIT) wsc1 = p.w_scale[1];
     AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};             // split-fp16 product: operand scale of this tile's image (see conv3x3_halo_kernel)
@@ -1923,7 +1962,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
         ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
     }
     if constexpr (SPLIT) pe.alpha = p.alpha * wsc1 * asc.inv;
-    if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, ge, acc, wave, lane, n0, pre_bq, pe.alpha);
+    if constexpr (!BWD) pe.w_row0 = cls * p.Cout;
+    if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, ge, acc, wave, lane, n0, pre_bq, pe.alpha, pre_we);
     else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, ge, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
 }
 
@@ -2157,9 +2197,10 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
             const int co = 4 * lh + r;
             if (co >= p.Cout) continue;
             const float bv = p.bias ? p.bias[co] : 0.0f;
+            const float am = (SPLIT && p.w_rexp) ? ldexpf(alpha, -p.w_rexp[co]) : alpha;  // (row scale of the split weights)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                yb[(long long)co * p.HoWo + (long long)(g.ty0 + wave * 2 + i) * p.Wo + g.tx0 + lr] = acc[i][r] * alpha + bv;
+                yb[(long long)co * p.HoWo + (long long)(g.ty0 + wave * 2 + i) * p.Wo + g.tx0 + lr] = acc[i][r] * am + bv;
         }
     }
 }
@@ -2673,6 +2714,8 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     EOD_REQUIRE(!d->w_split || (conv_split_ok(d, Ho, Wo) && d->w_scale),
                 "conv: w_split needs a geometry for which eod_conv_split_ok(d) == 1 and the w_scale of eod_pack_conv_weight_split");
     p.w_scale = d->w_split ? d->w_scale : nullptr;
+    p.w_rexp = d->w_split ? reinterpret_cast<const int*>(d->w_scale) + 4 : nullptr;  // (EOD_WSCALE_ROWS of csrc/misc.hip)
+    p.w_row0 = 0;
     p.a_bound = d->w_split ? d->a_bound : nullptr;
     EOD_REQUIRE(!d->x_presplit || (d->w_split && d->a_bound && !halo_ok && !d->upsample && !d->w_tapmajor && !d->gn_scale_shift),
                 "conv: x_presplit needs w_split with the producer's bound table, on the generic kernel (1x1 / stride-2 / small maps)");

@@ -63,19 +63,50 @@ __global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restr
     }
 }
 
+// Per-ROW part of the scale (round 3): output row j (one output channel: Cin * taps consecutive OIHW values) is packed under
+// s_j = s * 2^d_j with d_j = E - e_j >= 0 the distance of the row's binary exponent e_j from the tensor's E, so that EVERY row's largest
+// value lies in (2^12, 2^13] and every row keeps its own 22 bits -- with the tensor scale alone a row 2^18 times smaller than the
+// largest one starts to lose bits (fp16 subnormals) and an output channel (a whole GroupNorm group, once renormalised) can be off by
+// 1e-4 ... 1 where the reference's fp32 product is exact.  d_j (int32, clamped to 100, 0 for an all-zero row) is stored at
+// scale[EOD_WSCALE_ROWS + j]; the conv epilogues multiply column j by 2^-d_j on top of scale[1].  One wave per row.
+constexpr int EOD_WSCALE_ROWS = 4;  // float slots in front of the per-row exponents (keeps them 16-byte aligned)
+__global__ __launch_bounds__(256) void row_exp_kernel(const float* __restrict__ w, long long row_len, const float* __restrict__ w2,
+                                                      long long row_len2, int rows, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= rows) return;
+    float m = 0.0f;
+    for (long long i = lane; i < row_len; i += 64) m = fmaxf(m, fabsf(w[(long long)j * row_len + i]));
+    for (long long i = lane; i < row_len2; i += 64) m = fmaxf(m, fabsf(w2[(long long)j * row_len2 + i]));  // (a second tensor sharing the scale)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) {
+        int d = 0;
+        if (m > 0.0f && m < 3.0e38f) {
+            int e;
+            frexpf(m, &e);
+            const int E = 13 - ilogbf(scale[0]);  // scale[0] = 2^(13 - E)
+            d = min(max(E - e, 0), 100);
+        }
+        reinterpret_cast<int*>(scale)[EOD_WSCALE_ROWS + j] = d;
+    }
+}
+
 __global__ void pack_conv_w_split_kernel(const float* __restrict__ w, half_t* __restrict__ dst, const float* __restrict__ scale, int Cout,
                                          int Cin, int taps, int cin_pad) {
     const float s = scale[0];
+    const int* rexp = reinterpret_cast<const int*>(scale) + EOD_WSCALE_ROWS;
     const long long groups = (long long)taps * Cout * (cin_pad / 8);
     for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
         const int cg = (int)(gi % (cin_pad / 8));
         const long long r = gi / (cin_pad / 8);
         const int co = (int)(r % Cout), tap = (int)(r / Cout);
+        const float sj = ldexpf(s, rexp[co]);
         half8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ci = cg * 8 + j;
-            const float v = ci < Cin ? w[((long long)co * Cin + ci) * taps + tap] * s : 0.0f;
+            const float v = ci < Cin ? w[((long long)co * Cin + ci) * taps + tap] * sj : 0.0f;
             hi[j] = (half_t)v;
             lo[j] = (half_t)(v - (float)hi[j]);
         }
@@ -91,6 +122,7 @@ extern "C" int eod_pack_conv_weight_split(const float* w, void* dst, float* scal
     EOD_REQUIRE(eod_aligned16(dst), "pack_conv_weight_split: dst must be 16-byte aligned");
     const int taps = ksize * ksize;
     hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cout * Cin * taps, scale);
+    hipLaunchKernelGGL(row_exp_kernel, dim3((Cout + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, (long long)Cin * taps, nullptr, 0LL, Cout, scale);
     const long long groups = (long long)taps * Cout * (cin_pad / 8);
     const unsigned blocks = (unsigned)((groups + 255) / 256 > 4096 ? 4096 : (groups + 255) / 256);
     hipLaunchKernelGGL(pack_conv_w_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, scale, Cout, Cin, taps, cin_pad);
@@ -107,6 +139,7 @@ extern "C" int eod_pack_conv_weight_split_pair(const float* w, void* dst, const 
     const int taps = ksize * ksize;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, st, w, (long long)Cout * Cin * taps, scale, w2, (long long)Cout * Cin2);
+    hipLaunchKernelGGL(row_exp_kernel, dim3((Cout + 3) / 4), dim3(256), 0, st, w, (long long)Cin * taps, w2, (long long)Cin2, Cout, scale);
     const long long g1 = (long long)taps * Cout * (cin_pad / 8), g2 = (long long)Cout * (Cin2 / 8);
     const unsigned b1 = (unsigned)((g1 + 255) / 256 > 4096 ? 4096 : (g1 + 255) / 256), b2 = (unsigned)((g2 + 255) / 256 > 4096 ? 4096 : (g2 + 255) / 256);
     hipLaunchKernelGGL(pack_conv_w_split_kernel, dim3(b1), dim3(256), 0, st, w, (half_t*)dst, scale, Cout, Cin, taps, cin_pad);
@@ -171,14 +204,16 @@ __global__ void pack_conv_w_tapmajor_kernel(const float* __restrict__ w, T* __re
 __global__ void pack_conv_w_tapmajor_split_kernel(const float* __restrict__ w, half_t* __restrict__ dst, const float* __restrict__ scale,
                                                   int Cout, int Cin, int cin_pad, int ldk) {
     const float s = scale[0];
+    const int* rexp = reinterpret_cast<const int*>(scale) + EOD_WSCALE_ROWS;
     const long long groups = (long long)Cout * (ldk / 8);
     for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long long)gridDim.x * blockDim.x) {
         const int kg = (int)(gi % (ldk / 8)), co = (int)(gi / (ldk / 8));
+        const float sj = ldexpf(s, rexp[co]);
         half8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = kg * 8 + j, tap = k / cin_pad, ci = k - tap * cin_pad;
-            const float v = (tap < 9 && ci < Cin) ? w[((long long)co * Cin + ci) * 9 + tap] * s : 0.0f;
+            const float v = (tap < 9 && ci < Cin) ? w[((long long)co * Cin + ci) * 9 + tap] * sj : 0.0f;
             hi[j] = (half_t)v;
             lo[j] = (half_t)(v - (float)hi[j]);
         }
@@ -207,6 +242,7 @@ extern "C" int eod_pack_conv_weight_tapmajor_split(const float* w, void* dst, fl
     EOD_REQUIRE(w && dst && scale && Cout > 0 && Cin > 0 && cin_pad >= Cin && eod_aligned16(dst), "pack_conv_weight_tapmajor_split: bad args");
     const int ldk = eod_conv_tapmajor_ldk(cin_pad, EOD_F32);
     hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cout * Cin * 9, scale);
+    hipLaunchKernelGGL(row_exp_kernel, dim3((Cout + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, (long long)Cin * 9, nullptr, 0LL, Cout, scale);
     const long long groups = (long long)Cout * (ldk / 8);
     const unsigned blocks = (unsigned)((groups + 255) / 256 > 4096 ? 4096 : (groups + 255) / 256);
     hipLaunchKernelGGL(pack_conv_w_tapmajor_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (half_t*)dst, scale, Cout, Cin, cin_pad, ldk);

@@ -72,7 +72,7 @@ class _LazyConvW:
             cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
             cin_pad = self.cin_pad or cin
             dst = prog.empty((k * k, cout, cin_pad), torch.float32)  # 4 bytes per element: [8 x fp16 hi | 8 x fp16 lo] per 8 channels
-            scale = prog.empty((2,), torch.float32)
+            scale = prog.empty((_lib.WSCALE_ROWS + cout,), torch.float32)  # {s, 1/(16 s), -, -} + one int32 row exponent per output row
             check(prog.L.eod_pack_conv_weight_split(ptr(w), ptr(dst), ptr(scale), cout, cin, k, cin_pad,
                                                     current_stream_ptr(prog.device)), "pack_conv_weight_split")
             self._split = (dst, scale)
@@ -89,7 +89,7 @@ class _LazyConvW:
         cin_pad = self.cin_pad or cin
         dst = prog.empty((k * k, cout, cin_pad), torch.float32)
         dst2 = prog.empty((1, cout, cin2), torch.float32)
-        scale = prog.empty((2,), torch.float32)
+        scale = prog.empty((_lib.WSCALE_ROWS + cout,), torch.float32)
         check(prog.L.eod_pack_conv_weight_split_pair(ptr(w), ptr(dst), ptr(w2), ptr(dst2), ptr(scale), cout, cin, k, cin_pad, cin2,
                                                      current_stream_ptr(prog.device)), "pack_conv_weight_split_pair")
         return dst, scale, dst2
@@ -194,7 +194,7 @@ class Program:
         assert w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3
         ldk = self.L.eod_conv_tapmajor_ldk(cin_pad, self.dt)
         if self.split:  # fp32x3 program: split-fp16 pairs + device scale (conv() sets w_split)
-            dst, scale = self.empty((cout, ldk), torch.float32), self.empty((2,), torch.float32)
+            dst, scale = self.empty((cout, ldk), torch.float32), self.empty((_lib.WSCALE_ROWS + cout,), torch.float32)
             check(self.L.eod_pack_conv_weight_tapmajor_split(ptr(w), ptr(dst), ptr(scale), cout, cin, cin_pad,
                                                              current_stream_ptr(self.device)), "pack_conv_weight_tapmajor_split")
             return ("split", dst, scale)

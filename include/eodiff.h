@@ -93,7 +93,9 @@ typedef struct {
                             w is the output of eod_pack_conv_weight_split, w_scale its scale pair.  Only where
                             eod_conv_split_ok(d) == 1 (fp32, C0 and C1 multiples of 8 -- or w_tapmajor with eod_pack_conv_weight_tapmajor_split);
                             rel. error ~2^-22 per product */
-    const float* w_scale; /* device pointer to {s, 1/(16 s)} written by eod_pack_conv_weight_split (w_split only) */
+    const float* w_scale; /* device pointer to the scale buffer written by eod_pack_conv_weight_split (w_split only): float {s, 1/(16 s), -, -}
+                           * followed by one int32 row exponent d_j per output row (4 + Cout slots; the parity-class form: 4 + 4 Cout):
+                           * row j is packed under s * 2^d_j, the epilogue multiplies column j by 2^-d_j / (16 s) */
     const float* a_bound; /* w_split: bound table [N][32] fp32 (device) of the tensor the conv SPLITS -- x | x2 as the conv sees them, i.e. behind
                             the fused GroupNorm + SiLU when gn_scale_shift is set: entry maximum per image >= max|element|.  The kernel
                             derives a power-of-two operand scale per image from it (no host synchronisation), so the product is
@@ -176,8 +178,9 @@ int eod_gemm_nt(const eod_gemm_desc* d, void* stream);
 int eod_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int Cout, int Cin, int ksize,
                          int cin_pad, void* stream);
 /* split-fp16 weights of the fp32x3 product (eod_conv_desc.w_split): [tap][Cout][cin_pad] at 4 bytes per element, every 8 input
- * channels as [8 x fp16 hi | 8 x fp16 lo] of s*w, s = 2^k per tensor chosen on the device; scale (device, 2 floats) receives
- * {s, 1/(16 s)}.  cin_pad % 8 == 0.  No host synchronisation. */
+ * channels as [8 x fp16 hi | 8 x fp16 lo] of s_j*w, s_j = s * 2^d_j: s = 2^k per tensor and d_j >= 0 per output row, both chosen on the
+ * device so that every row's largest value lies in (2^12, 2^13] (each output channel keeps its own 22 bits whatever the other rows hold);
+ * scale (device, 4 + Cout slots of 4 bytes) receives float {s, 1/(16 s), -, -} and int32 d_j.  cin_pad % 8 == 0.  No host synchronisation. */
 int eod_pack_conv_weight_split(const float* w_oihw, void* dst, float* scale, int Cout, int Cin, int ksize, int cin_pad, void* stream);
 /* two weights that feed ONE accumulator (eod_conv_desc.skip_w: out_layers' 3x3 conv + the 1x1 skip_connection, unet_openai.py:341,352):
  * both packed as above with one common scale s taken over the two tensors.  w2 is [Cout][Cin2] (1x1), dst2 [Cout][Cin2] at 4 bytes. */

@@ -402,3 +402,98 @@ def test_groupnorm_written_presplit_feeds_a_1x1_conv(kind, case):
     got, _ = run(build)
     ref = F.conv2d(F.group_norm(x.double(), 32, gam.double(), bet.double(), eps=1e-5), w.double(), b.double())
     assert rel_per_image(got, ref) < GATE
+
+
+# ------------------------------------------------------------------------------------------------ weights: output rows of any relative magnitude
+def _row_magnitudes(cout, span, seed):
+    """output-channel magnitudes over `span` decades (a trained net's dead channels next to live ones): the split weights carry a scale per
+    ROW (csrc/misc.hip: row_exp_kernel), so every output channel keeps its own 22 bits; with one scale per tensor a channel 1e8 times
+    smaller than the largest one was off by 1e-3 and one 1e12 times smaller was lost -- visible as soon as a GroupNorm renormalises it"""
+    g = torch.Generator().manual_seed(seed)
+    mag = 10.0 ** (torch.rand(cout, generator=g) * span - span / 2)
+    mag[0], mag[-1] = 10.0 ** (span / 2), 10.0 ** (-span / 2)
+    return mag
+
+
+def worst_channel(got, ref):
+    d, r = (got.double() - ref).flatten(2).norm(dim=2), ref.flatten(2).norm(dim=2)
+    return float((d / r.clamp_min(1e-300)).max())
+
+
+@pytest.mark.parametrize("case", [
+    # kind, N, Cin, H, W, Cout
+    ("halo", 2, 128, 16, 32, 128), ("halo_gn", 2, 128, 16, 32, 256), ("halo_gn", 2, 96, 16, 16, 384), ("halo", 1, 64, 8, 16, 64),
+    ("skip", 2, 128, 16, 32, 128), ("1x1", 2, 160, 16, 16, 128), ("1x1", 1, 256, 24, 16, 768), ("s2", 2, 128, 32, 32, 128),
+    ("splitk", 5, 96, 8, 8, 96), ("up4", 2, 128, 8, 16, 128), ("ups", 1, 96, 16, 32, 192), ("first", 2, 3, 32, 32, 128),
+    ("head", 2, 128, 16, 32, 3),
+])
+def test_output_channels_of_any_relative_magnitude(case):
+    kind, N, Cin, H, W, Cout = case
+    span = 12
+    mag = _row_magnitudes(Cout, span, 7)
+    k = 1 if kind == "1x1" else 3
+    x = synth_input(f"wr{case}", (N, Cin, H, W), 81)
+    w = synth_input(f"wrw{case}", (Cout, Cin, k, k), 82, scale=1.0 / math.sqrt(Cin * k * k)) * mag[:, None, None, None]
+    b = synth_input("wrb", (Cout,), 83, scale=0.1) * mag
+    gam, bet = 1.0 + 0.2 * synth_input("wrg", (Cin,), 84), 0.1 * synth_input("wrbt", (Cin,), 85)
+    xs = synth_input(f"wrs{case}", (N, 64, H, W), 86)
+    w1 = synth_input(f"wrw1{case}", (Cout, 64, 1, 1), 87, scale=0.125) * mag[:, None, None, None]
+    out = {}
+
+    def build(prog):
+        a = Act(nhwc(prog, x), N, H, W, Cin)
+        bb = prog.f32(b.to(DEV))
+        if kind in ("halo", "splitk"):
+            y, i = prog.conv(a, prog.pack_conv(w.to(DEV)), bb, Cout)
+        elif kind == "halo_gn":
+            g = (prog.gn_stats([a], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True)
+            y, i = prog.conv(a, prog.pack_conv(w.to(DEV)), bb, Cout, gn=g)
+        elif kind == "skip":
+            ax = [Act(nhwc(prog, xs), N, H, W, 64)]
+            if not prog.conv_skip_ok(a, Cout, ax):
+                pytest.skip("fused skip conv switched off")
+            y, i = prog.conv(a, prog.pack_conv(w.to(DEV)), bb, Cout, skip=(ax, w1.to(DEV), None))
+        elif kind == "1x1":
+            y, i = prog.conv(a, prog.pack_conv(w.to(DEV)), bb, Cout, ksize=1, stride=1, pad=0)
+        elif kind == "s2":
+            y, i = prog.conv(a, prog.pack_conv(w.to(DEV)), bb, Cout, ksize=3, stride=2, pad=1)
+        elif kind == "up4":
+            if not prog.conv_up4_ok(a, Cout):
+                pytest.skip("parity-class form switched off")
+            y, i = prog.conv(a, prog.pack_conv_up4(w.to(DEV)), bb, Cout, upsample="up4")
+        elif kind == "ups":
+            y, i = prog.conv(a, prog.pack_conv(w.to(DEV)), bb, Cout, upsample=True)
+        elif kind == "first":
+            cp = round_up(Cin, prog.epc)
+            a, idx = prog.to_nhwc(N, Cin, 0, H, W, cp)
+            build.x = x.to(DEV).contiguous()
+            prog.ops[idx].u.small.p[0] = build.x.data_ptr()
+            y, i = prog.conv(a, prog.pack_conv_tapmajor(w.to(DEV), cp), bb, Cout, w_tapmajor=True)
+        elif kind == "head":
+            g = (prog.gn_stats([a], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True)
+            out["y"] = torch.empty((N, Cout, H, W), dtype=torch.float32, device=DEV)
+            _, i = prog.conv(a, prog.pack_conv(w.to(DEV)), bb, Cout, out_nchw_f32=True, gn=g)
+            prog.ops[i].u.conv.y = out["y"].data_ptr()
+            y = None
+        assert prog.ops[i].u.conv.w_split == 1
+        return y
+
+    if kind == "head":
+        prog = Program(DEV, "fp32x3")
+        build(prog)
+        prog.run()
+        torch.cuda.synchronize()
+        got = out["y"].cpu()
+    else:
+        got, _ = run(build, None)
+    xd = x.double()
+    if kind in ("halo_gn", "head"):
+        xd = F.silu(F.group_norm(xd, 32, gam.double(), bet.double(), eps=1e-5))
+    if kind in ("up4", "ups"):
+        xd = F.interpolate(xd, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xd, w.double(), b.double(), stride=2 if kind == "s2" else 1, padding=k // 2)
+    if kind == "skip":
+        ref = ref + F.conv2d(xs.double(), w1.double())
+    e = worst_channel(got, ref)
+    print(f"{case}: worst output channel over {span} decades of row magnitudes: {e:.2e}")
+    assert torch.isfinite(got).all() and e < GATE
