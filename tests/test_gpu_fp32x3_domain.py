@@ -497,3 +497,34 @@ def test_output_channels_of_any_relative_magnitude(case):
     e = worst_channel(got, ref)
     print(f"{case}: worst output channel over {span} decades of row magnitudes: {e:.2e}")
     assert torch.isfinite(got).all() and e < GATE
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_unet_with_dead_and_loud_channels_in_front_of_every_groupnorm(i):
+    """whole random UNets (tests/test_gpu_fuzz_archs.py) whose first conv and every ResBlock in_layers conv -- the convs a GroupNorm
+    renormalises channel group by channel group -- have output rows spread over 12 decades (bias with them): with one scale per weight
+    TENSOR the small rows came out of the split product with few or no bits and the next GroupNorm blew that up; with a scale per row
+    the fp32x3 result sits where the exact-fp32 mode's does (3e-7 ... 1.5e-6 against the CPU oracle)"""
+    from eo_diffusion_amd.backbones.unet_openai import UNetModel, unet_param_shapes
+    from oracle import unet_ref as UR
+    from tests.test_gpu_fuzz_archs import _random_cfg
+    cfg, N, H, W, in_ch, cond_ch = _random_cfg(i)
+    sd = synth_state_dict(unet_param_shapes(**cfg), 40 + i)
+    g = torch.Generator().manual_seed(i)
+    for k, v in list(sd.items()):
+        if k.endswith("weight") and v.dim() == 4 and ("in_layers.2" in k or k.startswith("input_blocks.0.0")):
+            mag = 10.0 ** (torch.rand(v.shape[0], generator=g) * 12 - 6)
+            sd[k] = v * mag.view(-1, 1, 1, 1)
+            sd[k[:-6] + "bias"] = sd[k[:-6] + "bias"] * mag
+    x = synth_input(f"fz_x{i}", (N, in_ch, H, W), 41 + i)
+    cond = synth_input(f"fz_c{i}", (N, cond_ch, H, W), 42 + i) if cond_ch else None
+    t = torch.tensor([(37 * (i + 1) * (k + 1)) % 1000 for k in range(N)])
+    y = torch.tensor([(i + k) % 5 for k in range(N)]) if "num_classes" in cfg else None
+    with torch.no_grad():
+        ref = UR.unet_forward(sd, cfg, x, t, cond=cond, y=y)
+        assert torch.isfinite(ref).all()
+        u = UNetModel(**cfg).set_precision("fp32x3")
+        u.load_state_dict(sd)
+        u = u.to(DEV).eval()
+        out = u(x.to(DEV), t.to(DEV), cond=cond.to(DEV) if cond is not None else None, y=y.to(DEV) if y is not None else None).cpu()
+    assert torch.isfinite(out).all() and rel_l2(out, ref) < GATE, (i, rel_l2(out, ref))
