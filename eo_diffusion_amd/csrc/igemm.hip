@@ -117,7 +117,8 @@ template <> struct Mma<float> {
 // 2^-22 relative).  Measured on gfx950: fp16 SUBNORMAL inputs are honoured by the MFMA and produced by v_cvt_f16_f32
 // (tools/probe/mfma_denorm.hip), so `lo` keeps an absolute resolution of 2^-25 / scale even where it underflows the normal range.
 // Scaling (exact powers of two, undone by alpha in the epilogue):
-//   * weights: per tensor, s = 2^k with max|w|*s in (2^12, 2^13] (pack time, device side) -> lo_w is a normal fp16 for every weight
+//   * weights: s = 2^k per tensor with max|w|*s in (2^12, 2^13], times 2^d_j per output row so that EVERY row's maximum lies there (pack
+//     time, device side: csrc/misc.hip row_exp_kernel; the epilogues multiply column j by 2^-d_j) -> every output channel keeps 22 bits
 //     within 2^-17 of the largest one;
 //   * activations: per IMAGE, s_a = 2^k derived in the kernel from the bound table of the tensor (common.h: eod_gn_finalize /
 //     eod_act_bound write an upper bound B of max|x| per image; B s_a in [2^14, 2^15)), so every element of a tensor of any magnitude

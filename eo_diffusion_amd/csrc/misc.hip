@@ -36,7 +36,7 @@ extern "C" int eod_pack_conv_weight(const float* w, void* dst, int dtype, int Co
 
 // ---------------------------------------------------------------------------------------------
 // split-fp16 weights of the "fp32x3" mode (csrc/igemm.hip): OIHW fp32 -> [tap][Cout][cin_pad] at 4 bytes per element, every group
-// of 8 input channels stored as [8 x hi | 8 x lo] fp16 with hi = fp16(s*w), lo = fp16(s*w - hi); s = 2^k per tensor such that
+// of 8 input channels stored as [8 x hi | 8 x lo] fp16 with hi = fp16(s_j*w), lo = fp16(s_j*w - hi); s_j = s * 2^d_j (row part below), s = 2^k per tensor such that
 // max|w|*s lies in (2^12, 2^13].  scale[0] = s, scale[1] = 1 / (s * 16) (what the conv epilogue multiplies by: weight scale and the
 // activation scale of 16).  Two launches, no host round trip: the scale is read from device memory by the pack kernel and by the conv.
 // ---------------------------------------------------------------------------------------------
@@ -200,7 +200,7 @@ __global__ void pack_conv_w_tapmajor_kernel(const float* __restrict__ w, T* __re
     }
 }
 
-// the same in the split-fp16 format of the fp32x3 product (every 8 consecutive k = [8 x fp16 hi | 8 x fp16 lo] of s*w, per-tensor s)
+// the same in the split-fp16 format of the fp32x3 product (every 8 consecutive k = [8 x fp16 hi | 8 x fp16 lo] of s_j*w, s_j = s * 2^d_j as above)
 __global__ void pack_conv_w_tapmajor_split_kernel(const float* __restrict__ w, half_t* __restrict__ dst, const float* __restrict__ scale,
                                                   int Cout, int Cin, int cin_pad, int ldk) {
     const float s = scale[0];
