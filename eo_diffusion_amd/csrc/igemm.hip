@@ -119,7 +119,7 @@ template <> struct Mma<float> {
 // Scaling (exact powers of two, undone by alpha in the epilogue):
 //   * weights: s = 2^k per tensor with max|w|*s in (2^12, 2^13], times 2^d_j per output row so that EVERY row's maximum lies there (pack
 //     time, device side: csrc/misc.hip row_exp_kernel; the epilogues multiply column j by 2^-d_j) -> every output channel keeps 22 bits
-//     within 2^-17 of the largest one;
+//     (inside a row: every weight within 2^-17 of the row's largest one);
 //   * activations: per IMAGE, s_a = 2^k derived in the kernel from the bound table of the tensor (common.h: eod_gn_finalize /
 //     eod_act_bound write an upper bound B of max|x| per image; B s_a in [2^14, 2^15)), so every element of a tensor of any magnitude
 //     stays inside the fp16 range and lo_a resolves 2^-34 of the image's largest element or better.  This holds for EVERY consumer,
