@@ -528,3 +528,28 @@ def test_unet_with_dead_and_loud_channels_in_front_of_every_groupnorm(i):
         u = u.to(DEV).eval()
         out = u(x.to(DEV), t.to(DEV), cond=cond.to(DEV) if cond is not None else None, y=y.to(DEV) if y is not None else None).cpu()
     assert torch.isfinite(out).all() and rel_l2(out, ref) < GATE, (i, rel_l2(out, ref))
+
+
+def test_split_weight_pack_keeps_22_bits_of_every_row():
+    """the packed image itself (eod_pack_conv_weight_split): [tap][Cout][Cin/8][8 x hi | 8 x lo] fp16 of s * 2^d_j * w with the scale buffer
+    {s, 1/(16 s), -, -, d_0 ... d_{Cout-1}}: decoded, every row reproduces its fp32 weights to 2^-21 of the ROW's maximum over 30 decades of
+    row magnitudes, zero rows stay zero (d = 0), and every row's largest |s_j w| lies in (2^12, 2^13]"""
+    Cout, Cin, k = 96, 40, 3
+    g = torch.Generator().manual_seed(3)
+    mag = 10.0 ** (torch.rand(Cout, generator=g) * 30 - 15)
+    w = synth_input("pkw", (Cout, Cin, k, k), 5) * mag[:, None, None, None]
+    w[7] = 0.0
+    prog = Program(DEV, "fp32x3")
+    dst, scale = prog.pack_conv(w.to(DEV)).split()
+    torch.cuda.synchronize()
+    s = float(scale[0])
+    d = scale.view(torch.int32)[_lib.WSCALE_ROWS:_lib.WSCALE_ROWS + Cout].cpu()
+    assert float(scale[1]) == 1.0 / (16.0 * s) and int(d[7]) == 0 and int(d.min()) == 0 and int(d.max()) <= 100
+    img = dst.view(torch.float16).view(k * k, Cout, Cin // 8, 2, 8).float().cpu()     # [tap][co][group][hi|lo][8]
+    rec = (img[:, :, :, 0] + img[:, :, :, 1]).reshape(k * k, Cout, Cin).permute(1, 2, 0).reshape(Cout, Cin, k, k).double()
+    sj = s * torch.pow(torch.tensor(2.0, dtype=torch.float64), d.double())
+    top = (w.double().abs().flatten(1).amax(1) * sj)
+    live = top > 0
+    assert bool(((top[live] > 2.0 ** 12) & (top[live] <= 2.0 ** 13)).all())
+    err = ((rec / sj[:, None, None, None] - w.double()).abs().flatten(1).amax(1) / w.double().abs().flatten(1).amax(1).clamp_min(1e-300))
+    assert float(err[live].max()) < 2.0 ** -21 and float(rec[7].abs().max()) == 0.0
