@@ -882,6 +882,7 @@ def _forward_graph(self, prog, x, timesteps, cond, y):
               "out": th.empty(prog.out_shape, dtype=th.float32, device=dev)}
         prog.set_binding("x", st["x"].data_ptr())
         prog.set_binding("t", st["t"].data_ptr())
+        prog.set_binding("t_f32", 0)  # the captured program reads the int64 slot (an earlier fractional-timestep call may have left 1 here)
         prog.set_binding("out", st["out"].data_ptr())
         if cond is not None:
             st["cond"] = th.empty(tuple(cond.shape), dtype=th.float32, device=dev)

@@ -84,6 +84,7 @@ struct IgemmP {
     const char* b2;  // packed [Cout][SC0 + SC1] (the 1x1 weight; split mode: same scale as `b`)
     int SC0, SC1, skc0, skc1;
     int n_base;  // halo kernel: first output column of this launch (a conv of 384 columns runs as a 256-column and a 128-column launch)
+    int tpw;     // halo kernel, STREAM instances: consecutive pixel tiles (of one image and one N-tile) per workgroup; the others: 1
     // split-fp16 products: bound tables (common.h) of the activation operands -> a power-of-two operand scale per image, derived in
     // the kernel.  conv: a_bound [N][32] of the conv input, skip_bound of the fused skip conv's input; gemm (x3): a_bound / b_bound
     // [nb0][32] of the two operands.  NULL = fixed scale 16 (the caller guarantees |x| < 4094).
@@ -252,6 +253,24 @@ extern "C" int eod_debug_read_stamps(unsigned long long* host, int n) {
 }
 #else
 #define EOD_STAMP_AT(k) do { } while (0)
+#endif
+#ifdef EOD_TSTAMP
+// Diagnostic build only (-DEOD_TSTAMP, tools/debug/halo_timeline.py): wave 1 of a workgroup stamps the shader clock at four points of every
+// K-step of its second chunk (into the 512 filler bytes behind the last patch row of that chunk's buffer), copied to a buffer of its own
+// when the chunk ends.
+__device__ unsigned long long g_eod_tstamp[2048][40];
+extern "C" int eod_debug_read_tstamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_eod_tstamp), (size_t)n * 40 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#define EOD_TSTAMP_AT(idx)                                                                                      \
+    do {                                                                                                        \
+        if (GN && wave == 1 && cc == 1 && k == 0) {                                                             \
+            const unsigned long long ts_ = __builtin_amdgcn_s_memtime();                                        \
+            if (lane == 0) reinterpret_cast<unsigned long long*>(sA + ABUF + PR * 128)[idx] = ts_;              \
+        }                                                                                                       \
+    } while (0)
+#else
+#define EOD_TSTAMP_AT(idx) do { } while (0)
 #endif
 // XCD-aware tile mapping (bijective remap, guide T1)
 __device__ __forceinline__ void map_tile(const IgemmP& p, int& tile_m, int& tile_n) {
@@ -1131,7 +1150,7 @@ __device__ __forceinline__ void prefetch_bcol(const IgemmP& p, int ncols, int co
     }
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false, bool STREAM = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void conv3x3_halo_kernel(const IgemmP p) {
     static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M == 2), "fused skip conv: 16x16x32 instances of the 8x16 tile");
     static_assert(!SPLIT || (sizeof(T) == 4 && MS == 16), "the split-fp16 product is a mode of fp32 storage, on 16x16x32 MFMAs");
@@ -1139,6 +1158,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     constexpr bool XF = GN || SPLIT;  // the staged patch pieces are rewritten in place by the wave that DMA'd them
     // fp32-storage split instances (not the 32-column NCHW head): swapped MFMA operands + stores straight from the accumulators
     constexpr bool DIRECT = SPLIT && MS == 16 && BN >= 64;
+    // STREAM: a workgroup runs p.tpw consecutive pixel tiles of one image as ONE stream of chunks: the last chunk of tile k stages
+    // chunk 0 of tile k + 1 (patch pieces, their normalise / split pass, the first weight tile) exactly like any other next chunk, so
+    // only the first tile of a workgroup pays the prologue (DMA round trip + rewrite of the whole patch with the matrix pipe idle:
+    // 5.9 of a 48 us workgroup life on the 36-step layers, tools/debug/halo_stamps.py).  Needs an epilogue that leaves the operand
+    // ring alone (DIRECT); the fused skip phase reuses the ring and stays single-tile.
+    static_assert(!STREAM || (DIRECT && !SKIP && !UPS), "streaming instances: direct epilogue, no fused skip phase");
     constexpr int NW = WAVES_M * WAVES_N;      // 4 waves: 8x16 tile, 8 waves: 16x16 tile
     // WAVES_N = 4 (BN = 256): the 8x16 pixel tile with EIGHT waves, 2 x 4, each still 64 x 64 -- one workgroup covers the two N-tiles of a
     // 256-column conv, so the patch is fetched from HBM and normalised / split ONCE for both (one 8-wave workgroup per CU instead of two
@@ -1153,7 +1178,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / MS, TN = WN / MS;
     constexpr int GB = BN / 8, LB = GB / NW;
     constexpr int ABUF = PG * 1024, BSTAGE = BN * BKB;
-    static_assert(GB % NW == 0 && LAH <= 6 && (BSTAGES == 2 || BSTAGES == 3), "layout");
+    static_assert(GB % NW == 0 && LAH <= 6 && BSTAGES == 2, "layout");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sA = smem;              // [2][ABUF]
@@ -1166,8 +1191,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     int tile_m, tile_n;
     map_tile(p, tile_m, tile_n);
+    int ntile = 1;  // STREAM: tiles tile_m .. tile_m + ntile - 1 (the launcher keeps a run inside one image)
+    if constexpr (STREAM) {
+        tile_m *= p.tpw;
+        ntile = min(p.tpw, p.tiles_m - tile_m);
+    }
     const int n0 = p.n_base + tile_n * BN;
-    const TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode: ty0, tx0, n_first
+    TileGeom g = make_geom<true, BM>(p, tile_m);  // patch mode: ty0, tx0, n_first (of the tile whose K loop runs)
     // epilogue operands fetched NOW (their latency passes under the prologue's DMA; older than every DMA, so the counted vmcnt waits of
     // the loop are unaffected): per-column bias terms and the weights' scale
     float pre_bcol[DIRECT ? 1 : TN];
@@ -1211,13 +1241,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
 #pragma unroll
     for (int i = 0; i < LAH; ++i) {
         const int prow = (wave + NW * i) * 8 + srow;
-        const int py = prow / PW, px = prow - py * PW;
-        const int hi = (UPS ? g.ty0 / 2 : g.ty0) - 1 + py, wi = (UPS ? g.tx0 / 2 : g.tx0) - 1 + px;
-        const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        if (ok) pvalid |= 1u << i;
-        ppix[i] = (unsigned)(hi * p.W + wi);
+        const int px = prow - (prow / PW) * PW;
         pck |= (unsigned)(sslot ^ ((px >> 1) & 7)) << (3 * i);
     }
+    // pixel index / validity of this lane's patch rows for the tile at (ty0, tx0) (STREAM: called again for the next tile of the run)
+    auto set_tile_pieces = [&](const TileGeom& tg) {
+        pvalid = 0;
+#pragma unroll
+        for (int i = 0; i < LAH; ++i) {
+            const int prow = (wave + NW * i) * 8 + srow;
+            const int py = prow / PW, px = prow - py * PW;
+            const int hi = (UPS ? tg.ty0 / 2 : tg.ty0) - 1 + py, wi = (UPS ? tg.tx0 / 2 : tg.tx0) - 1 + px;
+            const bool ok = (wave + NW * i) < PG && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            if (ok) pvalid |= 1u << i;
+            ppix[i] = (unsigned)(hi * p.W + wi);
+        }
+    };
+    set_tile_pieces(g);
     auto pchunk_of = [&](int i) { return (int)((pck >> (3 * i)) & 7u); };
     unsigned b_v[LB];
 #pragma unroll
@@ -1373,12 +1413,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
 
     const int KC = p.kc0 + p.kc1;
     const int NSTEP = KC * 9;
-    // next-chunk lookup for the weight prefetch: step -> (chunk, tap)
-    auto issue_weights_for_step = [&](int st) {
-        const int c = st / 9, t = st - c * 9;
-        issue_weights(t, chunk_of(c), sB + (st % BSTAGES) * BSTAGE);
-    };
-    // ---- prologue: whole patch of chunk 0 + weights of the first BSTAGES-1 steps ----
+    const int TSTEP = NSTEP * ntile;  // K-steps of the whole run of tiles
+    // ---- prologue: whole patch of chunk 0 + weights of the first step ----
     {
         const Chunk c0 = chunk_of(0);
 #pragma unroll
@@ -1387,9 +1423,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         if constexpr (GN) {
             if (wave == 0) issue_ss(c0, sS);
         }
-#pragma unroll
-        for (int st = 0; st < BSTAGES - 1; ++st)
-            if (st < NSTEP) issue_weights_for_step(st);
+        issue_weights(0, c0, sB);
         if constexpr (XF) {
             // chunk 0: everything has to land before the first tap anyway; normalise / split the own pieces now
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1401,40 +1435,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         }
     }
     // DMA issued AFTER the weights of the step we are about to wait for may stay in flight (vmcnt retires in order):
-    //   pp1 / pp2 : a patch piece was issued one / two steps ago;  ww1 : weights were issued one step ago (3-stage ring)
+    //   pp1 : patch pieces (and wave 0's scale / shift table) issued one step ago, behind that step's weights
     EOD_STAMP_AT(1);
-    int pp1 = 0, pp2 = 0;
-    bool ww1 = BSTAGES == 3 && NSTEP > 1 && !XF;  // (XF: the prologue already drained everything)
-    int step = 0;
+    int pp1 = 0;
+    int step = 0;   // K-step of the run (weight stage = step & 1)
+    int qpar = 0;   // patch buffer (and scale / shift table) of the current chunk
+    for (int k = 0; k < ntile; ++k) {
     for (int cc = 0; cc < KC; ++cc) {
         const Chunk cur = chunk_of(cc);
-        const bool has_next = cc + 1 < KC;
-        const Chunk nxt = chunk_of(has_next ? cc + 1 : cc);
-        const char* abuf = sA + (cc & 1) * ABUF;
-        char* abuf_next = sA + ((cc + 1) & 1) * ABUF;
+        // the chunk behind this one in the stream: the tile's next one, or chunk 0 of the run's next tile
+        const bool next_tile = STREAM && cc + 1 == KC && k + 1 < ntile;
+        const bool has_next = cc + 1 < KC || next_tile;
+        const Chunk nxt = chunk_of(cc + 1 < KC ? cc + 1 : (next_tile ? 0 : cc));
+        if constexpr (STREAM) {
+            if (next_tile) set_tile_pieces(make_geom<true, BM>(p, tile_m + k + 1));  // this chunk's taps stage the NEXT tile's patch
+        }
+        const char* abuf = sA + qpar * ABUF;
+        char* abuf_next = sA + (qpar ^ 1) * ABUF;
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++step) {
-            {
-                const int allow = (BSTAGES == 3 ? (pp2 + (ww1 ? LB : 0)) : 0) + pp1;
-                switch (allow) {
-                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                }
+            // (STREAM: the first step of a later tile was waited for and fenced in front of the previous tile's epilogue, see below)
+            EOD_TSTAMP_AT(4 * t + 0);
+            if (!(STREAM && t == 0 && cc == 0 && k > 0)) {
+                if (pp1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (pp1 == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                if constexpr (XF) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): in-place normalisation / split writes are done
+                __builtin_amdgcn_s_barrier();
             }
-            if constexpr (XF) __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): in-place normalisation / split writes are done
-            __builtin_amdgcn_s_barrier();
-            // DMA for step + BSTAGES - 1: weights first, then (taps 0..LAH-1) one piece of the next chunk's patch
-            pp2 = pp1;
-            ww1 = false;
-            if (step + BSTAGES - 1 < NSTEP) {
-                issue_weights_for_step(step + BSTAGES - 1);
-                ww1 = true;
-            }
+            EOD_TSTAMP_AT(4 * t + 1);
+            // DMA for the next step: weights first, then (taps 0..LAH-1) one piece of the next chunk's patch
+            if (step + 1 < TSTEP) issue_weights(t < 8 ? t + 1 : 0, t < 8 ? cur : nxt, sB + ((step + 1) & 1) * BSTAGE);
             pp1 = 0;
             if (t < LAH && has_next && (wave + NW * t) < PG) {
                 issue_patch_piece(t, nxt, abuf_next);
@@ -1442,13 +1473,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
             }
             if constexpr (GN) {
                 if (t == 0 && has_next && wave == 0) {
-                    issue_ss(nxt, sS + ((cc + 1) & 1) * 1024);
+                    issue_ss(nxt, sS + (qpar ^ 1) * 1024);
                     ++pp1;
                 }
             }
+            EOD_TSTAMP_AT(4 * t + 2);
             // ---- MFMAs of tap t: A fragments = patch rows shifted by (dy, dx) ----
             const int dy = t / 3, dx = t - dy * 3;
-            const char* bst = sB + (step % BSTAGES) * BSTAGE;
+            const char* bst = sB + (step & 1) * BSTAGE;
             int arow[TM], asw[TM];  // (32x32x16 paths; the 16x16x32 ones read through acur)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -1535,22 +1567,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * (sizeof(T) == 4 ? 4 : 1), 0);
             }
             }
+            EOD_TSTAMP_AT(4 * t + 3);
             if constexpr (XF) {
                 // piece (t-2) of the NEXT chunk was issued two steps ago and is covered by this step's vmcnt wait;
                 // the scale/shift table (wave 0, tap 0) became visible with this step's barrier (t >= 2).
                 // (spreading these ~110 VALU ops into the MFMA gaps with sched_group_barrier was measured: 3 % SLOWER)
                 if (t >= 2 && t - 2 < LAH && has_next && (wave + NW * (t - 2)) < PG)
-                    transform_piece(t - 2, nxt, abuf_next, sS + ((cc + 1) & 1) * 1024);
+                    transform_piece(t - 2, nxt, abuf_next, sS + (qpar ^ 1) * 1024);
             }
         }
+        EOD_TSTAMP_AT(36);
+#ifdef EOD_TSTAMP
+        if (GN && wave == 1 && cc == 1 && k == 0 && blockIdx.x < 2048) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane < 37) g_eod_tstamp[blockIdx.x][lane] = reinterpret_cast<const unsigned long long*>(sA + ABUF + PR * 128)[lane];
+        }
+#endif
         if constexpr (MS == 16) {  // the next chunk reads the other patch buffer
-            const int flip = (cc & 1) ? -ABUF : ABUF;
+            const int flip = qpar ? -ABUF : ABUF;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 acur[0][dx] += flip;
                 acur[1][dx] += flip;
             }
         }
+        qpar ^= 1;
     }
     if constexpr (SKIP) {
         // ---- 1x1 skip conv over the block input: GEMM-layout ring in the same LDS, K-step = 32 / 64 channels of one source ----
@@ -1664,8 +1705,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
+    if constexpr (STREAM) {
+        // The direct epilogue leaves LDS alone.  Before it, the first barrier of the NEXT tile: this wave's DMA for that tile's first step
+        // has landed (the weights issued at the last tap; nothing younger is in flight) and every wave is done with the last tap's reads
+        // -- so the epilogue's loads and stores are never waited for by a counted vmcnt of the loop before they are a K-step old.
+        if (k + 1 < ntile) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
+    }
     EOD_STAMP_AT(2);
     if constexpr (SPLIT) {
         IgemmP pe = p;
@@ -1674,6 +1726,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     } else {
         igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
+    }
+    if constexpr (STREAM) {
+        if (k + 1 < ntile) {
+            g = make_geom<true, BM>(p, tile_m + k + 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < AccLayout<MS>::R; ++r) acc[i][j][r] = 0.0f;
+        }
+    }
     }
     EOD_STAMP_AT(3);
 }
@@ -2322,12 +2386,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 //   head              EOD_HEAD=0               the output head on the 32-column halo instance instead of conv_head_kernel
 //   halo_bn256        EOD_HALO_BN256=0         256- / 512-column convs as two 4-wave workgroups per pixel tile instead of one 8-wave one
 //   gn_fuse_max_cout  EOD_GN_FUSE_MAX_COUT=n   widest conv that takes its input GroupNorm in its patch staging (-1: the defaults)
+//   halo_tpw          EOD_HALO_TPW=n           pixel tiles per workgroup of the streaming halo instances (0: chosen per launch, 1: off)
 // (Round 2's EOD_IGEMM_CFG / EOD_MFMA_SHAPE / EOD_HALO_SPLIT_N / EOD_CONV_PARITY arms were measured slower and are gone: the fp16
 // products run on v_mfma_f32_16x16x32_f16, 384-column convs as 256 + 128, zero-insertion convs as four parity-class launches.)
-enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_COUNT };
-static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout"};
-static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT"};
-static int g_opt[OPT_COUNT] = {1, 1, 1, -1};
+enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_COUNT };
+static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw"};
+static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT", "EOD_HALO_TPW"};
+static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 0};
 static bool g_opt_init = false;
 static int opt(int k) {
     if (!g_opt_init) {
@@ -2414,7 +2479,7 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false, bool STREAM = false>
 static int launch_halo(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int NW = WAVES_M * WAVES_N, BM = WAVES_N == 4 ? 64 * WAVES_M : 32 * NW, TH = BM / 16;
@@ -2423,7 +2488,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128 + (GN ? 2048 : 0);
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP, STREAM>;
     if constexpr (SKIP) {
         p.skc0 = (p.SC0 + BK - 1) / BK;
         p.skc1 = (p.SC1 + BK - 1) / BK;
@@ -2442,7 +2507,24 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     p.tiles_pw = p.Wo / 16;
     p.tiles_pi = p.tiles_pw * (p.Ho / TH);
     p.tiles_m = p.tiles_pi * p.N;
-    const long long nblk = (long long)p.tiles_m * p.tiles_n;
+    // streaming instances (the kernel's STREAM): runs of tpw consecutive pixel tiles of one image per workgroup.  Which workgroup
+    // computes a tile never changes its result (same K order, same MFMAs, its own statistics slot), so the choice may depend on the batch.
+    p.tpw = 1;
+    if constexpr (SPLIT && MS == 16 && BN >= 128 && !SKIP && !UPS) {
+        const long long slots = 256LL * (NW == 4 ? 2 : 1);  // co-resident workgroups of the chip
+        int want = opt(OPT_HALO_TPW);
+        if (want <= 0) {  // at least two rounds of workgroups stay (measured on 256 x 256 and 128 x 128 maps: 4 ... 8 tiles per run tie)
+            want = 1;
+            while (want < 8 && (long long)p.tiles_m * p.tiles_n / (2 * want) >= 2 * slots) want *= 2;
+        }
+        while (want > 1 && p.tiles_pi % want) --want;
+        if constexpr (!STREAM) {
+            if (want > 1) return launch_halo<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP, true>(p, st);
+        } else {
+            p.tpw = want;
+        }
+    }
+    const long long nblk = (long long)(p.tiles_m / p.tpw) * p.tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffLL) {
         eod_set_error("conv_halo: bad grid %lld", nblk);
         return EOD_EINVAL;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(1024) void absmax_scale_kernel(const float* __restr
 // s_j = s * 2^d_j with d_j = E - e_j >= 0 the distance of the row's binary exponent e_j from the tensor's E, so that EVERY row's largest
 // value lies in (2^12, 2^13] and every row keeps its own 22 bits -- with the tensor scale alone a row 2^18 times smaller than the
 // largest one starts to lose bits (fp16 subnormals) and an output channel (a whole GroupNorm group, once renormalised) can be off by
-// 1e-4 ... 1 where the reference's fp32 product is exact.  d_j (int32, clamped to 100, 0 for an all-zero row) is stored at
+// 1e-4 ... 1 where the reference's fp32 product is exact.  d_j (int32, clamped to min(100, E + 109), 0 for an all-zero row) is stored at
 // scale[EOD_WSCALE_ROWS + j]; the conv epilogues multiply column j by 2^-d_j on top of scale[1].  One wave per row.
 constexpr int EOD_WSCALE_ROWS = 4;  // float slots in front of the per-row exponents (keeps them 16-byte aligned)
 __global__ __launch_bounds__(256) void row_exp_kernel(const float* __restrict__ w, long long row_len, const float* __restrict__ w2,
@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void row_exp_kernel(const float* __restrict__ 
             int e;
             frexpf(m, &e);
             const int E = 13 - ilogbf(scale[0]);  // scale[0] = 2^(13 - E)
-            d = min(max(E - e, 0), 100);
+            // d <= E + 109 keeps the row's pack scale 2^(13 - E + d) finite and the epilogue's 2^(E - 17 - d) a normal fp32 number when
+            // the whole tensor is tiny (max |w| < 2^-9: E < -9); rows further down lose bits gradually, as fp32 itself does there
+            d = min(max(E - e, 0), min(100, max(E + 109, 0)));
         }
         reinterpret_cast<int*>(scale)[EOD_WSCALE_ROWS + j] = d;
     }

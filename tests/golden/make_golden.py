@@ -2,6 +2,8 @@
 """Generate the golden fixtures under tests/golden/ by IMPORTING the reference in the build container.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [/root/reference] [training | training_13ch | ldm_tables | keyframe_lr | full_chain | train_loop | make_label | api_names]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py /root/reference --check     (regenerate EVERYTHING into a scratch
+        directory and compare with the committed fixtures, array by array, bit for bit; the log of the last run: tests/golden/CHECK.log)
 
 The reference never travels to the GPU box; only the .npz / .json data written here does.
 Harness-side adaptations (NOT reference behaviour):
@@ -24,6 +26,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = HERE  # where the generators write (--check: a scratch directory)
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 sys.path.insert(0, ROOT)
 sys.path.insert(1, REF)
@@ -59,7 +62,7 @@ def save(name, **arrs):
         if isinstance(v, torch.Tensor):
             v = v.detach().cpu().numpy()
         out[k] = np.asarray(v)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -223,7 +226,7 @@ def gen_unets():
         if cond is not None:
             arrs.update(cond=cond, y=y)
         save("unet_" + name, **arrs)
-    with open(os.path.join(HERE, "unet_cfgs.json"), "w") as f:
+    with open(os.path.join(OUT, "unet_cfgs.json"), "w") as f:
         json.dump(UNETS, f, indent=1)
 
 
@@ -245,7 +248,7 @@ def gen_keys():
         m = EODiffusion(u, timesteps=1000, image_size=kw["image_size"], in_channels=3)
         out[name] = {"cfg": kw, "unet": {k: list(v.shape) for k, v in u.state_dict().items()},
                      "eodiffusion": {k: list(v.shape) for k, v in m.state_dict().items()}}
-    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
         json.dump(out, f)
 
 
@@ -412,7 +415,7 @@ def gen_training(names=("u_a0_tiny", "u_a1_tiny", "u_film_updown", "u_cond_cls",
             dots.append(float((g * direction).sum()))
         arrs.update(grad_norm=np.asarray(norms), grad_dot=np.asarray(dots))
         save("train_grads_" + name, **arrs)
-        with open(os.path.join(HERE, "train_grads_" + name + "_keys.json"), "w") as f:
+        with open(os.path.join(OUT, "train_grads_" + name + "_keys.json"), "w") as f:
             json.dump(names, f)
 
 
@@ -440,15 +443,21 @@ def keyframe_frames(name, case):
 def gen_keyframe_lr():
     """KeyframeLR (script_utils/train_utils.py:17-226) run by the reference: the learning rate of `end` + 2 consecutive steps (the last
     two lie behind the schedule) and sample_lrs(25), for train.py's own schedule and three that exercise the shorthand forms"""
+    standins = []
     for name, mods in (("pytorch_lightning", ("Callback",)), ("pytorch_lightning.callbacks", ("ModelCheckpoint",)), ("timm", ()),
                        ("timm.utils", ()), ("timm.utils.model", ("get_state_dict", "unwrap_model")), ("utils", ("ExponentialMovingAverage",))):
         m = types.ModuleType(name)
         for attr in mods:
             setattr(m, attr, type(attr, (), {}))
-        sys.modules.setdefault(name, m)
+        if sys.modules.setdefault(name, m) is m:
+            standins.append(name)
     sys.path.insert(1, os.path.join(REF, "script_utils"))
     import train_utils as RT
     assert RT.__file__.startswith(REF), RT.__file__
+    # the stand-ins (the empty `utils` above all) and the module bound to them must not outlive this generator: gen_train_loop and
+    # gen_make_label import the reference's REAL script_utils/utils.py under the same name
+    for name in standins + ["train_utils"]:
+        sys.modules.pop(name, None)
     out = {}
     for name, case in KEYFRAME_CASES.items():
         opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
@@ -606,7 +615,7 @@ def gen_train_loop(steps=12, lr=1e-3, posmax=4, decay=0.9):
         pm, pe = m.model(xp, tp), ema.module.model(xp, tp)
     # the checkpoint train.py:137-138 would write at this point: its key layout (names, shapes, dtypes) and the EMA's update counter
     ckpt = {"model": m.state_dict(), "model_ema": ema.state_dict()}
-    with open(os.path.join(HERE, "checkpoint_layout_u_a1_tiny.json"), "w") as f:
+    with open(os.path.join(OUT, "checkpoint_layout_u_a1_tiny.json"), "w") as f:
         json.dump({part: {k: [list(v.shape), str(v.dtype)] for k, v in sdict.items()} for part, sdict in ckpt.items()}, f)
     n_avg = int(ckpt["model_ema"]["n_averaged"])
     print("  losses", " ".join(f"{v:.5f}" for v in losses))
@@ -647,12 +656,52 @@ def gen_api_names():
                 if isinstance(node, ast.ClassDef):
                     names += [f"{node.name}.{b.name}" for b in node.body if isinstance(b, ast.FunctionDef)]
         out[rel] = names
-    with open(os.path.join(HERE, "api_names.json"), "w") as f:
+    with open(os.path.join(OUT, "api_names.json"), "w") as f:
         json.dump(out, f, indent=1)
+
+
+def check_against_committed(tmp):
+    """every file the generators wrote into `tmp` against its committed twin: .npz array by array (names, dtypes, shapes, bytes), .json
+    by parsed value; returns the number of mismatches"""
+    bad, narr = 0, 0
+    produced = sorted(os.listdir(tmp))
+    for fn in produced:
+        ref = os.path.join(HERE, fn)
+        if not os.path.exists(ref):
+            print(f"  NOT COMMITTED  {fn}")
+            bad += 1
+            continue
+        if fn.endswith(".npz"):
+            a, b = np.load(os.path.join(tmp, fn)), np.load(ref)
+            same = sorted(a.files) == sorted(b.files)
+            for k in (a.files if same else []):
+                narr += 1
+                same = same and a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and a[k].tobytes() == b[k].tobytes()
+        else:
+            with open(os.path.join(tmp, fn)) as fa, open(ref) as fb:
+                same = json.load(fa) == json.load(fb)
+        if not same:
+            print(f"  DIFFERS  {fn}")
+            bad += 1
+    committed = sorted(f for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
+    for fn in committed:
+        if fn not in produced:
+            print(f"  NOT REGENERATED  {fn}")
+            bad += 1
+    print(f"check: {len(produced)} files regenerated ({narr} arrays), {len(committed)} committed, {bad} mismatches")
+    return bad
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 2 and sys.argv[2] == "--check":
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            OUT = tmp
+            for g in (gen_schedules, gen_ldm_tables, gen_modules, gen_unets, gen_keys, gen_sampler, gen_training, gen_keyframe_lr, gen_full_chain,
+                      gen_train_loop, gen_make_label, gen_api_names):
+                g()
+            sys.exit(1 if check_against_committed(tmp) else 0)
     if len(sys.argv) > 2 and sys.argv[2] == "api_names":
         gen_api_names()
         print("done")

@@ -1,5 +1,5 @@
-"""CPU (gloo, world_size 2) tests of the sharding / gather logic of eo_diffusion_amd.dist and of the rank
-invariance of the Philox noise source (via its numpy oracle)."""
+"""CPU (gloo; world sizes 2, 3 -- ragged shards -- and 8, the node's size) tests of the sharding / gather logic of
+eo_diffusion_amd.dist, the bucketed gradient average and the rank invariance of the Philox noise source (via its numpy oracle)."""
 import os
 
 import numpy as np
@@ -65,14 +65,58 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [4, 5])
-def test_gloo_world2_gather_matches_single_rank(n_total):
+@pytest.mark.parametrize("world,n_total", [(2, 4), (2, 5), (3, 7), (3, 9), (8, 16), (8, 13), (8, 5)])
+def test_gloo_gather_matches_single_rank(world, n_total):
+    """even and ragged shards, and (8 ranks, 5 samples) ranks that hold NO sample: every rank ends with the tensor one rank alone computes"""
     from oracle.philox_ref import philox_randn
     q = mp.get_context("spawn").Queue()
     port = _free_port()
-    res = _run_ranks(_worker, lambda r: (r, 2, port, n_total, q), q)
+    res = _run_ranks(_worker, lambda r: (r, world, port, n_total, q), q, world=world)
     ref = philox_randn(n_total, 48, 11, 0, 5, 1).reshape(n_total, 3, 4, 4)  # what ONE rank would have produced
-    for r in range(2):
+    for r in range(world):
+        assert np.array_equal(res[r], ref)
+
+
+class _PhiloxModel:
+    """stands in for EODiffusion in sharded_sampling: `sampling` returns noise keyed by the GLOBAL sample index plus what it was handed
+    (its rows of cond and y), so the test sees the offsets, the slices and the gather -- not a UNet"""
+
+    def sampling(self, n, clipped_reverse_diffusion=True, device=None, cond=None, y=None, rng=None, seed=0, sample_offset=0, progress=False):
+        from oracle.philox_ref import philox_randn
+        assert rng == "philox"
+        out = torch.from_numpy(philox_randn(n, 12, seed, sample_offset, 0, 1)).reshape(n, 3, 2, 2)
+        if cond is not None:
+            assert cond.shape[0] == n
+            out = out + cond
+        if y is not None:
+            assert y.shape == (n,)
+            out = out + y.view(n, 1, 1, 1).float()
+        return out
+
+
+def _sharded_worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eo_diffusion_amd.dist import sharded_sampling
+        cond = torch.arange(n_total * 12, dtype=torch.float32).reshape(n_total, 3, 2, 2) * 1e-3
+        y = torch.arange(n_total) * 10
+        full = sharded_sampling(_PhiloxModel(), n_total, seed=9, cond=cond, y=y, device="cpu")
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(3, 7), (8, 16), (8, 11)])
+def test_gloo_sharded_sampling_plumbing(world, n_total):
+    """sharded_sampling over 3 (ragged) and 8 ranks: each rank's slice of the global cond / y, its sample offset into the noise
+    stream and the gather reproduce the single-rank call"""
+    q = mp.get_context("spawn").Queue()
+    port = _free_port()
+    res = _run_ranks(_sharded_worker, lambda r: (r, world, port, n_total, q), q, world=world)
+    cond = torch.arange(n_total * 12, dtype=torch.float32).reshape(n_total, 3, 2, 2) * 1e-3
+    ref = _PhiloxModel().sampling(n_total, cond=cond, y=torch.arange(n_total) * 10, rng="philox", seed=9).numpy()
+    for r in range(world):
         assert np.array_equal(res[r], ref)
 
 
@@ -88,14 +132,15 @@ def _grad_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_gloo_world2_gradient_bucket_is_averaged():
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_gloo_gradient_bucket_is_averaged(world):
     """data-parallel training (config 5): every rank ends with the MEAN of the ranks' flat gradient buckets"""
     q = mp.get_context("spawn").Queue()
     port = _free_port()
-    res = _run_ranks(_grad_worker, lambda r: (r, 2, port, q), q)
-    ref = np.arange(1000, dtype=np.float32) * 1.5
-    for r in range(2):
-        assert np.array_equal(res[r], ref)
+    res = _run_ranks(_grad_worker, lambda r: (r, world, port, q), q, world=world)
+    ref = (torch.arange(1000, dtype=torch.float32) * float(sum(range(1, world + 1))) / world).numpy()
+    for r in range(world):
+        assert np.allclose(res[r], ref, rtol=1e-6, atol=0) and np.array_equal(res[r], res[0])
 
 
 def test_allreduce_mean_is_a_noop_without_a_process_group():

@@ -160,6 +160,57 @@ def test_halo_conv_random_shapes_vs_torch(prec, case):
     assert rel_l2(got, ref) < TOL[prec]
 
 
+STREAM_CASES = [  # N, C0, C1, H, W, Cout, gn : 3x3 convs on the streaming halo instances (128- and 256-column tiles), K tails, several images
+    (2, 128, 0, 32, 32, 128, True), (1, 96, 64, 24, 48, 256, True), (3, 64, 0, 16, 32, 128, False), (2, 40, 0, 32, 16, 384, False),
+    (1, 32, 0, 40, 16, 128, True), (2, 256, 0, 8, 32, 512, True),
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32x3"])
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_halo_stream_runs_are_bit_identical_to_single_tiles(prec, case):
+    """conv3x3_halo_kernel's STREAM form (a workgroup runs several pixel tiles as one stream of chunks: halo_tpw option): outputs and
+    GroupNorm partial sums must be the bits of the one-tile-per-workgroup launch for every run length, with the residual, the per-sample
+    bias and a fused input GroupNorm across a concat seam in play, and stay inside the mode's gate against torch."""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import Act
+    N, C0, C1, H, W, Cout, gn = case
+    xs = [synth_input(f"sx0{case}", (N, C0, H, W), 59, scale=1.5) + 0.3] + ([synth_input(f"sx1{case}", (N, C1, H, W), 59) - 0.2] if C1 else [])
+    C = C0 + C1
+    w = synth_input(f"sw{case}", (Cout, C, 3, 3), 59, scale=1.0 / math.sqrt(C * 9))
+    b = synth_input(f"sb{case}", (Cout,), 59, scale=0.1)
+    res = synth_input(f"sr{case}", (N, Cout, H, W), 59)
+    temb = synth_input(f"st{case}", (N, Cout), 59, scale=0.3)
+    gam = 1.0 + 0.2 * synth_input("sg", (C,), 59)
+    bet = 0.1 * synth_input("se", (C,), 59)
+    L = _lib.lib()
+
+    def run(tpw):
+        prev = L.eod_set_option(b"halo_tpw", tpw)
+        try:
+            prog = Program(DEV, prec)
+            to_act = lambda t: Act(prog.own(t.to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), t.shape[0], H, W, t.shape[1])
+            srcs = [to_act(t) for t in xs]
+            g = (prog.gn_stats(srcs, prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True) if gn and C % 32 == 0 else None
+            y, _ = prog.conv(srcs[0], prog.pack_conv(w.to(DEV)), prog.f32(b.to(DEV)), Cout, x2=srcs[1] if C1 else None, gn=g, stats=True,
+                             res=to_act(res), cbias=prog.f32(temb.to(DEV)), cbias_stride=Cout)
+            prog.run()
+            torch.cuda.synchronize()
+            return y.t.clone(), y.stats[0].clone()
+        finally:
+            L.eod_set_option(b"halo_tpw", prev)
+
+    y1, s1 = run(1)
+    for tpw in (2, 3, 4, 8, 0):
+        yt, st = run(tpw)
+        assert torch.equal(yt, y1) and torch.equal(st, s1), f"run length {tpw}"
+    hin = torch.cat(xs, 1)
+    if gn and C % 32 == 0:
+        hin = F.silu(F.group_norm(hin, 32, gam, bet, eps=1e-5))
+    ref = F.conv2d(hin, w, b, padding=1) + temb[:, :, None, None] + res
+    assert rel_l2(y1.float().permute(0, 3, 1, 2).cpu(), ref) < TOL[prec]
+
+
 @pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
 @pytest.mark.parametrize("gn", [False, True])
 @pytest.mark.parametrize("case", [(2, 128, 8, 16, 128), (1, 96, 16, 32, 192), (3, 64, 24, 16, 256), (1, 640, 16, 16, 160)])

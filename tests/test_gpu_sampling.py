@@ -262,3 +262,19 @@ def test_hipgraph_replay_is_bit_identical():
         g1b = m.model(x1, t1).clone()
         m.model.enable_graph(False)
     assert bits_equal(g1, ref1) and bits_equal(g2, ref2) and bits_equal(g1b, ref1)
+
+
+def test_hipgraph_capture_after_a_fractional_timestep_call():
+    """a call with floating-point timesteps runs un-captured and binds the timestep kernel to the fp32 slot; the first capture afterwards
+    (integer timesteps) must bind it back, or the graph would read the int64 words as fp32 for its whole life"""
+    m = _model("fp16")
+    x1 = synth_input("gx1", (2, 3, 16, 16), 1).to(DEV)
+    t1 = torch.tensor([3, 17], device=DEV)
+    with torch.no_grad():
+        ref1 = m.model(x1, t1).clone()
+        m.model.enable_graph(True)
+        reff = m.model(x1, torch.tensor([2.5, 16.25], device=DEV)).clone()   # un-captured
+        g1 = m.model(x1, t1).clone()                                          # first capture
+        g1b = m.model(x1, t1).clone()                                         # replay
+        m.model.enable_graph(False)
+    assert bits_equal(g1, ref1) and bits_equal(g1b, ref1) and not bits_equal(reff, ref1)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--gn", action="store_true")
     ap.add_argument("--up4", action="store_true", help="upsample shapes through conv_up4_halo_kernel")
     ap.add_argument("--batch", type=int, default=0, help="override the batch size of the shapes (default 16)")
+    ap.add_argument("--tpw", default="", help="comma list of halo_tpw option values (tiles per workgroup of the streaming halo instances) to time in turn")
     ap.add_argument("--presplit", action="store_true", help="fp32x3, 1x1 shapes: the input comes PRE-SPLIT from a normalising pass (the qkv conv behind AttentionBlock.norm)")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -67,17 +68,20 @@ def main():
             out = torch.empty((N, Cout, H, W), dtype=torch.float32, device=dev)
             prog.ops[_i].u.conv.y = out.data_ptr()
         prog.finalize()
-        for _ in range(3): prog.run()
-        torch.cuda.synchronize()
-        # HIP events around the conv op only (the program may hold a statistics / bound-table / normalising op in front of it)
-        prog.enable_timing(a.iters, only=[_i])
-        for _ in range(a.iters): prog.run()
-        torch.cuda.synchronize()
-        runs, ms = prog.read_timing()
-        prog.disable_timing()
-        dt = ms[_i] / runs * 1e-3
-        fl = 2.0 * N * (y.H * y.W if y is not None else H * W) * Cout * Cin * k * k
-        print(f"{name:8s} {a.prec}{' gn' if gn else ''}{' presplit' if x.presplit else ''} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
+        for tpw in ([int(v) for v in a.tpw.split(",")] if a.tpw else [None]):
+            if tpw is not None:
+                prog.L.eod_set_option(b"halo_tpw", tpw)
+            for _ in range(3): prog.run()
+            torch.cuda.synchronize()
+            # HIP events around the conv op only (the program may hold a statistics / bound-table / normalising op in front of it)
+            prog.enable_timing(a.iters, only=[_i])
+            for _ in range(a.iters): prog.run()
+            torch.cuda.synchronize()
+            runs, ms = prog.read_timing()
+            prog.disable_timing()
+            dt = ms[_i] / runs * 1e-3
+            fl = 2.0 * N * (y.H * y.W if y is not None else H * W) * Cout * Cin * k * k
+            print(f"{name:8s} {a.prec}{' gn' if gn else ''}{' presplit' if x.presplit else ''}{'' if tpw is None else f' tpw {tpw:2d}'} {dt*1e3:8.3f} ms  {fl/dt/1e12:8.1f} TF/s", flush=True)
 
 if __name__ == "__main__":
     main()
