@@ -20,8 +20,11 @@ GPU, RCCL) BEFORE touching the GPU and relays their output; under the driver's o
 an error, never a silent single-rank run.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (MFMA implicit-GEMM conv kernel, per-launch
-HIP-event timing on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on the
-host cores on a bounded sample of the same workload, plus BASELINE config 1 -- MNIST, T = 200 -- end to end).
+HIP-event timing on the launch stream inside the timed region; `roofline.hbm_bound` = the HBM-bound kernels of the step -- first conv,
+head conv, GroupNorm apply, Philox noise, DDPM update -- each with its algorithmic bytes, duration and GB/s against the 8 TB/s peak),
+`cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample of the same workload, plus BASELINE config 1 -- MNIST,
+T = 200 -- end to end), and short labelled runs of the other BASELINE configurations' step: `config2` (A0 @ 64 x 64, batch 16),
+`config3` (A1 @ 256 x 256, batch 8, masked DDIM step) and `train_fp16` (the training step of config 5's path at A0 @ 256 x 256, batch 16).
 """
 import argparse
 import json
@@ -187,6 +190,124 @@ def parity_probe(m, arch, size):
             f"{m.model.precision}", "probe_output": got}
 
 
+def is_hbm_bound_op(s):
+    """program ops whose roof is HBM: the thin-input first conv, the 3-channel head conv, GroupNorm apply passes"""
+    if s["kind"] == "gn_apply":
+        return True
+    return s["kind"] == "conv" and (s.get("kernel") == "conv_head_kernel" or "256x256 4->" in s["label"] or s["label"].endswith("->3"))
+
+
+def sampler_kernels_hbm(m, shape, dev, iters=20):
+    """eod_randn_philox and eod_ddpm_step, back to back between two events on the stream they are launched on (torch's current stream)"""
+    n = 1
+    for d in shape:
+        n *= d
+    x = m._philox(shape, dev, 2, 0, 5, 0)
+    t = torch.full((shape[0],), 500, dtype=torch.int64, device=dev)
+    out = []
+    for name, fn, nbytes in (("randn_philox", lambda: m._philox(shape, dev, 3, 0, 7, 1), 4 * n),
+                             ("ddpm_step", lambda: m._ddpm_update(x, x, x, t, clip=True), 4 * 4 * n)):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        sec = e0.elapsed_time(e1) / iters * 1e-3
+        out.append({"kernel": name, "op": f"{shape[0]}x{shape[1]}x{shape[2]}x{shape[3]} fp32", "bytes_algorithmic": nbytes, "ms": sec * 1e3,
+                    "GB/s": nbytes / sec / 1e9, "frac": nbytes / sec / HBM_PEAK})
+    return out
+
+
+def short_config_runs(dev, steps=5, warmup=2):
+    """labelled step times of the other BASELINE configurations (driver-run, a few steps each): config 2 = A0 @ 64 x 64, batch 16,
+    DDPM step; config 3 = A1 @ 256 x 256, batch 8, one masked (RePaint) DDIM step of a 250-step schedule, through the sampler's own loop"""
+    out = {}
+    with torch.no_grad():
+        m = build_model("A0", 64, "fp32x3", dev)
+        shape = (16, 3, 64, 64)
+        x = m._philox(shape, dev, 2, 0, m.timesteps, 0)
+
+        def step(x, i):
+            noise = m._philox(shape, dev, 3, 0, i, 1)
+            t = torch.full((16,), i, dtype=torch.int64, device=dev)
+            return m._ddpm_update(x, m.model(x, t), noise, t, clip=True)
+        for i in range(warmup):
+            x = step(x, 999 - i)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            x = step(x, 900 - i)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        out["config2"] = {"workload": "A0 @ 64x64x3, batch 16, DDPM step (Philox noise + UNet + clipped update), fp32x3", "steps": steps,
+                          "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt, "achieved_tflops": 642.1e9 / dt / 1e12,
+                          "frac": 642.1e9 / dt / PEAK["fp32x3"], "outputs_finite": bool(torch.isfinite(x).all())}
+        del m, x
+        torch.cuda.empty_cache()
+        from eo_diffusion_amd.diffusion.ddim import DDIMSampler
+        m = build_model("A1", 256, "fp32x3", dev)
+        smp = DDIMSampler(m)
+        g = torch.Generator().manual_seed(4)
+        gt = torch.rand((8, 3, 256, 256), generator=g).to(dev)
+        mask = torch.ones((8, 1, 256, 256))
+        mask[:, :, 64:160, 96:200] = 0.0
+        mask = mask.to(dev)
+        S = 250
+        per = []
+        for rep, nst in ((0, warmup), (1, steps)):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            # `nst` steps of the 250-step schedule (timesteps = n keeps the first n - 1 entries of the table, ddim.py:126-128)
+            xs, _ = smp.sample(S, 8, (3, 256, 256), eta=0.0, mask=mask, x0=gt, verbose=False, timesteps=nst + 1, progress=False)
+            torch.cuda.synchronize(dev)
+            per.append((time.perf_counter() - t0) / nst)
+        out["config3"] = {"workload": "A1 @ 256x256x3, batch 8, masked (RePaint) DDIM step of a 250-step schedule through DDIMSampler.sample "
+                                      "(schedule tables + x_T draw included in the call), fp32x3", "steps": steps, "ms_per_step": per[1] * 1e3,
+                          "steps_per_s": 1.0 / per[1], "achieved_tflops": 8818.7e9 / per[1] / 1e12, "frac": 8818.7e9 / per[1] / PEAK["fp32x3"],
+                          "outputs_finite": bool(torch.isfinite(xs).all())}
+        del m, smp, xs
+        torch.cuda.empty_cache()
+    return out
+
+
+def short_train_run(dev, steps=5, warmup=2):
+    """the training step of config 5's path (fp16 storage, fp16 MFMA) at A0 @ 256 x 256, batch 16: forward + MSE + backward + fused AdamW"""
+    from eo_diffusion_amd.optim import AdamW, mse_loss
+    from eo_diffusion_amd.training import UNetTrainer
+    m = build_model("A0", 256, "fp16", dev)
+    unet = m.model.train()
+    opt = AdamW(unet.parameters(), lr=1e-4)
+    tr = UNetTrainer(unet, 16, 256, 256, dev, loss_scale=1024.0)
+    g = torch.Generator(device=dev).manual_seed(100)
+    x = torch.rand((16, 3, 256, 256), device=dev, generator=g)
+    noise = torch.randn((16, 3, 256, 256), device=dev, generator=g)
+    t = torch.randint(0, m.timesteps, (16,), device=dev, generator=g)
+
+    def one():
+        pred = tr.forward(m._forward_diffusion(x, t, noise), t)
+        loss, dpred = mse_loss(pred, noise)
+        tr.backward(dpred, allreduce=False)
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        loss = one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    fl = 3.0 * sum(o.get("flops", 0.0) for o in tr.prog.op_stats())
+    res = {"workload": "training step, A0 @ 256x256x3, batch 16: q_sample + UNet forward + MSE + backward + fused AdamW, fp16 storage / fp16 MFMA, "
+                       "fp32 accumulate and master weights", "steps": steps, "ms_per_step": dt * 1e3, "steps_per_s": 1.0 / dt,
+           "images_per_s": 16.0 / dt, "achieved_tflops": fl / dt / 1e12, "frac": fl / dt / PEAK["fp16"], "loss_finite": bool(torch.isfinite(loss).all())}
+    del tr, opt, m
+    torch.cuda.empty_cache()
+    return res
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
@@ -250,7 +371,8 @@ def time_sampling(args, m, dev, rank, world, use_dist, dist, timing=True):
             # HIP events only around the dominant kernel's launches (an event pair idles the stream for ~8 us; bracketing
             # all ~130 ops of a step would cost ~1.3 ms/step).  --dump-ops times every op instead.
             stats0 = prog.op_stats()
-            only = None if args.dump_ops else [k for k, s in enumerate(stats0) if s.get("kernel") in ("conv3x3_halo_kernel", "conv_up4_halo_kernel")]
+            only = None if args.dump_ops else [k for k, s in enumerate(stats0) if s.get("kernel") in ("conv3x3_halo_kernel", "conv_up4_halo_kernel")
+                                               or is_hbm_bound_op(s)]
             prog.enable_timing(args.steps, only=only)
         barrier()
         t0 = time.perf_counter()
@@ -264,7 +386,10 @@ def time_sampling(args, m, dev, rank, world, use_dist, dist, timing=True):
         barrier()
         dt = time.perf_counter() - t0
     if gathered is not None:  # (outside the timed region) the collective really delivered this rank's shard
+        ones = torch.ones((1,), dtype=torch.float32, device=x_t.device)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         time_sampling.collective = {"op": "all_gather_into_tensor", "backend": dist.get_backend(), "world": world,
+                                    "ranks_seen": int(ones.item()),
                                     "bytes_per_rank": x_t.numel() * 4, "device": str(gathered.device),
                                     "own_shard_bit_equal": bool(torch.equal(gathered[rank * N:(rank + 1) * N], x_t))}
     if use_dist:
@@ -306,6 +431,16 @@ def time_sampling(args, m, dev, rank, world, use_dist, dist, timing=True):
                                       "launches_per_step": len(up4), "kernel_ms_per_step": usec * 1e3,
                                       "algorithmic_tflops": ufl / usec / 1e12, "executed_tflops": uex / usec / 1e12,
                                       "frac_executed": uex / usec / peak, "kernel_share_of_step": usec / (dt / args.steps)}
+        # the HBM-bound kernels of the step against the HBM peak (north_star: "HBM GB/s ... against CDNA4 peak"): program ops from the same
+        # HIP events, the two sampler kernels from event pairs of their own around back-to-back launches (outside the timed region)
+        hb = []
+        for s_, t_ in zip(stats, ms):
+            if is_hbm_bound_op(s_) and t_ > 0:
+                sec = t_ / runs * 1e-3
+                hb.append({"kernel": s_.get("kernel") or s_["kind"], "op": s_["label"], "bytes_algorithmic": s_["bytes"], "ms": sec * 1e3,
+                           "GB/s": s_["bytes"] / sec / 1e9, "frac": s_["bytes"] / sec / HBM_PEAK})
+        hb += sampler_kernels_hbm(m, (N, 3, S, S), dev)
+        roof["hbm_bound"] = hb
         if args.dump_ops:
             roof["all_conv_launches"] = {"launches_per_step": len(allconv), "ms_per_step": asec * 1e3,
                                          "achieved_tflops": afl / asec / 1e12, "frac": afl / asec / peak}
@@ -318,6 +453,8 @@ def time_sampling(args, m, dev, rank, world, use_dist, dist, timing=True):
                 if key in prof:
                     # NOT measured in this run: HBM bytes per launch from a committed rocprofv3 --pmc pass over the same command
                     # (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); file and commit of origin are named in it
+                    roof["traffic"] = prof[key]["bytes_per_launch"]
+                    roof["traffic_unit"] = "bytes per launch (algorithmic: %.0f)" % prof[key]["algorithmic_bytes_per_launch"]
                     roof["traffic_from_profile"] = prof[key]
             except Exception:
                 pass
@@ -437,6 +574,13 @@ def main():
         if roof:
             res["roofline"] = roof
         res.update(secondary)
+        if world == 1 and not stub and not args.no_secondary and (args.arch, S, N) == ("A0", 256, 16):
+            for name, fn in (("configs", lambda: short_config_runs(dev)), ("train_fp16", lambda: short_train_run(dev))):
+                try:
+                    r_ = fn()
+                    res.update(r_ if name == "configs" else {name: r_})
+                except Exception as e:  # the headline stands on its own; say why an extra is missing
+                    res[name] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and not stub:
             res["cpu_baseline"] = cpu_baseline(args.arch, S, N)
         print(json.dumps(res), flush=True)

@@ -161,6 +161,9 @@ class EodError(RuntimeError):
     pass
 
 
+ABI_VERSION = 104  # EOD_ABI_VERSION of the include/eodiff.h this file mirrors
+
+
 def lib():
     """Load libeodiff.so once.  Raises if it is missing: the HIP extension is mandatory."""
     global _lib
@@ -178,6 +181,8 @@ def lib():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
+    if L.eod_version() != ABI_VERSION and os.environ.get("EOD_ABI_ANY", "0") != "1":  # (EOD_ABI_ANY=1: A/B tooling against an older build)
+        raise EodError(f"ABI mismatch: {LIB_PATH} was built for revision {L.eod_version()} of include/eodiff.h, this binding mirrors {ABI_VERSION}")
     for kind, st in ((1, ConvDesc), (2, GemmDesc), (3, TembDesc), (4, SmallDesc), (5, Op), (6, AttnDesc)):
         if L.eod_struct_size(kind) != C.sizeof(st):
             raise EodError(f"ABI mismatch: struct kind {kind}: C {L.eod_struct_size(kind)} vs ctypes {C.sizeof(st)}")

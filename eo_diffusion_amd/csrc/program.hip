@@ -32,7 +32,7 @@ void eod_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* eod_last_error(void) { return g_err; }
-extern "C" int eod_version(void) { return 100; }
+extern "C" int eod_version(void) { return EOD_ABI_VERSION; }
 extern "C" int eod_struct_size(int kind) {
     switch (kind) {
         case 1: return (int)sizeof(eod_conv_desc);

@@ -38,11 +38,12 @@ def require_gpu(t, what):
 
 class Act:
     """Channels-last activation handle: tensor of shape [N, H, W, C] in the storage dtype."""
-    __slots__ = ("t", "N", "H", "W", "C", "stats", "bound", "presplit")
+    __slots__ = ("t", "N", "H", "W", "C", "stats", "bound", "presplit", "csum")
 
     def __init__(self, t, N, H, W, C, stats=None):
         self.t, self.N, self.H, self.W, self.C = t, N, H, W, C
         self.stats = stats  # (fp32 tensor [N][P][C][2], P): GroupNorm partial sums emitted by the producing conv
+        self.csum = None   # training: (fp32 [N][P][C][2], P) per-channel sums a GroupNorm backward emitted with this gradient tensor
         self.bound = None   # fp32x3 programs: bound table [N][32] of this tensor once something has produced one (Program.bound_of)
         self.presplit = False  # fp32x3: the tensor holds [8 x fp16 hi | 8 x fp16 lo] groups of s_n * x (s_n from `bound`), for ONE
         #                        split-fp16 consumer on the generic conv kernel (eod_conv_desc.x_presplit); nothing else can read it
@@ -120,28 +121,9 @@ class Program:
     # ------------------------------------------------------------------ memory
     def empty(self, shape, dtype=None, zero=False):
         dtype = dtype or self.tdtype
-        if os.environ.get("EOD_DEBUG_TAIL_ALLOC", "0") == "1":  # debug allocator of the tests
-            t = self._empty_at_segment_end(shape, dtype, zero)
-        else:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
         self.keep.append(t)
         self.nbytes += t.numel() * t.element_size()
-        return t
-
-    def _empty_at_segment_end(self, shape, dtype, zero):
-        """EOD_DEBUG_TAIL_ALLOC=1 (tests only): every program buffer ENDS where its own allocator segment ends (requests of 10 MiB and
-        more get a segment of exactly their rounded size from torch's caching allocator), so that a kernel reading or writing past the
-        logical end of a buffer leaves the mapped range and faults on EVERY run instead of on the rare layout where the buffer happens
-        to be the last one of a segment (the per-sample bias read of round 3: tests/test_gpu_fuzz_archs.py)."""
-        shape = (int(shape),) if isinstance(shape, int) else tuple(int(v) for v in shape)
-        nbytes = max(16, int(math.prod(shape)) * torch.empty((), dtype=dtype).element_size())
-        seg = ((nbytes + (2 << 20) - 1) // (2 << 20)) * (2 << 20) + (10 << 20)
-        base = torch.empty((seg,), dtype=torch.uint8, device=self.device)
-        self.keep.append(base)
-        start = (seg - nbytes) & ~15
-        t = base[start:start + int(math.prod(shape)) * torch.empty((), dtype=dtype).element_size()].view(dtype).view(shape)
-        if zero:
-            t.zero_()
         return t
 
     def act(self, N, H, W, C, zero=False):

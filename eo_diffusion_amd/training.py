@@ -780,8 +780,8 @@ class UNetTrainer:
         if direct:
             # bias / timestep-projection gradients = per-channel sums of dY, taken from the NHWC tensor in place
             HW = Ho * Wo
-            if dy.stats is not None:  # the gradient came straight out of a GroupNorm backward, which summed its channels on the way
-                csum, Pn = dy.stats
+            if getattr(dy, "csum", None) is not None:  # the gradient came straight out of a GroupNorm backward, which summed its channels on the way
+                csum, Pn = dy.csum
             else:
                 Pn = max(1, min(256, HW // 64))
                 csum = bp.empty((N, Pn, dy.C, 2), torch.float32)
@@ -888,12 +888,16 @@ class UNetTrainer:
             dx = bp.act(s.N, s.H, s.W, s.C)
             prev = self._pop_single(s)
             # per-channel sums of dx on the way: if dx turns out to be the whole output gradient of the conv that produced s, that conv's
-            # bias / timestep-projection gradients come from them (no pass of their own over dY)
-            Ps = L.eod_gn_bwd_apply_slabs(dt, N, HW, s.C)
-            cs = bp.empty((N, Ps, s.C, 2), torch.float32, zero=True)
+            # bias / timestep-projection gradients come from them (no pass of their own over dY).  Only the direct backward-weights path
+            # (fp16 storage) reads them: elsewhere the kernel skips the reduction.  (dx.csum, not Act.stats: the forward engine reads that
+            # field as {sum, sum of squares} slots.)
+            cs, Ps = None, 0
+            if self.prog.precision == "fp16":
+                Ps = L.eod_gn_bwd_apply_slabs(dt, N, HW, s.C)
+                cs = bp.empty((N, Ps, s.C, 2), torch.float32, zero=True)
             self._call(L.eod_gn_bwd_apply, ptr(s.t), ptr(dy.t), ptr(rec.ss), ptr(coef), ptr(prev.t) if prev is not None else 0, dt,
                        N, HW, s.C, ctot, coff, int(rec.silu), ptr(dx.t), ptr(cs))
-            dx.stats = (cs, Ps)
+            dx.csum = (cs, Ps) if cs is not None else None
             self._add_grad(s, dx)
             coff += s.C
 

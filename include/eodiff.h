@@ -30,6 +30,12 @@ extern "C" {
 enum { EOD_F32 = 0, EOD_F16 = 1 };
 
 const char* eod_last_error(void);
+/* ABI revision of this header: bumped whenever an entry point's arguments, a descriptor layout or the size / meaning of a caller-provided
+ * state buffer changes (round 3 -> 4: eod_gn_finalize, eod_gn_apply, eod_gn_bwd_apply, eod_attention_fwd_nat, the 4 + Cout slot weight-scale
+ * buffer of eod_pack_conv_weight_split, the 4-int state of eod_adamw_step_guarded).  eod_version() returns the value the library was built
+ * with; a binding compares it with the header it mirrors at load time (eo_diffusion_amd/_lib.py does) instead of finding out by an
+ * out-of-bounds device write. */
+#define EOD_ABI_VERSION 104
 int eod_version(void);
 /* Kernel-selection options ("skip_fuse", "head", "halo_bn256": 1 / 0; "gn_fuse_max_cout": n, -1 = default): every option has one
  * measured-best default, the other arm computes the same function on another kernel (same-box A/B runs, per-switch parity tests).

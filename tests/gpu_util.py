@@ -30,3 +30,25 @@ def run_program(prec, x_nchw, emit):
 def load_into(module, sd):
     missing = module.load_state_dict(sd, strict=True)
     return module.to(DEV).eval()
+
+
+def program_empty_at_segment_end(self, shape, dtype=None, zero=False):
+    """test-side replacement of engine.Program.empty (monkeypatched in by the `tail_alloc` fixture): every program buffer ENDS where its
+    own allocator segment ends (requests of 10 MiB and more get a segment of exactly their rounded size from torch's caching allocator),
+    so that a kernel reading or writing past the logical end of a buffer leaves the mapped range and faults on EVERY run instead of on
+    the rare layout where the buffer happens to be the last one of a segment (the per-sample bias read of round 3)."""
+    import math
+    dtype = dtype or self.tdtype
+    shape = (int(shape),) if isinstance(shape, int) else tuple(int(v) for v in shape)
+    esz = torch.empty((), dtype=dtype).element_size()
+    nbytes = max(16, int(math.prod(shape)) * esz)
+    seg = ((nbytes + (2 << 20) - 1) // (2 << 20)) * (2 << 20) + (10 << 20)
+    base = torch.empty((seg,), dtype=torch.uint8, device=self.device)
+    self.keep.append(base)
+    start = (seg - nbytes) & ~15
+    t = base[start:start + int(math.prod(shape)) * esz].view(dtype).view(shape)
+    if zero:
+        t.zero_()
+    self.keep.append(t)
+    self.nbytes += seg
+    return t

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.gpu_util import DEV, TOL
+from eo_diffusion_amd.engine import Program
+from tests.gpu_util import DEV, TOL, program_empty_at_segment_end
 from tests.helpers import rel_l2
 from tests.synth import synth_input, synth_state_dict
 
@@ -108,11 +109,11 @@ def test_random_unet_configuration_vs_oracle(i):
 
 @pytest.mark.parametrize("i", range(FIRST, FIRST + N_CASES, 2))
 def test_random_unet_configuration_with_every_buffer_at_a_segment_end(i, monkeypatch):
-    """the same walk under EOD_DEBUG_TAIL_ALLOC=1 (engine.Program._empty_at_segment_end): every program buffer ends where its allocator
+    """the same walk with engine.Program.empty replaced by tests/gpu_util.program_empty_at_segment_end: every program buffer ends where its allocator
     segment ends, so a launch that reads or writes past the logical end of ANY buffer faults here, on every run.  (Round 3: the generic
     conv's epilogue read the per-sample bias row of image N for the rows behind the last image -- harmless on almost every layout,
     a memory fault on the one where the table was the last block of its segment.)"""
-    monkeypatch.setenv("EOD_DEBUG_TAIL_ALLOC", "1")
+    monkeypatch.setattr(Program, "empty", program_empty_at_segment_end)
     cfg, shape, errs = _run_case(i)
     for prec, e in errs.items():
         assert e < TOL[prec], (i, prec, e, cfg, shape)
@@ -176,7 +177,7 @@ def _train_case(i, prec):
 def test_random_unet_training_step_vs_oracle(i, prec, monkeypatch):
     """every parameter gradient of a random configuration (odd widths, 2-4 levels, attention anywhere, FiLM / updown / plain resampling,
     class and concat conditioning, non-square maps) against torch autograd of the oracle; program buffers at segment ends (see above)"""
-    monkeypatch.setenv("EOD_DEBUG_TAIL_ALLOC", "1")
+    monkeypatch.setattr(Program, "empty", program_empty_at_segment_end)
     cfg, shape, e_pred, worst, checked = _train_case(i, prec)
     print(f"train case {i} [{prec}]: N,H,W = {shape}, {cfg}: pred {e_pred:.2e}, worst of {checked} gradients {worst[1]:.2e} ({worst[0]})")
     assert e_pred < (2e-5 if prec == "fp32" else 1e-2)

@@ -66,7 +66,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/eodiff.h but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert L.eod_version() >= 100
+    assert L.eod_version() == _lib.ABI_VERSION
 
 
 def test_conv_geometry_queries_are_pure_host_predicates():

@@ -1,11 +1,13 @@
 #!/bin/bash
 # Collects, in ONE invocation on the GPU box (through gpurun, from the repo root), every artefact profiles/README.md describes for a round:
-#   bash tools/collect_profiles.sh r03 [A|B]  -> gpurun_out/r03_*   (then, in the build container: python tools/collect_profiles_summarise.py r03
-#                                                copies / condenses what is judged into profiles/)
+#   gpurun -- "EOD_TREE=$(git rev-parse --short HEAD) bash tools/collect_profiles.sh r04 [A|B]"  -> gpurun_out/r04_*
+#   (then, in the build container: python tools/collect_profiles_summarise.py r04 copies / condenses what is judged into profiles/)
+# EOD_TREE stamps the tree id into every header (the GPU box has no .git; expand it in the build container's shell).
 # Every rocprofv3 command has the program itself after `--` (python3 ...), counters in passes of their own (no trace domains with --pmc).
 set -e -o pipefail
 TAG=${1:-rXX}
 PART=${2:-all}   # A = bench lines + end-to-end calls + kernel stats, B = PMC passes + condense (one gpurun call each: 20-minute limit)
+export EOD_TREE=${EOD_TREE:-unstamped}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

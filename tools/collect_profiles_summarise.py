@@ -29,10 +29,14 @@ PEAK = {"fp32x3": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12}
 
 
 def commit():
+    """tree the numbers were measured on: EOD_TREE (the GPU box has no .git: the build container passes `git rev-parse --short HEAD`
+    on the gpurun command line, see collect_profiles.sh), else git here"""
+    if os.environ.get("EOD_TREE"):
+        return os.environ["EOD_TREE"]
     try:
-        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or "?"
     except Exception:
-        return ""
+        return "?"
 
 
 def last_json(path):

@@ -37,10 +37,13 @@ def main():
         raise SystemExit(f"no FETCH_SIZE / WRITE_SIZE rows for '{match}' under {root}: {list(sums)}")
     f_mean = sums["FETCH_SIZE"][0] / sums["FETCH_SIZE"][1]
     w_mean = sums["WRITE_SIZE"][0] / sums["WRITE_SIZE"][1]
-    try:
-        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    except Exception:
-        commit = ""
+    import os
+    commit = os.environ.get("EOD_TREE", "")
+    if not commit:
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            commit = "?"
     data = json.load(open(out)) if os.path.exists(out) else {}
     alg = None
     if len(sys.argv) > 4:  # per-op table of `bench.py --dump-ops`: algorithmic bytes (input + weights + output + residual) of the same launches
