@@ -67,6 +67,7 @@ struct IgemmP {
     float* stats;  // optional GroupNorm partial sums of the output: [N][stats_P][Cout][2]
     int stats_P, tiles_per_image;
     int splitk;    // conv: K-steps are split over gridDim.y workgroups; raw fp32 partial tiles go to `y` (= workspace)
+    int splitk_per;  // halo kernel: channel chunks per K slice (the last slice takes the rest + the fused skip phase)
     float alpha;
     const float* w_scale;  // split-fp16 mode: device {s, 1/(s*A_SCALE)} of the packed weights (eod_pack_conv_weight_split)
     const int* w_rexp;     // ... and its per-row exponents d_j (csrc/misc.hip: row_exp_kernel): column j is multiplied by 2^-d_j on top
@@ -1168,7 +1169,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     // WAVES_N = 4 (BN = 256): the 8x16 pixel tile with EIGHT waves, 2 x 4, each still 64 x 64 -- one workgroup covers the two N-tiles of a
     // 256-column conv, so the patch is fetched from HBM and normalised / split ONCE for both (one 8-wave workgroup per CU instead of two
     // 4-wave ones: the same waves per SIMD): +3.5 ... 10 % on the 256- and 512-column convs.  (The mirror image for 128-column convs -- a
-    // 16 x 16 pixel tile, 4 x 2 waves, halo 1.27x instead of 1.41x and one weight tile per 256 pixels -- measured -1 ... +2 %, and the
+    // 16 x 16 pixel tile, 4 x 2 waves, halo 1.27x instead of 1.41x and one weight tile per 256 pixels -- measured -1 ... +2 % (round 4, fp16
+    // storage, where the weight DMA is the larger share of a K-step: -1 ... +3 %), and the
     // same 2 x 4 form of conv_up4_halo_kernel +0.4 %: neither is used; a three-stage weight ring on this instance: -2 %.)
     constexpr int BM = WAVES_N == 4 ? 64 * WAVES_M : 32 * NW, TH = BM / 16, TW = 16;
     constexpr int PH = UPS ? TH / 2 + 2 : TH + 2, PW = UPS ? TW / 2 + 2 : TW + 2, PR = PH * PW;  // 180 (60) patch rows
@@ -1412,11 +1414,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     }
 
     const int KC = p.kc0 + p.kc1;
-    const int NSTEP = KC * 9;
+    // split-K (maps with too few pixel tiles to fill the chip): gridDim.y workgroups share a tile, each takes a run of channel chunks (all
+    // nine taps of a chunk stay together) and writes a raw fp32 partial tile; the fused skip phase rides in the last one
+    int kc_begin = 0, kc_end = KC;
+    if (p.splitk > 1) {
+        kc_begin = (int)blockIdx.y * p.splitk_per;
+        kc_end = (int)blockIdx.y == p.splitk - 1 ? KC : kc_begin + p.splitk_per;
+    }
+    const int NSTEP = (kc_end - kc_begin) * 9;
     const int TSTEP = NSTEP * ntile;  // K-steps of the whole run of tiles
-    // ---- prologue: whole patch of chunk 0 + weights of the first step ----
+    // ---- prologue: whole patch of the first chunk + weights of the first step ----
     {
-        const Chunk c0 = chunk_of(0);
+        const Chunk c0 = chunk_of(kc_begin);
 #pragma unroll
         for (int i = 0; i < LAH; ++i)
             if ((wave + NW * i) < PG) issue_patch_piece(i, c0, sA);
@@ -1441,12 +1450,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     int step = 0;   // K-step of the run (weight stage = step & 1)
     int qpar = 0;   // patch buffer (and scale / shift table) of the current chunk
     for (int k = 0; k < ntile; ++k) {
-    for (int cc = 0; cc < KC; ++cc) {
+    for (int cc = kc_begin; cc < kc_end; ++cc) {
         const Chunk cur = chunk_of(cc);
-        // the chunk behind this one in the stream: the tile's next one, or chunk 0 of the run's next tile
-        const bool next_tile = STREAM && cc + 1 == KC && k + 1 < ntile;
-        const bool has_next = cc + 1 < KC || next_tile;
-        const Chunk nxt = chunk_of(cc + 1 < KC ? cc + 1 : (next_tile ? 0 : cc));
+        // the chunk behind this one in the stream: the tile's next one, or chunk 0 of the run's next tile (a stream is never split in K)
+        const bool next_tile = STREAM && cc + 1 == kc_end && k + 1 < ntile;
+        const bool has_next = cc + 1 < kc_end || next_tile;
+        const Chunk nxt = chunk_of(cc + 1 < kc_end ? cc + 1 : (next_tile ? 0 : cc));
         if constexpr (STREAM) {
             if (next_tile) set_tile_pieces(make_geom<true, BM>(p, tile_m + k + 1));  // this chunk's taps stage the NEXT tile's patch
         }
@@ -1456,7 +1465,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         for (int t = 0; t < 9; ++t, ++step) {
             // (STREAM: the first step of a later tile was waited for and fenced in front of the previous tile's epilogue, see below)
             EOD_TSTAMP_AT(4 * t + 0);
-            if (!(STREAM && t == 0 && cc == 0 && k > 0)) {
+            if (!(STREAM && t == 0 && cc == kc_begin && k > 0)) {
                 if (pp1 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (pp1 == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1594,6 +1603,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         qpar ^= 1;
     }
     if constexpr (SKIP) {
+      if (p.splitk <= 1 || (int)blockIdx.y == p.splitk - 1) {
         // ---- 1x1 skip conv over the block input: GEMM-layout ring in the same LDS, K-step = 32 / 64 channels of one source ----
         constexpr int LA = BM / 8 / NW;                    // 8-row pieces of the pixel tile per wave (4)
         constexpr int STG_A = BM * BKB, STG = STG_A + BSTAGE;
@@ -1704,6 +1714,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
                 }
             }
         }
+      }
     }
     if constexpr (STREAM) {
         // The direct epilogue leaves LDS alone.  Before it, the first barrier of the NEXT tile: this wave's DMA for that tile's first step
@@ -1719,13 +1730,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         __builtin_amdgcn_s_barrier();        // every wave is done with the operand buffers: reuse them for the epilogue
     }
     EOD_STAMP_AT(2);
+    IgemmP pe = p;
+    if (p.splitk > 1) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;  // raw fp32 partial tile of this K slice (the launcher cleared bias / residual / statistics)
     if constexpr (SPLIT) {
-        IgemmP pe = p;
         pe.alpha = p.alpha * wsc1 * asc.inv;  // undo the weight and activation scales (exact powers of two)
-        if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(p, g, acc, wave, lane, n0, pre_bq, pe.alpha, pre_we);
+        if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, g, acc, wave, lane, n0, pre_bq, pe.alpha, pre_we);
         else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
+    } else if constexpr (sizeof(T) == 2 && !STREAM) {
+        if (p.splitk > 1) igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
+        else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, false, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     } else {
-        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(p, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     }
     if constexpr (STREAM) {
         if (k + 1 < ntile) {
@@ -2387,12 +2402,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 //   halo_bn256        EOD_HALO_BN256=0         256- / 512-column convs as two 4-wave workgroups per pixel tile instead of one 8-wave one
 //   gn_fuse_max_cout  EOD_GN_FUSE_MAX_COUT=n   widest conv that takes its input GroupNorm in its patch staging (-1: the defaults)
 //   halo_tpw          EOD_HALO_TPW=n           pixel tiles per workgroup of the streaming halo instances (0: chosen per launch, 1: off)
+//   halo_splitk       EOD_HALO_SPLITK=0        3x3 convs on maps with fewer than two workgroups per CU unsplit in K (64-column tiles instead)
 // (Round 2's EOD_IGEMM_CFG / EOD_MFMA_SHAPE / EOD_HALO_SPLIT_N / EOD_CONV_PARITY arms were measured slower and are gone: the fp16
 // products run on v_mfma_f32_16x16x32_f16, 384-column convs as 256 + 128, zero-insertion convs as four parity-class launches.)
-enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_COUNT };
-static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw"};
-static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT", "EOD_HALO_TPW"};
-static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 0};
+enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_HALO_SPLITK, OPT_COUNT };
+static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw", "halo_splitk"};
+static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT", "EOD_HALO_TPW", "EOD_HALO_SPLITK"};
+static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 0, 1};
 static bool g_opt_init = false;
 static int opt(int k) {
     if (!g_opt_init) {
@@ -2507,6 +2523,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     p.tiles_pw = p.Wo / 16;
     p.tiles_pi = p.tiles_pw * (p.Ho / TH);
     p.tiles_m = p.tiles_pi * p.N;
+    p.tiles_per_image = p.tiles_pi;  // (statistics slots: tile of the image x WAVES_M)
     // streaming instances (the kernel's STREAM): runs of tpw consecutive pixel tiles of one image per workgroup.  Which workgroup
     // computes a tile never changes its result (same K order, same MFMAs, its own statistics slot), so the choice may depend on the batch.
     p.tpw = 1;
@@ -2518,6 +2535,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
             while (want < 8 && (long long)p.tiles_m * p.tiles_n / (2 * want) >= 2 * slots) want *= 2;
         }
         while (want > 1 && p.tiles_pi % want) --want;
+        if (p.splitk > 1) want = 1;
         if constexpr (!STREAM) {
             if (want > 1) return launch_halo<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP, true>(p, st);
         } else {
@@ -2529,7 +2547,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
         eod_set_error("conv_halo: bad grid %lld", nblk);
         return EOD_EINVAL;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)(p.splitk > 1 ? p.splitk : 1)), dim3(64 * NW), lds, st, p);
     EOD_CHECK_LAUNCH("conv3x3_halo");
     return EOD_OK;
 }
@@ -2629,8 +2647,9 @@ static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
            !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C;
 }
 // 256-column convs with a fused GroupNorm on the 8-wave instance that shares one patch between the two N-tiles (EOD_HALO_BN256=0: off, A/B)
+static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo);
 static bool halo_bn256(const eod_conv_desc* d) {
-    const bool on = opt(OPT_HALO_BN256) != 0;
+    const bool on = opt(OPT_HALO_BN256) != 0 && conv_splitk(d, d->H, d->W, true) <= 1;
     // only where it still fills the chip: one 8-wave workgroup occupies a CU, so fewer than 256 of them leave CUs idle (32 x 32 maps at
     // batch 8: 128 workgroups, measured -20 %; the choice never changes a result: same K order, same MFMAs)
     const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * (d->Cout / 256);
@@ -2641,11 +2660,11 @@ static bool halo_bn256(const eod_conv_desc* d) {
 // at the nominal batch of 16, never from the actual batch -- and the choice never changes a result (same K order, same MFMA tiles).
 static bool halo_bn64(const eod_conv_desc* d) {
     const long long wgs = 16LL * (d->H / 8) * (d->W / 16) * ((d->Cout + 127) / 128);
-    return d->Cout > 64 && !d->upsample && wgs < 256;
+    return d->Cout > 64 && !d->upsample && wgs < 256 && conv_splitk(d, d->H, d->W, true) <= 1;
 }
 // 384, 640, ... columns: all but the last 128 on the 8-wave form, as a launch of its own
 static bool halo_bn256_plus128(const eod_conv_desc* d) {
-    const bool on = opt(OPT_HALO_BN256) != 0;
+    const bool on = opt(OPT_HALO_BN256) != 0 && conv_splitk(d, d->H, d->W, true) <= 1;
     const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * ((d->Cout - 128) / 256);
     return on && d->Cout > 256 && d->Cout % 256 == 128 && !d->upsample && wgs >= 256;
 }
@@ -2686,14 +2705,46 @@ extern "C" int eod_conv_gn_fusable(const eod_conv_desc* d) {
 }
 
 // split-K factor of a conv that the generic kernel would run with too few workgroups to fill the chip (small maps)
+// K slices of a split halo conv: `s` slices of `per` channel chunks, the last one takes the rest + the fused skip phase.  The largest
+// s <= smax whose longest slice stays within 25 % of the mean (K-steps, the skip phase's included); per of that plan is returned.
+static int halo_split_plan(const eod_conv_desc* d, int smax, int* per_out) {
+    const int bk = 128 / eod_esize(d->dtype);
+    const int kc = (d->C0 + bk - 1) / bk + (d->C1 + bk - 1) / bk;
+    const int sk = d->skip_x ? (d->skip_C0 + bk - 1) / bk + (d->skip_C1 + bk - 1) / bk : 0;  // K-steps of the skip phase
+    const int total = kc * 9 + sk;
+    for (int s = smax; s >= 2; --s) {
+        for (int per = (total + 9 * s - 1) / (9 * s); per >= 1 && per >= total / (9 * s); --per) {
+            if (per * (s - 1) >= kc) continue;  // the last slice keeps at least one chunk
+            const int last = (kc - per * (s - 1)) * 9 + sk, longest = last > per * 9 ? last : per * 9;
+            if ((long long)longest * s * 100 <= (long long)total * 125) {
+                if (per_out) *per_out = per;
+                return s;
+            }
+        }
+    }
+    return 1;
+}
 static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo) {
-    if (halo || d->out_nchw_f32 || d->Cout % 4 || d->w_tapmajor) return 1;
     // the factor must NOT depend on the batch size: the K summation order of a sample has to be the same whether it is
     // computed alone or inside a larger batch (bit-exact batch-sharding invariance), so a nominal batch of 16 is used
+    const int bk = 128 / eod_esize(d->dtype);
+    if (halo) {
+        // halo-patch kernel: 128-column tiles of 8 x 16 pixels; fewer than one workgroup per CU (16 x 16 maps at batch 16) -> the channel
+        // chunks are split over gridDim.y workgroups (whole chunks: the nine taps of a chunk share its staged patch).  32 x 32 maps
+        // (256 workgroups) measured SLOWER split in two: the reduce pass costs more than the second workgroup per CU gains.
+        if (!opt(OPT_HALO_SPLITK) || d->out_nchw_f32 || d->upsample || d->Cout <= 64 || d->Cout % 4) return 1;
+        const long long wgs = 16LL * (Ho / 8) * (Wo / 16) * ((d->Cout + 127) / 128);
+        const int kc = (d->C0 + bk - 1) / bk + (d->C1 + bk - 1) / bk;
+        if (wgs >= 256 || kc < 4) return 1;
+        int s = (int)((512 + wgs - 1) / wgs);
+        if (s > kc / 2) s = kc / 2;  // at least two chunks (18 K-steps) per slice
+        if (s > 8) s = 8;
+        return halo_split_plan(d, s, nullptr);
+    }
+    if (d->out_nchw_f32 || d->Cout % 4 || d->w_tapmajor) return 1;
     const long long M = 16LL * Ho * Wo;
     const int bn = d->Cout <= 32 ? 32 : (d->Cout <= 64 ? 64 : 128);
     const long long tiles = ((M + 127) / 128) * ((d->Cout + bn - 1) / bn);
-    const int bk = 128 / eod_esize(d->dtype);
     const int kt = ((d->C0 + bk - 1) / bk + (d->C1 + bk - 1) / bk) * d->ksize * d->ksize;
     if (tiles >= 128 || kt < 8) return 1;
     int s = (int)(512 / tiles);  // two workgroups per CU (same-box A/B on the 64 x 64 configuration: 3.59 -> 3.47 ms per step against 256 / tiles)
@@ -2723,6 +2774,28 @@ extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     const int bm = conv_bm(d, halo);
     if ((Ho * Wo) % bm != 0) return 0;  // tiles must not straddle images
     return (Ho * Wo / bm) * conv_waves_m(d, halo);
+}
+
+// second pass of a split-K conv: sum the gridDim.y raw fp32 partial tiles of the workspace in their fixed order, apply alpha / bias /
+// per-sample bias / residual, store y (and the next GroupNorm's partial sums: one slot per image)
+static int splitk_finish(const eod_conv_desc* d, const IgemmP& p, int splitk, hipStream_t st) {
+    if (d->stats) {  // reduce + the next GroupNorm's partial sums (one slot per image)
+        const dim3 grid((unsigned)((p.Cout + 63) / 64), (unsigned)d->N);
+        if (d->dtype == EOD_F16)
+            hipLaunchKernelGGL(splitk_reduce_stats_kernel<half_t>, grid, dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y, d->stats);
+        else
+            hipLaunchKernelGGL(splitk_reduce_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, d->stats);
+        EOD_CHECK_LAUNCH("splitk_reduce_stats");
+        return EOD_OK;
+    }
+    const long long total4 = p.M * p.Cout / 4;
+    const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+    if (d->dtype == EOD_F16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, (const float*)nullptr);  // (split-fp16 partial tiles arrive un-scaled)
+    EOD_CHECK_LAUNCH("splitk_reduce");
+    return EOD_OK;
 }
 
 extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
@@ -2817,95 +2890,121 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         p.gn_silu = d->gn_silu;
         return d->dtype == EOD_F16 ? launch_head<half_t, false>(p, st) : launch_head<float, true>(p, st);
     }
-    if (d->skip_x) {  // ResBlock 1x1 skip conv fused behind the 3x3 K loop
-        EOD_REQUIRE(conv_skip_geom_ok(d) && halo_ok && d->skip_w, "conv: skip_x needs a geometry for which eod_conv_skip_ok(d) == 1, and skip_w");
-        EOD_REQUIRE((d->skip_C1 > 0) == (d->skip_x2 != nullptr), "conv: skip_x2 / skip_C1 mismatch");
-        EOD_REQUIRE(eod_aligned16(d->skip_x) && eod_aligned16(d->skip_x2) && eod_aligned16(d->skip_w), "conv: 16-byte alignment (skip operands)");
-        {
-            const int es = d->dtype == EOD_F16 ? 2 : 4;
-            const long long smax = d->skip_C0 > d->skip_C1 ? d->skip_C0 : d->skip_C1;
-            EOD_REQUIRE((long long)d->H * d->W * smax * es < 0x7fffffffLL && (long long)d->Cout * (d->skip_C0 + d->skip_C1) * es < 0x7fffffffLL,
-                        "conv: skip operand exceeds the 2 GiB window");
-        }
-        p.sx0 = (const char*)d->skip_x;
-        p.sx1 = (const char*)d->skip_x2;
-        p.b2 = (const char*)d->skip_w;
-        p.SC0 = d->skip_C0;
-        p.SC1 = d->skip_C1;
-        p.gn_ss = d->gn_scale_shift;
-        p.gn_silu = d->gn_silu;
-        if (halo_bn64(d)) {
-            if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 64, 2, 2, false, 2, true, true, 16, true>(p, st)
-                                                     : launch_halo<float, 64, 2, 2, false, 2, false, true, 16, true>(p, st);
-            return d->gn_scale_shift ? launch_halo<half_t, 64, 2, 2, false, 2, true, false, 16, true>(p, st)
-                                     : launch_halo<half_t, 64, 2, 2, false, 2, false, false, 16, true>(p, st);
-        }
-        if (d->w_split && halo_bn256(d))
-            return d->gn_scale_shift ? launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(p, st)
-                                     : launch_halo<float, 256, 2, 4, false, 2, false, true, 16, true>(p, st);
-        if (d->w_split && d->gn_scale_shift && halo_bn256_plus128(d)) {  // 256 columns on the 8-wave form, the last 128 on the 4-wave one
-            IgemmP q = p;
-            q.Ncols = d->Cout - 128;
-            const int rc = launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(q, st);
-            if (rc != EOD_OK) return rc;
-            p.n_base = d->Cout - 128;
-            return launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st);
-        }
-        if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st)
-                                                 : launch_halo<float, 128, 2, 2, false, 2, false, true, 16, true>(p, st);
-        if (d->gn_scale_shift && halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16, true>(p, st);
-        return d->gn_scale_shift ? launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16, true>(p, st)
-                                 : launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16, true>(p, st);
-    }
-    if (halo_ok && d->w_split) {
-        // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)
-        if (d->gn_scale_shift) {
-            EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
+    // ---- halo-patch kernels (3x3 / stride 1 / pad 1 on maps that tile into 8 x 16 patches), with or without the fused skip conv ----
+    constexpr int NOT_HALO = 1 << 20;
+    auto run_halo = [&](IgemmP& p) -> int {
+        if (d->skip_x) {  // ResBlock 1x1 skip conv fused behind the 3x3 K loop
+            EOD_REQUIRE(conv_skip_geom_ok(d) && halo_ok && d->skip_w, "conv: skip_x needs a geometry for which eod_conv_skip_ok(d) == 1, and skip_w");
+            EOD_REQUIRE((d->skip_C1 > 0) == (d->skip_x2 != nullptr), "conv: skip_x2 / skip_C1 mismatch");
+            EOD_REQUIRE(eod_aligned16(d->skip_x) && eod_aligned16(d->skip_x2) && eod_aligned16(d->skip_w), "conv: 16-byte alignment (skip operands)");
+            {
+                const int es = d->dtype == EOD_F16 ? 2 : 4;
+                const long long smax = d->skip_C0 > d->skip_C1 ? d->skip_C0 : d->skip_C1;
+                EOD_REQUIRE((long long)d->H * d->W * smax * es < 0x7fffffffLL && (long long)d->Cout * (d->skip_C0 + d->skip_C1) * es < 0x7fffffffLL,
+                            "conv: skip operand exceeds the 2 GiB window");
+            }
+            p.sx0 = (const char*)d->skip_x;
+            p.sx1 = (const char*)d->skip_x2;
+            p.b2 = (const char*)d->skip_w;
+            p.SC0 = d->skip_C0;
+            p.SC1 = d->skip_C1;
             p.gn_ss = d->gn_scale_shift;
             p.gn_silu = d->gn_silu;
-            if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st);
-            if (halo_bn64(d)) return launch_halo<float, 64, 2, 2, false, 2, true, true, 16>(p, st);
-            if (halo_bn256(d)) return launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(p, st);
-            if (halo_bn256_plus128(d)) {
+            if (halo_bn64(d)) {
+                if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 64, 2, 2, false, 2, true, true, 16, true>(p, st)
+                                                         : launch_halo<float, 64, 2, 2, false, 2, false, true, 16, true>(p, st);
+                return d->gn_scale_shift ? launch_halo<half_t, 64, 2, 2, false, 2, true, false, 16, true>(p, st)
+                                         : launch_halo<half_t, 64, 2, 2, false, 2, false, false, 16, true>(p, st);
+            }
+            if (d->w_split && halo_bn256(d))
+                return d->gn_scale_shift ? launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(p, st)
+                                         : launch_halo<float, 256, 2, 4, false, 2, false, true, 16, true>(p, st);
+            if (d->w_split && d->gn_scale_shift && halo_bn256_plus128(d)) {  // 256 columns on the 8-wave form, the last 128 on the 4-wave one
                 IgemmP q = p;
                 q.Ncols = d->Cout - 128;
-                const int rc = launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(q, st);
+                const int rc = launch_halo<float, 256, 2, 4, false, 2, true, true, 16, true>(q, st);
                 if (rc != EOD_OK) return rc;
                 p.n_base = d->Cout - 128;
+                return launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st);
+            }
+            if (d->w_split) return d->gn_scale_shift ? launch_halo<float, 128, 2, 2, false, 2, true, true, 16, true>(p, st)
+                                                     : launch_halo<float, 128, 2, 2, false, 2, false, true, 16, true>(p, st);
+            if (d->gn_scale_shift && halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16, true>(p, st);
+            return d->gn_scale_shift ? launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16, true>(p, st)
+                                     : launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16, true>(p, st);
+        }
+        if (halo_ok && d->w_split) {
+            // fp32 storage, three fp16 MFMAs per product (weights pre-split and pre-scaled, activations split in LDS)
+            if (d->gn_scale_shift) {
+                EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
+                p.gn_ss = d->gn_scale_shift;
+                p.gn_silu = d->gn_silu;
+                if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, true, true, 16>(p, st);
+                if (halo_bn64(d)) return launch_halo<float, 64, 2, 2, false, 2, true, true, 16>(p, st);
+                if (halo_bn256(d)) return launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(p, st);
+                if (halo_bn256_plus128(d)) {
+                    IgemmP q = p;
+                    q.Ncols = d->Cout - 128;
+                    const int rc = launch_halo<float, 256, 2, 4, false, 2, true, true, 16>(q, st);
+                    if (rc != EOD_OK) return rc;
+                    p.n_base = d->Cout - 128;
+                    return launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st);
+                }
                 return launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st);
             }
-            return launch_halo<float, 128, 2, 2, false, 2, true, true, 16>(p, st);
+            if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st);
+            if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false, true, 16>(p, st);
+            if (halo_bn64(d)) return launch_halo<float, 64, 2, 2, false, 2, false, true, 16>(p, st);
+            return launch_halo<float, 128, 2, 2, false, 2, false, true, 16>(p, st);
         }
-        if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false, true, 16>(p, st);
-        if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false, true, 16>(p, st);
-        if (halo_bn64(d)) return launch_halo<float, 64, 2, 2, false, 2, false, true, 16>(p, st);
-        return launch_halo<float, 128, 2, 2, false, 2, false, true, 16>(p, st);
+        if (halo_ok && d->dtype == EOD_F16) {
+            if (d->gn_scale_shift) {
+                EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
+                p.gn_ss = d->gn_scale_shift;
+                p.gn_silu = d->gn_silu;
+                if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, true, false, 16>(p, st);
+                if (halo_bn64(d)) return launch_halo<half_t, 64, 2, 2, false, 2, true, false, 16>(p, st);
+                if (halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16>(p, st);
+                return launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16>(p, st);
+            }
+            if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, false, false, 16>(p, st);
+            if (d->upsample) return launch_halo<half_t, 128, 2, 2, true, 2, false, false, 16>(p, st);
+            if (halo_bn64(d)) return launch_halo<half_t, 64, 2, 2, false, 2, false, false, 16>(p, st);
+            return launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16>(p, st);
+        }
+        if (halo_ok) {  // exact fp32 (v_mfma_f32_32x32x2_f32 on the same byte-oriented LDS image)
+            if (d->gn_scale_shift) {  // GroupNorm(+SiLU) of the input fused into the patch staging
+                EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
+                p.gn_ss = d->gn_scale_shift;
+                p.gn_silu = d->gn_silu;
+                return d->Cout <= 32 ? launch_halo<float, 32, 4, 1, false, 2, true>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true>(p, st);
+            }
+            if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false>(p, st);  // head conv (out_nchw_f32)
+            if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false>(p, st);
+            return launch_halo<float, 128, 2, 2, false, 2, false>(p, st);
+        }
+        return NOT_HALO;
+    };
+    if (halo_ok) {
+        const int hsk = conv_splitk(d, Ho, Wo, true);
+        if (hsk > 1) {
+            // too few pixel tiles to fill the chip: K slices over gridDim.y workgroups (fp32 partial tiles in the caller's workspace),
+            // then the deterministic reduce + bias / residual (+ statistics) pass
+            EOD_REQUIRE(d->workspace && d->workspace_bytes >= eod_conv_workspace_size(d), "conv: workspace of %lld bytes required (eod_conv_workspace_size)", (long long)eod_conv_workspace_size(d));
+            IgemmP q = p;
+            q.stats = nullptr;
+            q.splitk = hsk;
+            (void)halo_split_plan(d, hsk, &q.splitk_per);
+            q.y = (char*)d->workspace;
+            q.bias = nullptr; q.bias_mode = 0; q.cbias = nullptr; q.res = nullptr; q.alpha = 1.0f;
+            const int rc = run_halo(q);
+            if (rc != EOD_OK) return rc == NOT_HALO ? EOD_EINVAL : rc;
+            return splitk_finish(d, p, hsk, st);
+        }
     }
-    if (halo_ok && d->dtype == EOD_F16) {
-        if (d->gn_scale_shift) {
-            EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
-            p.gn_ss = d->gn_scale_shift;
-            p.gn_silu = d->gn_silu;
-            if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, true, false, 16>(p, st);
-            if (halo_bn64(d)) return launch_halo<half_t, 64, 2, 2, false, 2, true, false, 16>(p, st);
-            if (halo_bn256(d)) return launch_halo<half_t, 256, 2, 4, false, 2, true, false, 16>(p, st);
-            return launch_halo<half_t, 128, 2, 2, false, 2, true, false, 16>(p, st);
-        }
-        if (d->Cout <= 32) return launch_halo<half_t, 32, 4, 1, false, 2, false, false, 16>(p, st);
-        if (d->upsample) return launch_halo<half_t, 128, 2, 2, true, 2, false, false, 16>(p, st);
-        if (halo_bn64(d)) return launch_halo<half_t, 64, 2, 2, false, 2, false, false, 16>(p, st);
-        return launch_halo<half_t, 128, 2, 2, false, 2, false, false, 16>(p, st);
-    }
-    if (halo_ok) {  // exact fp32 (v_mfma_f32_32x32x2_f32 on the same byte-oriented LDS image)
-        if (d->gn_scale_shift) {  // GroupNorm(+SiLU) of the input fused into the patch staging
-            EOD_REQUIRE(!d->upsample, "conv: fused input GroupNorm is not available together with upsample");
-            p.gn_ss = d->gn_scale_shift;
-            p.gn_silu = d->gn_silu;
-            return d->Cout <= 32 ? launch_halo<float, 32, 4, 1, false, 2, true>(p, st) : launch_halo<float, 128, 2, 2, false, 2, true>(p, st);
-        }
-        if (d->Cout <= 32) return launch_halo<float, 32, 4, 1, false, 2, false>(p, st);  // head conv (out_nchw_f32)
-        if (d->upsample) return launch_halo<float, 128, 2, 2, true, 2, false>(p, st);
-        return launch_halo<float, 128, 2, 2, false, 2, false>(p, st);
+    {
+        const int rc = run_halo(p);
+        if (rc != NOT_HALO) return rc;
     }
     EOD_REQUIRE(!d->gn_scale_shift, "conv: fused input GroupNorm needs the halo-patch kernel (ask eod_conv_gn_fusable first)");
     const int splitk = conv_splitk(d, Ho, Wo, false);
@@ -2921,23 +3020,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         const int rc = d->w_split ? launch_conv_split(q, splitk, st)
                                   : d->dtype == EOD_F16 ? launch_T<half_t, true>(q, splitk, st) : launch_T<float, true>(q, splitk, st);
         if (rc != EOD_OK) return rc;
-        if (d->stats) {  // reduce + the next GroupNorm's partial sums (one slot per image)
-            const dim3 grid((unsigned)((p.Cout + 63) / 64), (unsigned)d->N);
-            if (d->dtype == EOD_F16)
-                hipLaunchKernelGGL(splitk_reduce_stats_kernel<half_t>, grid, dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y, d->stats);
-            else
-                hipLaunchKernelGGL(splitk_reduce_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, d->stats);
-            EOD_CHECK_LAUNCH("splitk_reduce_stats");
-            return EOD_OK;
-        }
-        const long long total4 = p.M * p.Cout / 4;
-        const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-        if (d->dtype == EOD_F16)
-            hipLaunchKernelGGL(splitk_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const half_t*)d->res, (half_t*)d->y, (const float*)nullptr);
-        else
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)d->workspace, splitk, p.M, p.Cout, p.HoWo, d->alpha, d->bias, d->cbias, (long long)d->cbias_stride, (const float*)d->res, (float*)d->y, (const float*)nullptr);  // (split-fp16 partial tiles arrive un-scaled)
-        EOD_CHECK_LAUNCH("splitk_reduce");
-        return EOD_OK;
+        return splitk_finish(d, p, splitk, st);
     }
     if (d->w_split) return launch_conv_split(p, 1, st);
     if (conv_parity_ok(d, Ho, Wo)) {

@@ -211,6 +211,69 @@ def test_halo_stream_runs_are_bit_identical_to_single_tiles(prec, case):
     assert rel_l2(y1.float().permute(0, 3, 1, 2).cpu(), ref) < TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
+@pytest.mark.parametrize("case", [  # N, C0, C1, H, W, Cout, gn, skip channels
+    (3, 256, 0, 16, 16, 384, True, 0), (2, 512, 384, 16, 16, 384, True, 0), (2, 384, 0, 16, 16, 384, True, 256), (1, 640, 0, 8, 32, 256, False, 0),
+    (2, 256, 0, 16, 16, 256, True, 512), (3, 136, 0, 16, 16, 200, False, 0),
+])
+def test_halo_conv_split_in_k_vs_torch_and_batch_invariant(prec, case):
+    """3x3 convs on maps with fewer than two workgroups per CU run the halo kernel with its channel chunks split over gridDim.y workgroups
+    (conv3x3_halo_kernel, p.splitk) + the reduce pass: against torch, against the unsplit arm (halo_splitk = 0), with the statistics of
+    the reduce pass, and every image's bits independent of the batch it is computed in (the factor is a function of the per-image geometry)"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import Act
+    N, C0, C1, H, W, Cout, gn, sc = case
+    C = C0 + C1
+    xs = [synth_input(f"kx0{case}", (N, C0, H, W), 61, scale=1.3) + 0.2] + ([synth_input(f"kx1{case}", (N, C1, H, W), 61) - 0.1] if C1 else [])
+    xk = synth_input(f"kxs{case}", (N, max(sc, 8), H, W), 61)
+    w = synth_input(f"kw{case}", (Cout, C, 3, 3), 61, scale=1.0 / math.sqrt(C * 9))
+    b = synth_input(f"kb{case}", (Cout,), 61, scale=0.1)
+    w1 = synth_input(f"kw1{case}", (Cout, max(sc, 8), 1, 1), 61, scale=1.0 / math.sqrt(max(sc, 8)))
+    res = synth_input(f"kr{case}", (N, Cout, H, W), 61)
+    gam, bet = 1.0 + 0.2 * synth_input("kg", (C,), 61), 0.1 * synth_input("ke", (C,), 61)
+    L = _lib.lib()
+
+    def run(n, splitk_on):
+        prev = L.eod_set_option(b"halo_splitk", int(splitk_on))
+        try:
+            prog = Program(DEV, prec)
+            to_act = lambda t: Act(prog.own(t[:n].to(DEV).permute(0, 2, 3, 1).contiguous().to(prog.tdtype)), n, H, W, t.shape[1])
+            srcs = [to_act(t) for t in xs]
+            g = (prog.gn_stats(srcs, prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True) if gn and C % 32 == 0 else None
+            skip = None
+            if sc and prec != "fp32":
+                ax = [to_act(xk)]
+                if prog.conv_skip_ok(srcs[0], Cout, ax):
+                    skip = (ax, w1.to(DEV), None)
+            y, i = prog.conv(srcs[0], prog.pack_conv(w.to(DEV)), prog.f32(b.to(DEV)), Cout, x2=srcs[1] if C1 else None, gn=g, stats=True,
+                             res=None if skip else to_act(res), skip=skip)
+            used = bool(prog.ops[i].u.conv.workspace)
+            prog.run()
+            torch.cuda.synchronize()
+            return y.t.clone(), y.stats[0].clone(), skip is not None, used
+        finally:
+            L.eod_set_option(b"halo_splitk", prev)
+
+    y3, s3, skipped, used = run(N, True)
+    # (fp16 storage has 64-channel chunks: 136 channels are three chunks, and fewer than four stay unsplit; csrc/igemm.hip: conv_splitk)
+    assert used == ((prec, C0) != ("fp16", 136)), "which arm this geometry runs on"
+    y0, _, _, used0 = run(N, False)
+    assert not used0
+    y1, s1, _, _ = run(1, True)
+    assert torch.equal(y1[0], y3[0]) and torch.equal(s1[0], s3[0]), "image 0 differs between batch 1 and the full batch"
+    hin = torch.cat(xs, 1)
+    if gn and C % 32 == 0:
+        hin = F.silu(F.group_norm(hin, 32, gam, bet, eps=1e-5))
+    elif prec == "fp16":
+        hin = hin.half().float()
+    ref = F.conv2d(hin, w, b, padding=1)
+    ref = ref + (F.conv2d(xk.half().float() if prec == "fp16" else xk, w1) if skipped else (res.half().float() if prec == "fp16" else res))
+    got = y3.float().permute(0, 3, 1, 2).cpu()
+    assert rel_l2(got, ref) < TOL[prec] and rel_l2(y0.float().permute(0, 3, 1, 2).cpu(), ref) < TOL[prec]
+    tot = s3.sum(1).cpu()  # [N][Cout][2]: the reduce pass's sums of the stored values
+    assert torch.allclose(tot[..., 0], got.sum((2, 3)), rtol=2e-3, atol=2e-2)
+
+
 @pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
 @pytest.mark.parametrize("gn", [False, True])
 @pytest.mark.parametrize("case", [(2, 128, 8, 16, 128), (1, 96, 16, 32, 192), (3, 64, 24, 16, 256), (1, 640, 16, 16, 160)])
