@@ -190,11 +190,12 @@ __device__ __forceinline__ bool decode_row(const IgemmP& p, const TileGeom& g, i
         nrel = 0;
         ho = g.ty0 + (r >> p.tw_log2);
         wo = g.tx0 + (r & ((1 << p.tw_log2) - 1));
+        const bool inside = wo < p.Wd;  // (halo kernel on 8-wide maps: the right half of the 8 x 16 tile lies behind the map)
         if (p.par) {
             ho = 2 * ho + p.par_y;
             wo = 2 * wo + p.par_x;
         }
-        return true;
+        return inside;
     }
     int rem = g.rem_first + r;
     nrel = 0;
@@ -602,11 +603,12 @@ __device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const Tile
     // channel tile by channel tile (16 channels: this lane's quad c0 + 16 j .. + 3 of the TM pixels 16 i + lp), so that only ONE tile's
     // statistics accumulators and two tiles' residuals are live next to the accumulators (all TN at once: 76 spilled registers)
     long long off[TM];
+    bool rok[TM];  // (8-wide maps: the right half of the tile lies behind the map; every other patch-mode tile is whole)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         int nrel, ho, wo;
-        decode_row<BM>(p, g, wm * WM + i * 16 + lp, nrel, ho, wo);  // patch mode: every row of the tile exists
-        off[i] = (((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo) * p.Cout;
+        rok[i] = decode_row<BM>(p, g, wm * WM + i * 16 + lp, nrel, ho, wo);
+        off[i] = rok[i] ? (((long long)(g.n_first + nrel) * p.Ho + ho) * p.Wo + wo) * p.Cout : 0;
     }
     const int slot = ((p.tw_log2 >= 0) ? (g.tile_m - g.n_first * p.tiles_per_image) : (g.rem_first / BM)) * WAVES_M + wm;
     // pre-split output (the qkv conv in front of the fused attention): [8 x fp16 hi | 8 x fp16 lo] per 8 channels of s_n * y; the lanes
@@ -634,6 +636,9 @@ __device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const Tile
             for (int i = 0; i < TM; ++i) {
                 f32x4 v = acc[i][j] * am + bq[j];
                 if (res) v += rv[j & 1][i];
+                if (!rok[i]) {  // never stored, not part of the statistics
+                    v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 if (ps_scale != 0.0f) {
                     typedef int i32x2 __attribute__((ext_vector_type(2)));
                     half4 h4, l4;
@@ -649,8 +654,8 @@ __device__ __forceinline__ void halo_epilogue_direct(const IgemmP& p, const Tile
                     const int s0 = odd ? hb[0] : lb[0], s1 = odd ? hb[1] : lb[1];   // what the partner needs: my hi (I am odd) / my lo (even)
                     const int r0 = __shfl_xor(s0, 16), r1 = __shfl_xor(s1, 16);
                     const i32x4 w = odd ? i32x4{r0, r1, lb[0], lb[1]} : i32x4{hb[0], hb[1], r0, r1};
-                    *reinterpret_cast<i32x4*>(y + off[i] + (c & ~7) + (odd ? 4 : 0)) = w;
-                } else {
+                    if (rok[i]) *reinterpret_cast<i32x4*>(y + off[i] + (c & ~7) + (odd ? 4 : 0)) = w;
+                } else if (rok[i]) {
                     *reinterpret_cast<f32x4*>(y + off[i] + c) = v;
                 }
                 ss += v;
@@ -1123,7 +1128,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 //     (taps 0..5)].  vmcnt retires in order, so the wait for step s's weights is vmcnt(1) when a patch piece was
 //     issued after them and vmcnt(0) otherwise: every patch piece gets two full K-steps to land.
 //   * everything else (MFMA tiling, buffer-descriptor OOB zero fill, concat sources, epilogue) is shared with igemm.
-// Requirements (checked by the launcher, otherwise the generic kernel runs): ksize 3, stride 1, pad 1, Wo % 16 == 0,
+// Requirements (checked by the launcher, otherwise the generic kernel runs): ksize 3, stride 1, pad 1, Wo % 16 == 0 (or Wo == 8, half tiles),
 // Ho % 8 == 0 (with or without the virtual nearest-2x upsampling of the input).
 // =============================================================================================
 // UPS = true: the conv input is the nearest-2x upsampling of x (Upsample.conv, unet_openai.py:236-241).  The 8x16
@@ -1617,10 +1622,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         // row r of the tile = pixel (ty0 + r / 16, tx0 + r % 16) -- always inside the image; rows use the (row >> 1) & 7 swizzle, which
         // for this lane's pieces is bchunk0 (the weight rows' value)
         unsigned xpix[LA], wv[LB];
+        unsigned xok = 0;  // bit i: the pixel exists (8-wide maps: the right half of the tile lies behind the map)
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int row = (wave + NW * i) * 8 + srow;
             xpix[i] = (unsigned)((g.ty0 + (row >> 4)) * p.W + g.tx0 + (row & 15));
+            if (g.tx0 + (row & 15) < p.W) xok |= 1u << i;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
@@ -1633,7 +1640,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
             const bool ktail = kin + BK > cw;
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
-                unsigned v = xpix[i] * (unsigned)(cw * ES) + bchunk0 * 16;
+                unsigned v = ((xok >> i) & 1u) ? xpix[i] * (unsigned)(cw * ES) + bchunk0 * 16 : EOD_OOB;
                 if (ktail) v = (kin + bchunk0 * EPC < cw) ? v : EOD_OOB;
                 if (src)
                     blds16(rsX1, v, (unsigned)(kin * ES), stg + (wave + NW * i) * 1024);
@@ -2401,14 +2408,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 //   head              EOD_HEAD=0               the output head on the 32-column halo instance instead of conv_head_kernel
 //   halo_bn256        EOD_HALO_BN256=0         256- / 512-column convs as two 4-wave workgroups per pixel tile instead of one 8-wave one
 //   gn_fuse_max_cout  EOD_GN_FUSE_MAX_COUT=n   widest conv that takes its input GroupNorm in its patch staging (-1: the defaults)
-//   halo_tpw          EOD_HALO_TPW=n           pixel tiles per workgroup of the streaming halo instances (0: chosen per launch, 1: off)
+//   halo_tpw          EOD_HALO_TPW=n           pixel tiles per workgroup of the streaming halo instances (1: off = the default; 0: chosen
+//                                              per launch).  Measured (round 4): single layers 3-8 % faster at 4-8 tiles per run, the
+//                                              whole 256 x 256 step 0.4 % SLOWER than off (same-box A/B, three interleaved runs)
 //   halo_splitk       EOD_HALO_SPLITK=0        3x3 convs on maps with fewer than two workgroups per CU unsplit in K (64-column tiles instead)
 // (Round 2's EOD_IGEMM_CFG / EOD_MFMA_SHAPE / EOD_HALO_SPLIT_N / EOD_CONV_PARITY arms were measured slower and are gone: the fp16
 // products run on v_mfma_f32_16x16x32_f16, 384-column convs as 256 + 128, zero-insertion convs as four parity-class launches.)
 enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_HALO_SPLITK, OPT_COUNT };
 static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw", "halo_splitk"};
 static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT", "EOD_HALO_TPW", "EOD_HALO_SPLITK"};
-static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 0, 1};
+static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 1, 1};
 static bool g_opt_init = false;
 static int opt(int k) {
     if (!g_opt_init) {
@@ -2520,7 +2529,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     p.tiles_n = (p.Ncols - p.n_base + BN - 1) / BN;
     p.tw_log2 = 4;  // TH x 16 pixel patches
     p.th = TH;
-    p.tiles_pw = p.Wo / 16;
+    p.tiles_pw = (p.Wo + 15) / 16;
     p.tiles_pi = p.tiles_pw * (p.Ho / TH);
     p.tiles_m = p.tiles_pi * p.N;
     p.tiles_per_image = p.tiles_pi;  // (statistics slots: tile of the image x WAVES_M)
@@ -2591,7 +2600,10 @@ extern "C" int eod_conv_tapmajor_ldk(int C0, int dtype) {
 static bool conv_uses_halo(const eod_conv_desc* d, int Ho, int Wo) {
     // wide convs (128-column tiles) and the narrow NCHW-fp32 head conv (32-column tiles, 4x1 waves)
     const bool shape_ok = ((d->Cout > 64 && !d->out_nchw_f32) || (d->Cout <= 32 && d->out_nchw_f32 && !d->upsample)) && d->upsample != 2;
-    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && Wo % 16 == 0 && Ho % 8 == 0 && shape_ok && !d->w_tapmajor;
+    // (8-wide maps of the wide convs too: one image row per tile row, the right half of the 8 x 16 tile masked -- half the MFMA rows idle, on
+    //  maps whose launches are latency-bound; with the K slices of conv_splitk they leave the generic kernel's 16-way split + gather)
+    const bool w_ok = Wo % 16 == 0 || (Wo == 8 && d->Cout > 64 && !d->out_nchw_f32 && !d->upsample);
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && w_ok && Ho % 8 == 0 && shape_ok && !d->w_tapmajor;
 }
 static int conv_waves_m(const eod_conv_desc* d, bool halo) { return (halo || d->Cout > 64) ? 2 : 4; }
 static int conv_bm(const eod_conv_desc* d, bool halo) { return 128; }
@@ -2652,20 +2664,20 @@ static bool halo_bn256(const eod_conv_desc* d) {
     const bool on = opt(OPT_HALO_BN256) != 0 && conv_splitk(d, d->H, d->W, true) <= 1;
     // only where it still fills the chip: one 8-wave workgroup occupies a CU, so fewer than 256 of them leave CUs idle (32 x 32 maps at
     // batch 8: 128 workgroups, measured -20 %; the choice never changes a result: same K order, same MFMAs)
-    const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * (d->Cout / 256);
+    const long long wgs = (long long)d->N * (d->H / 8) * ((d->W + 15) / 16) * (d->Cout / 256);
     return on && d->Cout % 256 == 0 && !d->upsample && wgs >= 256;
 }
 // few pixel tiles (16 x 16 maps and smaller at batch 16): 64-column N-tiles double the workgroup count of a launch that cannot fill the
 // chip (a 384-column conv on a 16 x 16 map at batch 16 has 32 x 3 = 96 workgroups of 128 columns).  Decided from the PER-IMAGE geometry
 // at the nominal batch of 16, never from the actual batch -- and the choice never changes a result (same K order, same MFMA tiles).
 static bool halo_bn64(const eod_conv_desc* d) {
-    const long long wgs = 16LL * (d->H / 8) * (d->W / 16) * ((d->Cout + 127) / 128);
+    const long long wgs = 16LL * (d->H / 8) * ((d->W + 15) / 16) * ((d->Cout + 127) / 128);
     return d->Cout > 64 && !d->upsample && wgs < 256 && conv_splitk(d, d->H, d->W, true) <= 1;
 }
 // 384, 640, ... columns: all but the last 128 on the 8-wave form, as a launch of its own
 static bool halo_bn256_plus128(const eod_conv_desc* d) {
     const bool on = opt(OPT_HALO_BN256) != 0 && conv_splitk(d, d->H, d->W, true) <= 1;
-    const long long wgs = (long long)d->N * (d->H / 8) * (d->W / 16) * ((d->Cout - 128) / 256);
+    const long long wgs = (long long)d->N * (d->H / 8) * ((d->W + 15) / 16) * ((d->Cout - 128) / 256);
     return on && d->Cout > 256 && d->Cout % 256 == 128 && !d->upsample && wgs >= 256;
 }
 // ResBlock 1x1 skip conv fused behind the 3x3 K loop (conv3x3_halo_kernel<SKIP>; EOD_SKIP_FUSE=0: off, A/B)
@@ -2733,7 +2745,7 @@ static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo) {
         // chunks are split over gridDim.y workgroups (whole chunks: the nine taps of a chunk share its staged patch).  32 x 32 maps
         // (256 workgroups) measured SLOWER split in two: the reduce pass costs more than the second workgroup per CU gains.
         if (!opt(OPT_HALO_SPLITK) || d->out_nchw_f32 || d->upsample || d->Cout <= 64 || d->Cout % 4) return 1;
-        const long long wgs = 16LL * (Ho / 8) * (Wo / 16) * ((d->Cout + 127) / 128);
+        const long long wgs = 16LL * (Ho / 8) * ((Wo + 15) / 16) * ((d->Cout + 127) / 128);
         const int kc = (d->C0 + bk - 1) / bk + (d->C1 + bk - 1) / bk;
         if (wgs >= 256 || kc < 4) return 1;
         int s = (int)((512 + wgs - 1) / wgs);
@@ -2771,6 +2783,7 @@ extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const bool halo = conv_uses_halo(d, Ho, Wo);
     if (conv_splitk(d, Ho, Wo, halo) > 1) return 1;  // split-K: the reduce pass takes the sums, one slot per image
+    if (halo) return (Ho / 8) * ((Wo + 15) / 16) * 2;  // 8 x 16 pixel tiles (8-wide maps: half of each tile masked), two wave rows each
     const int bm = conv_bm(d, halo);
     if ((Ho * Wo) % bm != 0) return 0;  // tiles must not straddle images
     return (Ho * Wo / bm) * conv_waves_m(d, halo);

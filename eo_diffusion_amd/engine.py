@@ -643,7 +643,7 @@ class Program:
                 fl = 2.0 * m * d.Cout * (cin_alg * d.ksize * d.ksize + sc)
                 by = es * (d.N * d.H * d.W * (cin + sc) + d.ksize * d.ksize * d.Cout * cin + d.Cout * sc + (0 if d.out_nchw_f32 else m * d.Cout)) \
                     + (4 * m * d.Cout if d.out_nchw_f32 else 0) + (es * m * d.Cout if d.res else 0)
-                geo = d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and d.Wo % 16 == 0 and d.Ho % 8 == 0
+                geo = d.ksize == 3 and d.stride == 1 and d.pad == 1 and not d.pad_tl and (d.Wo % 16 == 0 or (d.Wo == 8 and d.Cout > 64 and not d.upsample)) and d.Ho % 8 == 0
                 halo = geo and d.Cout > 64 and not d.out_nchw_f32 and not d.w_tapmajor  # mirrors conv_uses_halo() in csrc/igemm.hip
                 head = geo and d.Cout <= 32 and d.out_nchw_f32 and not d.upsample  # 32-column instance (HBM-bound head conv)
                 headk = head and bool(d.gn_scale_shift) and d.Cout <= 16 and d.C1 == 0 and cin <= 384 and self.precision != "fp32" \

@@ -334,7 +334,7 @@ def test_ldm_p_sample_loop_vs_reference_trajectory():
 
 
 # ------------------------------------------------------------------------------------------------ every kernel-selection switch, both arms
-SWITCHES = ["up4", "skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout"]
+SWITCHES = ["up4", "skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw"]
 
 
 @pytest.mark.parametrize("prec", ["fp32x3", "fp16"])
@@ -343,7 +343,8 @@ def test_a0_256_forward_with_each_kernel_switch_off(prec, switch, monkeypatch):
     """Every kernel-selection switch has one default arm (what the other tests of this file run) and one alternative arm that
     computes the same function on other kernels: EOD_UP4=0 (nine-tap convs behind an upsampling), skip_fuse=0 (1x1 skip convs as
     launches of their own), head=0 (the output head on the 32-column halo instance), halo_bn256=0 (256- / 512-column convs on two 4-wave
-    workgroups), gn_fuse_max_cout=0 (every GroupNorm as a separate pass).  Each alternative arm is held to the SAME oracle gate at the
+    workgroups), gn_fuse_max_cout=0 (every GroupNorm as a separate pass), halo_tpw=0 (the streaming halo instances: several pixel tiles
+    per workgroup, run length chosen per launch; the default 1 is the plain one-tile form).  Each alternative arm is held to the SAME oracle gate at the
     metric's image size, and the launch program is checked to really differ from the default one."""
     from eo_diffusion_amd import _lib
     L = _lib.lib()
@@ -365,7 +366,7 @@ def test_a0_256_forward_with_each_kernel_switch_off(prec, switch, monkeypatch):
             prev = L.eod_set_option(switch.encode(), 0)
         u = _unet("A0", 256, prec).to(DEV).eval()
         sig1 = program_signature(u)
-        if switch != "halo_bn256":  # (that one changes the instance inside eod_conv2d_igemm, not the op list)
+        if switch not in ("halo_bn256", "halo_tpw"):  # (those change the instance inside eod_conv2d_igemm, not the op list)
             assert sig1 != sig0, f"{switch}=0 did not change the launch program"
         with torch.no_grad():
             out = u(x.to(DEV), t.to(DEV)).cpu()

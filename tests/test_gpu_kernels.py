@@ -215,6 +215,8 @@ def test_halo_stream_runs_are_bit_identical_to_single_tiles(prec, case):
 @pytest.mark.parametrize("case", [  # N, C0, C1, H, W, Cout, gn, skip channels
     (3, 256, 0, 16, 16, 384, True, 0), (2, 512, 384, 16, 16, 384, True, 0), (2, 384, 0, 16, 16, 384, True, 256), (1, 640, 0, 8, 32, 256, False, 0),
     (2, 256, 0, 16, 16, 256, True, 512), (3, 136, 0, 16, 16, 200, False, 0),
+    # 8-wide maps: one image row per tile row, the right half of the 8 x 16 tile masked
+    (3, 512, 0, 8, 8, 512, True, 0), (2, 512, 512, 8, 8, 512, True, 0), (2, 384, 0, 8, 8, 512, True, 384), (2, 256, 0, 16, 8, 384, False, 0),
 ])
 def test_halo_conv_split_in_k_vs_torch_and_batch_invariant(prec, case):
     """3x3 convs on maps with fewer than two workgroups per CU run the halo kernel with its channel chunks split over gridDim.y workgroups
