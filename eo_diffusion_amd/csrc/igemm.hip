@@ -2658,7 +2658,8 @@ static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
     return on && halo_ok && d->out_nchw_f32 && d->Cout <= 16 && d->gn_scale_shift && d->C1 == 0 && !d->x2 && !d->upsample && !d->res && !d->cbias &&
            !d->stats && store_ok && d->C0 % 8 == 0 && d->C0 <= HEAD_MAX_C;
 }
-// 256-column convs with a fused GroupNorm on the 8-wave instance that shares one patch between the two N-tiles (EOD_HALO_BN256=0: off, A/B)
+// 256-column convs with a fused GroupNorm on the 8-wave instance that shares one patch between the two N-tiles (EOD_HALO_BN256=0: off, A/B).
+// (fp16 storage WITHOUT a fused GroupNorm -- the training step's convs -- measured on it in round 4: 128 x 128 maps -3 %, 32 x 32 +2 %: not used)
 static int conv_splitk(const eod_conv_desc* d, int Ho, int Wo, bool halo);
 static bool halo_bn256(const eod_conv_desc* d) {
     const bool on = opt(OPT_HALO_BN256) != 0 && conv_splitk(d, d->H, d->W, true) <= 1;
