@@ -135,9 +135,12 @@ def main():
     a = ap.parse_args()
     cases = [int(v) for v in a.cases.split(",")] if a.cases else list(range(a.first, a.first + a.count))
     rows = []
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     for i in cases:
         r = study_case(i, a.gate)
         rows.append(r)
+        with open(a.out + ".progress", "a") as pf:   # (a long run must keep writing: one line per case)
+            pf.write(json.dumps([r["case"], r["err_hip_fp16_vs_oracle_fp32"]]) + "\n")
         if r["err_hip_fp16_vs_oracle_fp32"] > a.gate:
             print(f"case {i}: deepest map {r['deepest_map']}, {r['worst_param']}: HIP fp16 vs oracle fp32 {r['err_hip_fp16_vs_oracle_fp32']:.2e} | "
                   f"oracle under fp16 storage vs oracle fp32 {r['err_oracle_fp16_storage_vs_oracle_fp32']:.2e} (its own worst: "
