@@ -1316,23 +1316,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         const unsigned v = lane < 32 ? (unsigned)(lane * 16 + ((c.src ? p.C0 : 0) + c.kin) * 8) : EOD_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void*)ssbuf, 16, v, 0, 0, 0);
     };
-    auto transform_piece = [&](int i, const Chunk& c, char* abuf, const char* ssbuf) {
+    // the rewrite of a piece in two parts: its LDS reads (the piece's 16 bytes of this lane + the scale / shift entries of its channels),
+    // and the arithmetic + write-back
+    struct XfPre {
+        i32x4 raw;
+        f32x4 q[GN ? (ES == 2 ? 4 : 2) : 1];
+    };
+    auto xf_load = [&](int i, char* abuf, const char* ssbuf, XfPre& pre) {
+        const int pc = pchunk_of(i);
+        pre.raw = *reinterpret_cast<const i32x4*>(abuf + (wave + NW * i) * 1024 + lane * 16);
+        if constexpr (GN) {
+            const float* sp = reinterpret_cast<const float*>(ssbuf) + pc * EPC * 2;
+#pragma unroll
+            for (int k = 0; k < (ES == 2 ? 4 : 2); ++k) pre.q[k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
+        }
+    };
+    auto xf_finish = [&](int i, const Chunk& c, char* abuf, const XfPre& pre) {
         const int pc = pchunk_of(i);
         const bool ok = ((pvalid >> i) & 1u) && (!c.ktail || (c.kin + pc * EPC < c.cw));
         char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
-        const i32x4 raw = *reinterpret_cast<const i32x4*>(ptr);
+        const i32x4 raw = pre.raw;
         i32x4 outv = raw;
         if constexpr (GN) {
-            const float* sp = reinterpret_cast<const float*>(ssbuf) + pc * EPC * 2;
             if constexpr (ES == 2) {
                 const half8 h = __builtin_bit_cast(half8, raw);
                 half8 o;
-                f32x4 q[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(sp + 4 * k);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float v = (float)h[e] * q[e >> 1][(e & 1) * 2] + q[e >> 1][(e & 1) * 2 + 1];
+                    float v = (float)h[e] * pre.q[e >> 1][(e & 1) * 2] + pre.q[e >> 1][(e & 1) * 2 + 1];
                     if (p.gn_silu) v = silu_f<true>(v);
                     o[e] = (half_t)v;
                 }
@@ -1340,7 +1351,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
             } else {
                 const f32x4 f = __builtin_bit_cast(f32x4, raw);
                 f32x4 o;
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(sp), q1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const f32x4 q0 = pre.q[0], q1 = pre.q[GN && ES != 2 ? 1 : 0];
                 const float sc[4] = {q0[0], q0[2], q1[0], q1[2]}, sh[4] = {q0[1], q0[3], q1[1], q1[3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1363,6 +1374,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         } else {
             if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
         }
+    };
+    auto transform_piece = [&](int i, const Chunk& c, char* abuf, const char* ssbuf) {
+        XfPre pre;
+        xf_load(i, abuf, ssbuf, pre);
+        xf_finish(i, c, abuf, pre);
     };
     auto issue_weights = [&](int tap, const Chunk& c, char* bst) {
         const unsigned soff = (unsigned)(tap * tapstride) + c.bk;
@@ -1586,6 +1602,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
                 // piece (t-2) of the NEXT chunk was issued two steps ago and is covered by this step's vmcnt wait;
                 // the scale/shift table (wave 0, tap 0) became visible with this step's barrier (t >= 2).
                 // (spreading these ~110 VALU ops into the MFMA gaps with sched_group_barrier was measured: 3 % SLOWER)
+                // (round 4: its LDS reads issued in FRONT of the step's MFMAs instead, +12 live registers: single layers -1 %, step +-0)
                 if (t >= 2 && t - 2 < LAH && has_next && (wave + NW * (t - 2)) < PG)
                     transform_piece(t - 2, nxt, abuf_next, sS + (qpar ^ 1) * 1024);
             }
