@@ -154,7 +154,34 @@ __device__ __forceinline__ void split4(const f32x4& f, int (&hi)[2], int (&lo)[2
     const auto lb = __builtin_bit_cast(__attribute__((ext_vector_type(2))) int, l);
     hi[0] = hb[0]; hi[1] = hb[1]; lo[0] = lb[0]; lo[1] = lb[1];
 }
+// The same split of s * v (s a power of two, so s * v is exact): hi = fp16(s v), lo = fp16(s v - hi), in EIGHT instructions for four
+// values -- v_fma_mixlo / mixhi_f16 multiply in fp32, add the (negated fp16) third operand and write one half of the destination, so the
+// scale multiply, the conversions back to fp32 and the packing of the C form (14 instructions as hipcc emits it) disappear.  Same bits:
+// s v and s v - hi are exact in fp32, each is rounded to fp16 once (round to nearest even, fp16 subnormals kept: the mode the casts use).
+// (the trailing s_nop: a DPP move may read the results right behind the statement, and hipcc pads nothing it cannot see)
+__device__ __forceinline__ void split4_scaled(const f32x4& v, float s, int (&hi)[2], int (&lo)[2]) {
+    int h01, h23, l01, l23;
+    asm("v_fma_mixlo_f16 %0, %4, %5, 0\n\t"
+        "v_fma_mixlo_f16 %1, %4, %7, 0\n\t"
+        "v_fma_mixhi_f16 %0, %4, %6, 0\n\t"
+        "v_fma_mixhi_f16 %1, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %4, %5, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %4, %7, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %4, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %4, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
+        : "v"(s), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    hi[0] = h01; hi[1] = h23; lo[0] = l01; lo[1] = l23;
+}
 // the lane holding the EVEN chunk of a pair keeps [hi_even | hi_odd], the lane holding the ODD chunk keeps [lo_even | lo_odd]
+__device__ __forceinline__ i32x4 split_pair_exchange_scaled(const f32x4& v, float s, bool odd_chunk) {
+    int hi[2], lo[2];
+    split4_scaled(v, s, hi, lo);
+    const int s0 = odd_chunk ? hi[0] : lo[0], s1 = odd_chunk ? hi[1] : lo[1];
+    const int r0 = __builtin_amdgcn_mov_dpp(s0, 0xB1, 0xF, 0xF, true), r1 = __builtin_amdgcn_mov_dpp(s1, 0xB1, 0xF, 0xF, true);
+    return odd_chunk ? i32x4{r0, r1, lo[0], lo[1]} : i32x4{hi[0], hi[1], r0, r1};
+}
 __device__ __forceinline__ i32x4 split_pair_exchange(const f32x4& f, bool odd_chunk) {
     int hi[2], lo[2];
     split4(f, hi, lo);
@@ -503,8 +530,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmP& p, const TileGeom& 
                 // of the 8-channel group, same row) become [8 x hi | 8 x lo] of s * y -- every lane takes part in the exchange
                 f32x4 v4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = (float)o_[e] * ps_scale;
-                const i32x4 w4 = split_pair_exchange(v4, ((cj >> 2) & 1) != 0);
+                for (int e = 0; e < 4; ++e) v4[e] = (float)o_[e];
+                const i32x4 w4 = split_pair_exchange_scaled(v4, ps_scale, ((cj >> 2) & 1) != 0);
                 if (ok[it]) *reinterpret_cast<i32x4*>(reinterpret_cast<OT*>(p.y) + off[it]) = w4;
                 continue;
             }
@@ -996,20 +1023,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void igemm_kernel(const 
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 char* ptr = sa + (wave + NW * i) * 1024 + lane * 16;
-                f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] *= a_s[i];
-                *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (a_chunk[i] & 1) != 0);
+                const f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+                *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange_scaled(f, a_s[i], (a_chunk[i] & 1) != 0);
             }
             }
             if constexpr (!CONV) {  // GEMM (attention with wide heads): the B operand is an fp32 activation too
 #pragma unroll
                 for (int i = 0; i < LB; ++i) {
                     char* ptr = sa + STAGE_A + (wave + NW * i) * 1024 + lane * 16;
-                    f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] *= bs0.s;
-                    *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (b_chunk[i] & 1) != 0);
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+                    *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange_scaled(f, bs0.s, (b_chunk[i] & 1) != 0);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the rewritten pieces are in LDS before the barrier publishes them
@@ -1221,6 +1244,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     // split-fp16 product: power-of-two operand scale of this tile's image from the bound table(s) (wave-uniform, common.h); the fused
     // skip conv shares the accumulators, so the launch runs on the smaller of the two tensors' scales
     AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};
+    const float silu_k = p.gn_silu ? -1.44269504088896341f : 0.0f, silu_c = p.gn_silu ? 0.0f : -__builtin_inff();  // (see xf_finish)
     if constexpr (SPLIT) {
         if (p.a_bound) asc = ab_scale_of(ab_wave_bound(p.a_bound, g.n_first));
         if constexpr (SKIP) {
@@ -1356,21 +1380,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = f[e] * sc[e] + sh[e];
-                    // (fp32x3: v_exp_f32 / v_rcp_f32 form, ~2 ulp -- far inside the 2^-22 of the split product that consumes it;
-                    //  the exact-fp32 mode keeps the IEEE expf / divide form)
-                    if (p.gn_silu) v = silu_f<SPLIT>(v);
+                    if constexpr (SPLIT) {
+                        // x * sigmoid(x) as v * rcp(1 + 2^(k v + c)) with (k, c) = (-log2 e, 0), or (0, -inf) without a SiLU: the exponential
+                        // is then 0 and the factor exactly 1 -- the same bits as the branch-free select it replaces, four selects fewer
+                        // (v_exp_f32 / v_rcp_f32, ~2 ulp: far inside the 2^-22 of the split product that consumes it)
+                        v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(v, silu_k, silu_c)));
+                    } else {
+                        if (p.gn_silu) v = silu_f<SPLIT>(v);   // (the exact-fp32 mode keeps the IEEE expf / divide form)
+                    }
                     o[e] = v;
                 }
                 outv = __builtin_bit_cast(i32x4, o);
             }
-            if (!ok) outv = raw;  // conv zero padding / masked channel tail: stays zero
+            if constexpr (!SPLIT) {
+                if (!ok) outv = raw;  // conv zero padding / masked channel tail: stays zero
+            }
         }
         if constexpr (SPLIT) {
-            // fp32 chunk -> its half of the pair's [8 x hi | 8 x lo] image (zeros stay zeros); both lanes of a pair take part
-            f32x4 f = __builtin_bit_cast(f32x4, outv);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) f[e] *= asc.s;
-            *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pc & 1) != 0);
+            // fp32 chunk -> its half of the pair's [8 x hi | 8 x lo] image; both lanes of a pair take part.  Conv zero padding and masked
+            // channel tails (their lanes read zeros, which a GroupNorm shift would move) go through scale 0: they stay zero
+            const float sl = (GN && !ok) ? 0.0f : asc.s;
+            *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange_scaled(__builtin_bit_cast(f32x4, outv), sl, (pc & 1) != 0);
         } else {
             if (ok) *reinterpret_cast<i32x4*>(ptr) = outv;
         }
@@ -1682,10 +1712,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
 #pragma unroll
                 for (int i = 0; i < LA; ++i) {
                     char* ptr = stg + (wave + NW * i) * 1024 + lane * 16;
-                    f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] *= asc.s;
-                    *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (bchunk0 & 1) != 0);
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+                    *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange_scaled(f, asc.s, (bchunk0 & 1) != 0);
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
             }
@@ -1892,10 +1920,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     };
     auto split_piece = [&](int i, char* abuf) {  // SPLIT: fp32 chunk -> its half of the pair's [8 x hi | 8 x lo] image (zeros stay zeros)
         char* ptr = abuf + (wave + NW * i) * 1024 + lane * 16;
-        f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] *= asc.s;
-        *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(f, (pchunk_of(i) & 1) != 0);
+        const f32x4 f = *reinterpret_cast<const f32x4*>(ptr);
+        *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange_scaled(f, asc.s, (pchunk_of(i) & 1) != 0);
     };
     // tap slot of K-step s (a = s >> 1, b = s & 1) of the 3x3 frame: forward (par_y + a, par_x + b); backward (1 - p + a, 1 - q + b)
     auto issue_weights = [&](int s, const Chunk& c, char* bst) {
@@ -2186,9 +2212,10 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
                 for (int e = 0; e < 4; ++e) {
                     float v = f[e] * sc[e] + sh[e];
                     if (p.gn_silu) v = silu_f<true>(v);
-                    o[e] = ok ? v * asc.s : 0.0f;  // conv zero padding / masked channel tail stay zero
+                    o[e] = v;
                 }
-                *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange(o, (pc & 1) != 0);
+                // (conv zero padding / masked channel tail stay zero: scale 0)
+                *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange_scaled(o, ok ? asc.s : 0.0f, (pc & 1) != 0);
             } else {
                 const half8 h = __builtin_bit_cast(half8, raw);
                 half8 o;
