@@ -158,7 +158,7 @@ __device__ __forceinline__ void split4(const f32x4& f, int (&hi)[2], int (&lo)[2
 // values -- v_fma_mixlo / mixhi_f16 multiply in fp32, add the (negated fp16) third operand and write one half of the destination, so the
 // scale multiply, the conversions back to fp32 and the packing of the C form (14 instructions as hipcc emits it) disappear.  Same bits:
 // s v and s v - hi are exact in fp32, each is rounded to fp16 once (round to nearest even, fp16 subnormals kept: the mode the casts use).
-// (the trailing s_nop: a DPP move may read the results right behind the statement, and hipcc pads nothing it cannot see)
+// (the DPP moves of the exchange read SELECTS of these results, instructions hipcc sees and pads itself)
 __device__ __forceinline__ void split4_scaled(const f32x4& v, float s, int (&hi)[2], int (&lo)[2]) {
     int h01, h23, l01, l23;
     asm("v_fma_mixlo_f16 %0, %4, %5, 0\n\t"
@@ -168,8 +168,7 @@ __device__ __forceinline__ void split4_scaled(const f32x4& v, float s, int (&hi)
         "v_fma_mixlo_f16 %2, %4, %5, -%0 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixlo_f16 %3, %4, %7, -%1 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %2, %4, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %3, %4, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "s_nop 1"
+        "v_fma_mixhi_f16 %3, %4, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
         : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23)
         : "v"(s), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
     hi[0] = h01; hi[1] = h23; lo[0] = l01; lo[1] = l23;
@@ -1325,7 +1324,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     auto issue_patch_piece = [&](int i, const Chunk& c, char* abuf) {
         const int pc = pchunk_of(i);
         unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(c.cw * ES) + pc * 16 : EOD_OOB;
-        if (c.ktail) v = (c.kin + pc * EPC < c.cw) ? v : EOD_OOB;
+        if (__builtin_expect(c.ktail, 0)) v = (c.kin + pc * EPC < c.cw) ? v : EOD_OOB;
         if (c.src)
             blds16(rsA1, v, (unsigned)(c.kin * ES), abuf + (wave + NW * i) * 1024);
         else
@@ -1410,14 +1409,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         xf_load(i, abuf, ssbuf, pre);
         xf_finish(i, c, abuf, pre);
     };
-    auto issue_weights = [&](int tap, const Chunk& c, char* bst) {
+    // (the K-tail mask of a lane's weight offsets is a property of the CHUNK: bve holds the current chunk's, rebuilt once per chunk, so
+    //  that the eight taps that stay inside it issue their weight DMA without a select per piece)
+    unsigned bve[LB];
+    auto weight_offsets = [&](const Chunk& c, unsigned (&out)[LB]) {
+        const bool kok = !c.ktail || (c.kin + (SPLIT ? (bchunk0 >> 1) * 8 : bchunk0 * EPC) < c.cw);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) out[i] = kok ? b_v[i] : EOD_OOB;
+    };
+    auto issue_weights_at = [&](int tap, const Chunk& c, const unsigned (&off)[LB], char* bst) {
         const unsigned soff = (unsigned)(tap * tapstride) + c.bk;
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            unsigned v = b_v[i];
-            if (c.ktail) v = (c.kin + (SPLIT ? (bchunk0 >> 1) * 8 : bchunk0 * EPC) < c.cw) ? v : EOD_OOB;
-            blds16(rsB, v, soff, bst + (wave + NW * i) * 1024);
-        }
+        for (int i = 0; i < LB; ++i) blds16(rsB, off[i], soff, bst + (wave + NW * i) * 1024);
+    };
+    auto issue_weights = [&](int tap, const Chunk& c, char* bst) {
+        unsigned off[LB];
+        weight_offsets(c, off);
+        issue_weights_at(tap, c, off, bst);
     };
 
     typename AccLayout<MS>::vec acc[TM][TN];
@@ -1512,6 +1520,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         }
         const char* abuf = sA + qpar * ABUF;
         char* abuf_next = sA + (qpar ^ 1) * ABUF;
+        weight_offsets(cur, bve);
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++step) {
             // (STREAM: the first step of a later tile was waited for and fenced in front of the previous tile's epilogue, see below)
@@ -1525,7 +1534,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
             }
             EOD_TSTAMP_AT(4 * t + 1);
             // DMA for the next step: weights first, then (taps 0..LAH-1) one piece of the next chunk's patch
-            if (step + 1 < TSTEP) issue_weights(t < 8 ? t + 1 : 0, t < 8 ? cur : nxt, sB + ((step + 1) & 1) * BSTAGE);
+            if (step + 1 < TSTEP) {
+                if (t < 8) issue_weights_at(t + 1, cur, bve, sB + ((step + 1) & 1) * BSTAGE);
+                else issue_weights(0, nxt, sB + ((step + 1) & 1) * BSTAGE);
+            }
             pp1 = 0;
             if (t < LAH && has_next && (wave + NW * t) < PG) {
                 issue_patch_piece(t, nxt, abuf_next);
