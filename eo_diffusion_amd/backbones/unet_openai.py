@@ -419,9 +419,9 @@ def _qkv_attention_standalone(mod, qkv):
     assert width % (3 * nh) == 0
     d = width // (3 * nh)
     Cc = nh * d
-    if d % 8 or d > 64:
-        raise _lib.EodError(f"{type(mod).__name__} standalone: head dim {d} must be a multiple of 8 and <= 64 (inside AttentionBlock the "
-                            "other head sizes run through the GEMM path)")
+    if d % 8 or d > (64 if default_precision() == "fp32" else 512):
+        raise _lib.EodError(f"{type(mod).__name__} standalone: head dim {d} must be a multiple of 8 and <= 512 (<= 64 in the exact fp32 "
+                            "mode; inside AttentionBlock the other head sizes run through the GEMM path)")
     prog = Program(qkv.device, default_precision())
     a0, i_in = prog.to_nhwc(bs, width, 0, 1, length, width)
     xin = qkv.detach().contiguous().float()
@@ -530,7 +530,14 @@ class AttentionBlock(_Emitter):
         assert x.C == Cc
         N, T = x.N, x.HW
         d_nat = Cc // nh
-        if d_nat % 8 == 0 and d_nat <= 64 and os.environ.get("EOD_ATTN", "nat") == "nat":
+        # wide heads (the ONE 512-channel head of the train.py:50 middle block, :675-681): the same natural-layout call, served by
+        # csrc/attn_wide.hip (fp16 and split-fp16 products; the exact fp32 mode keeps the materialised path below) -- for SHORT
+        # sequences, where the five launches of the materialised path are the cost (T = 64 / 256: 0.048 / 0.068 ms against 0.077 /
+        # 0.087 in fp16, 0.053 against 0.108 ms at T = 256 in fp32x3).  Its workgroups own 32 queries, so K and V are re-staged T / 32
+        # times: at T = 1024 (256 x 256 inputs) the materialised path is the faster one (0.26 against 0.35 ms) and stays.  The choice
+        # depends on the sequence length only (never on the batch: a sample's bits do not depend on its neighbours).
+        wide = 64 < d_nat <= 512 and prog.precision != "fp32" and T <= 512
+        if d_nat % 8 == 0 and (d_nat <= 64 or wide) and os.environ.get("EOD_ATTN", "nat") == "nat":
             # fused attention straight on the qkv projection's natural channel layout (legacy [h][q|k|v][d], new [q|k|v][h][d]):
             # one projection GEMM, no packed q|k / transposed v operands, T x T never materialised in ANY precision mode
             # (eod_attention_fwd_nat; fp16: fp16 MFMA; fp32x3: fp32 in / out with split-fp16 products, the projections run as 1x1 convs
@@ -546,15 +553,16 @@ class AttentionBlock(_Emitter):
                 # combinations of v rows: the table of qkv bounds them).  Otherwise the table of qkv comes from the conv epilogue's sums
                 # of squares (no pass over qkv) and the kernels split in LDS / registers.
                 bq = prog.f32(self.qkv.bias)
-                ps = xn.presplit and T % 128 == 0 and T >= 256 and Cc % 8 == 0  # (whole conv tiles per image, no split-K shapes)
+                ps = xn.presplit and T % 128 == 0 and T >= 256 and Cc % 8 == 0 and not wide  # (whole conv tiles per image, no split-K shapes)
+                out_ps = Cc % 8 == 0 and not wide
                 qkv_bound = prog.linear_bound(xn.bound, self.qkv.weight.view(3 * Cc, Cc), bq) if ps else None
                 qkv, _ = prog.conv(xn, prog.pack_conv(self.qkv.weight.view(3 * Cc, Cc, 1, 1)), bq, 3 * Cc, ksize=1, stride=1, pad=0,
                                    stats=not ps, y_presplit_bound=qkv_bound)
                 a = prog.act(N, x.H, x.W, Cc)
                 if not ps:
                     qkv_bound = prog.bound_of([qkv])
-                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs, qkv_bound=qkv_bound, out_presplit=Cc % 8 == 0, in_presplit=ps)
-                a.bound, a.presplit = qkv_bound, Cc % 8 == 0
+                prog.attention_nat(qkv.t, a.t, N, T, Cc, nh, d_nat, qo, ko, vo, hs, qkv_bound=qkv_bound, out_presplit=out_ps, in_presplit=ps)
+                a.bound, a.presplit = qkv_bound, out_ps
                 out, _ = prog.conv(a, prog.pack_conv(self.proj_out.weight.view(Cc, Cc, 1, 1)), prog.f32(self.proj_out.bias), Cc,
                                    ksize=1, stride=1, pad=0, res=x, stats=True)
                 return out

@@ -476,12 +476,21 @@ int eod_attention_fwd_nat_x3(const float* qkv, float* out, float* lse, int N, in
 int eod_attention_fwd_nat_f32(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int d, int q_off, int k_off, int v_off,
                               int head_stride, hipStream_t st);  // csrc/attn_f32.hip
 
+int eod_attention_fwd_wide(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off, int k_off,
+                           int v_off, int head_stride, const float* qkv_bound, hipStream_t st);  // csrc/attn_wide.hip
+
 extern "C" int eod_attention_fwd_nat(const void* qkv, void* out, float* lse, int dtype, int N, int T, int C, int heads, int d, int q_off,
                                      int k_off, int v_off, int head_stride, const float* qkv_bound, int flags, void* stream) {
     const int out_presplit = (flags & EOD_ATTN_OUT_PRESPLIT) != 0, in_presplit = (flags & EOD_ATTN_IN_PRESPLIT) != 0;
     EOD_REQUIRE(qkv && out && N > 0 && T > 0 && heads > 0 && d > 0 && C == heads * d, "attention_fwd_nat: bad args");
     EOD_REQUIRE(dtype == EOD_F16 || dtype == EOD_F32, "attention_fwd_nat: bad dtype %d", dtype);
-    EOD_REQUIRE(d % 8 == 0 && d <= 64, "attention_fwd_nat: the head dim must be a multiple of 8 and <= 64");
+    EOD_REQUIRE(d % 8 == 0 && d <= 512, "attention_fwd_nat: the head dim must be a multiple of 8 and <= 512");
+    if (d > 64) {  // wide heads: the head dim split over the waves of a workgroup (csrc/attn_wide.hip); fp16 and split-fp16 products
+        EOD_REQUIRE(!(dtype == EOD_F32 && (flags & EOD_ATTN_EXACT_F32)), "attention_fwd_nat: the exact fp32 product exists for head dims <= 64");
+        EOD_REQUIRE(!out_presplit && !in_presplit, "attention_fwd_nat: pre-split tensors exist for head dims <= 64");
+        EOD_REQUIRE((long long)T * 3 * C * eod_esize(dtype) < 0x7fffffffLL * 4LL, "attention_fwd_nat: sequence too long");
+        return eod_attention_fwd_wide(qkv, out, lse, dtype, N, T, C, heads, d, q_off, k_off, v_off, head_stride, qkv_bound, (hipStream_t)stream);
+    }
     if (dtype == EOD_F32 && (flags & EOD_ATTN_EXACT_F32)) {  // exact fp32 mode: IEEE fp32 products on v_mfma_f32_32x32x2_f32 (csrc/attn_f32.hip)
         EOD_REQUIRE(!out_presplit && !in_presplit, "attention_fwd_nat: pre-split tensors belong to the split-fp16 product, not to the exact fp32 one");
         return eod_attention_fwd_nat_f32((const float*)qkv, (float*)out, lse, N, T, C, heads, d, q_off, k_off, v_off, head_stride, (hipStream_t)stream);

@@ -519,7 +519,7 @@ class Program:
 
     def attention_nat(self, qkv, out, N, T, Cc, heads, d, q_off, k_off, v_off, head_stride, lse=None, qkv_bound=None, out_presplit=False,
                       in_presplit=False):
-        """fused attention on the natural qkv layout [N][T][3C] (head dim % 8 == 0 and <= 64, any T): eod_attention_fwd_nat.  fp32 storage
+        """fused attention on the natural qkv layout [N][T][3C] (head dim % 8 == 0 and <= 512 -- <= 64 in the exact fp32 mode --, any T): eod_attention_fwd_nat.  fp32 storage
         (fp32x3): qkv_bound = bound table [N][32] of qkv (None: |q|, |k|, |v| < 4094 guaranteed by the caller); out_presplit: `out` is
         written pre-split (scale from qkv_bound) for the proj_out conv"""
         flags = (_lib.ATTN_OUT_PRESPLIT if out_presplit else 0) | (_lib.ATTN_IN_PRESPLIT if in_presplit else 0) | \

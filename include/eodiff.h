@@ -461,8 +461,10 @@ int eod_scale_f32(float* x, int64_t n, float s, void* stream);
 /* softmax backward on rows (QKVAttention, unet_openai.py:479): dS[r][j] = P[r][j] * (dP[r][j] - sum_k dP[r][k] P[r][k]),
  * P / dS storage dtype with row stride ldp, dP fp32 with row stride lds; columns n..ldp-1 of dS are written as zeros */
 /* fused attention forward on the NATURAL qkv layout [N][T][3C] (channel = q_off / k_off / v_off + head*head_stride + j; legacy
- * order: 0, d, 2d, 3d; new order: 0, C, 2C, d), head dim a multiple of 8 and <= 64, any T; out [N][T][C]; lse optional
- * [N][heads][T].  The T x T weights of unet_openai.py:476-480 / 508-514 never exist in HBM.
+ * order: 0, d, 2d, 3d; new order: 0, C, 2C, d), head dim a multiple of 8 and <= 512, any T; out [N][T][C]; lse optional
+ * [N][heads][T].  The T x T weights of unet_openai.py:476-480 / 508-514 never exist in HBM.  Head dims above 64 (the one 512-channel
+ * head of the train.py:50 architecture's middle block, unet_openai.py:675-681) run on csrc/attn_wide.hip: the head dim split over the
+ * waves of a workgroup, EOD_F16 and EOD_F32 (split-fp16 products) only, no pre-split tensors.
  *   EOD_F16: K / V tiles staged row-major by LDS-DMA, V^T through transposed LDS reads (csrc/attn_bwd.hip)
  *   EOD_F32: fp32 in / out, fp32 online softmax, both contractions as three fp16 MFMAs per product on operands split into
  *            hi + lo halves (fp32-grade, ~2^-22 per product; csrc/attn_x3.hip) */

@@ -655,8 +655,13 @@ def test_flash_attention_backward_short_sequence_with_loss_scaled_gradient(T, he
     test_flash_attention_backward_vs_autograd(T, heads, d, False, False, dO_scale=50.0)
 
 
+WIDE_HEADS = [(256, 1, 512, False), (16, 1, 512, True), (77, 2, 128, False), (300, 1, 96, True), (1024, 1, 256, False), (50, 3, 72, False),
+              (40, 1, 384, True), (33, 2, 200, False)]  # head dims above 64: csrc/attn_wide.hip (512 = the train.py:50 middle block)
+
+
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
-                                                 (64, 4, 8, False), (144, 6, 32, True), (36, 9, 32, True), (2304, 3, 32, True), (300, 2, 24, True)])
+                                                 (64, 4, 8, False), (144, 6, 32, True), (36, 9, 32, True), (2304, 3, 32, True), (300, 2, 24, True)]
+                         + WIDE_HEADS)
 def test_attention_forward_natural_layout(T, heads, d, new_order):
     """eod_attention_fwd_nat: fused attention straight on the qkv conv output (both channel orders), ragged sequence lengths,
     with the log-sum-exp output -- vs torch softmax(q k^T / sqrt(d)) v"""
@@ -682,7 +687,7 @@ def test_attention_forward_natural_layout(T, heads, d, new_order):
 
 @pytest.mark.parametrize("T,heads,d,new_order", [(49, 2, 16, False), (196, 1, 32, True), (128, 2, 48, False), (1000, 2, 64, False), (4096, 1, 48, True),
                                                  (64, 4, 8, False), (4096, 2, 64, False),
-                                                 (144, 6, 32, True), (36, 9, 32, True), (2304, 3, 32, True), (300, 2, 24, True)])
+                                                 (144, 6, 32, True), (36, 9, 32, True), (2304, 3, 32, True), (300, 2, 24, True)] + WIDE_HEADS)
 @pytest.mark.parametrize("mag", [0.8, 4.0])
 @pytest.mark.parametrize("bound", [False, True])
 def test_attention_forward_natural_layout_fp32(T, heads, d, new_order, mag, bound):

@@ -126,6 +126,51 @@ def test_flash_attention_longer_sequences(C, heads, hw, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
+@pytest.mark.parametrize("C,heads,hw,new", [(512, 1, (16, 16), False), (512, 1, (4, 4), False), (256, 2, (9, 7), True), (192, 1, (32, 32), False),
+                                            (320, 1, (12, 12), True)])
+def test_attention_block_wide_heads(prec, C, heads, hw, new, monkeypatch):
+    """AttentionBlock with head dims above 64 -- the train.py:50 architecture's middle block is ONE head of 512 channels
+    (unet_openai.py:675-681) at 16 x 16 (256 x 256 input) or 4 x 4 (64 x 64): fp16 / fp32x3 run the fused wide-head kernel
+    (csrc/attn_wide.hip), fp32 the materialised path; vs the CPU oracle, and vs the product's own materialised path on the same inputs"""
+    from eo_diffusion_amd.backbones.unet_openai import AttentionBlock
+    from oracle import unet_ref as UR
+    from tests.synth import synth_input
+    monkeypatch.setenv("EOD_PRECISION", prec)
+    sd = synth_state_dict(attn_shapes(C), 4)
+    x = synth_input(f"wa{C}{hw}", (2, C) + hw, 2)
+    x[1] *= 37.0  # (per-image operand scales)
+    blk = AttentionBlock(C, num_heads=heads, use_new_attention_order=new)
+    load_into(blk, sd)
+    with torch.no_grad():
+        y = blk(x.to(DEV)).cpu()
+        monkeypatch.setenv("EOD_ATTN", "gemm")
+        y2 = blk(x.to(DEV)).cpu()
+    ref = UR.attention_block({"a." + k: v for k, v in sd.items()}, "a", x, heads, new)
+    for n in range(2):
+        assert rel_l2(y[n], ref[n]) < TOL[prec], n
+        assert rel_l2(y[n], y2[n]) < 2 * TOL[prec], n
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
+@pytest.mark.parametrize("cls,heads,d,T", [("QKVAttentionLegacy", 1, 512, 256), ("QKVAttention", 2, 128, 77), ("QKVAttention", 1, 200, 16)])
+def test_qkv_attention_standalone_wide_heads(prec, cls, heads, d, T, monkeypatch):
+    """QKVAttention(Legacy).forward(qkv) on their own with head dims above 64 (fused, csrc/attn_wide.hip); the exact fp32 mode has no
+    fused kernel for them and says so"""
+    import eo_diffusion_amd.backbones.unet_openai as U
+    from oracle import unet_ref as UR
+    from tests.synth import synth_input
+    monkeypatch.setenv("EOD_PRECISION", prec)
+    qkv = synth_input(f"sw{cls}{T}", (2, 3 * heads * d, T), 6)
+    ref = (UR.qkv_attention_legacy if cls == "QKVAttentionLegacy" else UR.qkv_attention_new)(qkv, heads)
+    with torch.no_grad():
+        out = getattr(U, cls)(heads)(qkv.to(DEV)).cpu()
+    assert rel_l2(out, ref) < (2e-3 if prec == "fp16" else 5e-6)
+    monkeypatch.setenv("EOD_PRECISION", "fp32")
+    with pytest.raises(U._lib.EodError):
+        getattr(U, cls)(heads)(qkv.to(DEV))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
 @pytest.mark.parametrize("factory,size", [("UNetSmall", 32), ("UNet", 28), ("UNetBig", 32)])   # (UNetBig: base width 192 -- the first conv spans two N-tiles)
 def test_factory_presets_vs_oracle(prec, factory, size):
     """UNetBig/UNet/UNetSmall presets (unet_openai.py:783-922): FiLM, resblock_updown, new attention order,
