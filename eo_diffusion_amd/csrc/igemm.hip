@@ -2348,6 +2348,135 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
     }
 }
 
+// =============================================================================================
+// conv_first_x3_kernel: the UNet's FIRST conv in the fp32x3 mode -- 3x3 / stride 1 / pad 1 over an image of <= 8 (padded) channels
+// (unet_openai.py:609, input_blocks.0.0; tap-major weights [Cout][ldk], k = tap * CP + c, eod_pack_conv_weight_tapmajor_split).
+// 9 x CP x Cout MACs per pixel against 4 x Cout bytes of output: HBM-bound on the WRITE side.  On the generic kernel a workgroup lived
+// ~17 us for two K-steps (gathered LDS-DMA of 16 + 16 pieces per step, the in-LDS split, two barriers per step, 64 KiB of LDS: two
+// workgroups per CU and nothing to hide the first fetch behind): 0.27 ms for 537 MB = 2.0 TB/s.  Here the 10 x 18 pixel patch of an
+// 8 x 16 tile is ONE 16- or 32-byte load per thread, split on the way into 3-6 KiB of LDS ([CP x hi | CP x lo] per pixel), the
+// weights go from L2 straight into registers, the k-groups of a pixel are plain LDS reads at tap offsets (k-group = two taps of 4
+// channels, or one tap of 8), ONE barrier per workgroup, and three workgroups fit a CU (160 registers).  Swapped MFMA operands and the direct
+// epilogue of the halo kernel (halo_epilogue_direct: 16-byte stores from the accumulators, bias, GroupNorm partial sums in the same
+// two slots per tile).
+// =============================================================================================
+template <int CP>
+__global__ __launch_bounds__(256, 3) void conv_first_x3_kernel(const IgemmP p) {
+    static_assert(CP == 4 || CP == 8, "one or two 16-byte chunks of fp32 channels per pixel");
+    constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
+    constexpr int PW = 18, PR = 10 * PW, PB = CP * 4;        // LDS bytes per patch pixel: [CP x fp16 hi | CP x fp16 lo]
+    constexpr int KG = (9 * CP + 7) / 8, STEPS = (KG + 3) / 4;  // 8-element k-groups that hold taps; MFMA steps of 4 groups
+    constexpr int ZOFF = PR * PB;                            // 32 zero bytes behind the patch: what the k-groups past tap 8 read
+    __shared__ __attribute__((aligned(16))) char sP[PR * PB + 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    map_tile(p, tile_m, tile_n);
+    const int n0 = tile_n * BN;
+    const TileGeom g = make_geom<true, BM>(p, tile_m);
+    f32x4 pre_bq[TN];
+    int pre_we[TN];
+    prefetch_bcol4<TN>(p, p.Ncols, n0 + wn * 64, lane, g.n_first, pre_bq);
+    prefetch_wexp4<TN>(p, p.Ncols, n0 + wn * 64, 0, lane, pre_we);
+    const float wsc1 = p.w_scale[1];
+    AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};
+    if (p.a_bound) asc = ab_scale_of(ab_wave_bound(p.a_bound, g.n_first));
+
+    // ---- the patch: one pixel per thread, scaled and split on the way into LDS (zeros outside the image = the conv's padding) ----
+    if (tid < PR) {
+        const int py = tid / PW, px = tid - py * PW;
+        const int hi = g.ty0 - 1 + py, wi = g.tx0 - 1 + px;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+            const float* src = reinterpret_cast<const float*>(p.a0) + (((long long)g.n_first * p.H + hi) * p.W + wi) * CP;
+            a = *reinterpret_cast<const f32x4*>(src);
+            if constexpr (CP == 8) c = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        int ha[2], la[2];
+        split4_scaled(a, asc.s, ha, la);
+        if constexpr (CP == 4) {
+            *reinterpret_cast<i32x4*>(sP + tid * PB) = i32x4{ha[0], ha[1], la[0], la[1]};
+        } else {
+            int hc[2], lc[2];
+            split4_scaled(c, asc.s, hc, lc);
+            *reinterpret_cast<i32x4*>(sP + tid * PB) = i32x4{ha[0], ha[1], hc[0], hc[1]};
+            *reinterpret_cast<i32x4*>(sP + tid * PB + 16) = i32x4{la[0], la[1], lc[0], lc[1]};
+        }
+    } else if (tid < PR + 2) {
+        *reinterpret_cast<i32x4*>(sP + ZOFF + (tid - PR) * 16) = i32x4{0, 0, 0, 0};
+    }
+    __syncthreads();
+
+    const int lp = lane & 15, kgl = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.b), 0, p.Cout * p.ldk * 4, 0x00020000);
+    typename AccLayout<16>::vec acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // patch address of (tile row 4 wm, column lp) shifted by a tap
+    auto tap_addr = [&](int tap) {
+        const int dy = (tap * 11) >> 5, dx = tap - dy * 3;  // tap / 3, tap % 3 for tap < 9
+        return ((wm * 4 + dy) * PW + lp + dx) * PB;
+    };
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int gq = 4 * s + kgl;  // this lane's k-group: 8 consecutive k = tap * CP + c
+        i32x4 wh[TN], wl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn * 64 + j * 16 + lp;
+            const unsigned off = (co < p.Ncols && gq * 8 < p.ldk) ? (unsigned)(co * p.ldk * 4 + gq * 32) : EOD_OOB;
+            wh[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 0, 0);
+            wl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, off, 16, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            i32x4 xh, xl;
+            if constexpr (CP == 8) {
+                const int a = gq < 9 ? tap_addr(gq) + i * PW * PB : ZOFF;
+                xh = *reinterpret_cast<const i32x4*>(sP + a);
+                xl = *reinterpret_cast<const i32x4*>(sP + a + 16);
+            } else {
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                const int a0 = 2 * gq < 9 ? tap_addr(2 * gq) + i * PW * PB : ZOFF;
+                const int a1 = 2 * gq + 1 < 9 ? tap_addr(2 * gq + 1) + i * PW * PB : ZOFF;
+                const i32x4 p0 = *reinterpret_cast<const i32x4*>(sP + a0), p1 = *reinterpret_cast<const i32x4*>(sP + a1);
+                xh = i32x4{p0[0], p0[1], p1[0], p1[1]};
+                xl = i32x4{p0[2], p0[3], p1[2], p1[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {  // D = W X^T, smallest terms first (see conv3x3_halo_kernel)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wh[j]), __builtin_bit_cast(half8, xl), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wl[j]), __builtin_bit_cast(half8, xh), acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wh[j]), __builtin_bit_cast(half8, xh), acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    IgemmP pe = p;
+    pe.alpha = p.alpha * wsc1 * asc.inv;  // undo the weight and activation scales (exact powers of two)
+    halo_epilogue_direct<BM, BN, 2, 2>(pe, g, acc, wave, lane, n0, pre_bq, pe.alpha, pre_we);
+}
+
+template <int CP> static int launch_first(IgemmP& p, hipStream_t st) {
+    p.tiles_n = (p.Ncols + 127) / 128;
+    p.tw_log2 = 4;
+    p.th = 8;
+    p.tiles_pw = p.Wo / 16;
+    p.tiles_pi = p.tiles_pw * (p.Ho / 8);
+    p.tiles_m = p.tiles_pi * p.N;
+    p.tiles_per_image = p.tiles_pi;
+    const long long nblk = (long long)p.tiles_m * p.tiles_n;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) {
+        eod_set_error("conv_first: bad grid %lld", nblk);
+        return EOD_EINVAL;
+    }
+    hipLaunchKernelGGL(conv_first_x3_kernel<CP>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+    EOD_CHECK_LAUNCH("conv_first");
+    return EOD_OK;
+}
+
 template <typename T, bool SPLIT> static int launch_head(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
     const size_t lds = 3 * (size_t)(24 * 1024) + HEAD_MAX_C * 8;
@@ -2468,12 +2597,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 //                                              per launch).  Measured (round 4): single layers 3-8 % faster at 4-8 tiles per run, the
 //                                              whole 256 x 256 step 0.4 % SLOWER than off (same-box A/B, three interleaved runs)
 //   halo_splitk       EOD_HALO_SPLITK=0        3x3 convs on maps with fewer than two workgroups per CU unsplit in K (64-column tiles instead)
+//   first             EOD_FIRST=0              the fp32x3 first conv (tap-major weights) on the generic kernel instead of conv_first_x3_kernel
 // (Round 2's EOD_IGEMM_CFG / EOD_MFMA_SHAPE / EOD_HALO_SPLIT_N / EOD_CONV_PARITY arms were measured slower and are gone: the fp16
 // products run on v_mfma_f32_16x16x32_f16, 384-column convs as 256 + 128, zero-insertion convs as four parity-class launches.)
-enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_HALO_SPLITK, OPT_COUNT };
-static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw", "halo_splitk"};
-static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT", "EOD_HALO_TPW", "EOD_HALO_SPLITK"};
-static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 1, 1};
+enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_HALO_SPLITK, OPT_FIRST, OPT_COUNT };
+static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw", "halo_splitk", "first"};
+static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT", "EOD_HALO_TPW", "EOD_HALO_SPLITK",
+                                                 "EOD_FIRST"};
+static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 1, 1, 1};
 static bool g_opt_init = false;
 static int opt(int k) {
     if (!g_opt_init) {
@@ -2708,6 +2839,12 @@ static int conv_up4_bwd(const eod_conv_desc* d, void* stream) {
     return launch_up4<half_t, false, true>(p, (hipStream_t)stream);
 }
 // the UNet's output head on conv_head_kernel (EOD_HEAD=0: the 32-column halo instance, A/B)
+// the fp32x3 first conv (thin input, tap-major split weights) on conv_first_x3_kernel: 8 x 16 pixel tiles, 128-column workgroups
+static bool conv_first_ok(const eod_conv_desc* d, int Ho, int Wo) {
+    return opt(OPT_FIRST) != 0 && d->w_tapmajor && d->w_split && d->dtype == EOD_F32 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl &&
+           !d->upsample && d->C1 == 0 && !d->x2 && (d->C0 == 4 || d->C0 == 8) && Ho % 8 == 0 && Wo % 16 == 0 && d->Cout % 4 == 0 && d->Cout > 64 && !d->out_nchw_f32 &&
+           !d->gn_scale_shift && !d->skip_x && !d->x_presplit && !d->y_presplit_bound;
+}
 static bool conv_head_ok(const eod_conv_desc* d, bool halo_ok) {
     const bool on = opt(OPT_HEAD) != 0;
     const bool store_ok = d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
@@ -2955,6 +3092,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
         EOD_REQUIRE(conv_up4_ok(d), "conv: upsample = 3 (parity-class form of the nearest-2x conv) needs a geometry for which eod_conv_up4_ok(d) == 1");
         return d->dtype == EOD_F16 ? launch_up4<half_t, false>(p, st) : launch_up4<float, true>(p, st);
     }
+    if (conv_first_ok(d, Ho, Wo)) return d->C0 == 4 ? launch_first<4>(p, st) : launch_first<8>(p, st);
     if (conv_head_ok(d, halo_ok)) {  // output head: GroupNorm + SiLU fused, <= 16 channels, NCHW fp32 (conv_head_kernel)
         p.gn_ss = d->gn_scale_shift;
         p.gn_silu = d->gn_silu;

@@ -648,10 +648,13 @@ class Program:
                 head = geo and d.Cout <= 32 and d.out_nchw_f32 and not d.upsample  # 32-column instance (HBM-bound head conv)
                 headk = head and bool(d.gn_scale_shift) and d.Cout <= 16 and d.C1 == 0 and cin <= 384 and self.precision != "fp32" \
                     and self.L.eod_get_option(b"head") != 0  # mirrors conv_head_ok()
+                first = geo and bool(d.w_tapmajor) and bool(d.w_split) and d.Wo % 16 == 0 and d.Cout > 64 and d.C0 in (4, 8) and not d.out_nchw_f32 \
+                    and self.L.eod_get_option(b"first") != 0  # mirrors conv_first_ok()
                 up4 = d.upsample == 3  # parity-class form of the nearest-2x conv: the algorithm's 9 taps are executed as 4 (pre-summed)
                 out.append(dict(kind="conv", flops=fl, bytes=by, exec_flops=fl * (4.0 / 9.0 if up4 else 1.0),
                                 kernel="conv_up4_halo_kernel" if up4 else "conv3x3_halo_kernel" if halo else
-                                       "conv_head_kernel" if headk else "conv3x3_halo_kernel<BN=32>" if head else "igemm_kernel",
+                                       "conv_head_kernel" if headk else "conv3x3_halo_kernel<BN=32>" if head else
+                                       "conv_first_x3_kernel" if first else "igemm_kernel",
                                 label=f"conv{d.ksize}x{d.ksize}s{d.stride}{'u4' if up4 else 'u' if d.upsample else ''} {d.H}x{d.W} {cin}->{d.Cout}"
                                       + (f" +skip1x1 {sc}" if sc else "")))
             elif k == OP_GEMM:

@@ -37,10 +37,10 @@ const char* eod_last_error(void);
  * out-of-bounds device write. */
 #define EOD_ABI_VERSION 104
 int eod_version(void);
-/* Kernel-selection options ("skip_fuse", "head", "halo_bn256", "halo_splitk": 1 / 0; "gn_fuse_max_cout": n, -1 = default; "halo_tpw":
+/* Kernel-selection options ("skip_fuse", "head", "halo_bn256", "halo_splitk", "first": 1 / 0; "gn_fuse_max_cout": n, -1 = default; "halo_tpw":
  * pixel tiles per workgroup of the streaming halo instances, 1 = off = default, 0 = chosen per launch): every option has one
  * measured-best default, the other arm computes the same function on another kernel (same-box A/B runs, per-switch parity tests).
- * Read from the environment (EOD_SKIP_FUSE, EOD_HEAD, EOD_HALO_BN256, EOD_GN_FUSE_MAX_COUT, EOD_HALO_TPW, EOD_HALO_SPLITK) at first use; returns the previous value,
+ * Read from the environment (EOD_SKIP_FUSE, EOD_HEAD, EOD_HALO_BN256, EOD_GN_FUSE_MAX_COUT, EOD_HALO_TPW, EOD_HALO_SPLITK, EOD_FIRST) at first use; returns the previous value,
  * or EOD_EINVAL for an unknown name.  Plans built before a change keep the kernels they were built with. */
 int eod_set_option(const char* name, int value);
 int eod_get_option(const char* name);

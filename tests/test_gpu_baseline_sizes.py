@@ -334,7 +334,7 @@ def test_ldm_p_sample_loop_vs_reference_trajectory():
 
 
 # ------------------------------------------------------------------------------------------------ every kernel-selection switch, both arms
-SWITCHES = ["up4", "skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw"]
+SWITCHES = ["up4", "skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw", "first"]
 
 
 @pytest.mark.parametrize("prec", ["fp32x3", "fp16"])
@@ -344,10 +344,13 @@ def test_a0_256_forward_with_each_kernel_switch_off(prec, switch, monkeypatch):
     computes the same function on other kernels: EOD_UP4=0 (nine-tap convs behind an upsampling), skip_fuse=0 (1x1 skip convs as
     launches of their own), head=0 (the output head on the 32-column halo instance), halo_bn256=0 (256- / 512-column convs on two 4-wave
     workgroups), gn_fuse_max_cout=0 (every GroupNorm as a separate pass), halo_tpw=0 (the streaming halo instances: several pixel tiles
-    per workgroup, run length chosen per launch; the default 1 is the plain one-tile form).  Each alternative arm is held to the SAME oracle gate at the
+    per workgroup, run length chosen per launch; the default 1 is the plain one-tile form), first=0 (the fp32x3 first conv on the generic
+    kernel instead of conv_first_x3_kernel).  Each alternative arm is held to the SAME oracle gate at the
     metric's image size, and the launch program is checked to really differ from the default one."""
     from eo_diffusion_amd import _lib
     L = _lib.lib()
+    if switch == "first" and prec != "fp32x3":
+        pytest.skip("the dedicated first-conv kernel exists for the fp32x3 product only")
     x, t, ref, *_ = _a0_256_oracle()
 
     def program_signature(u):
