@@ -2164,49 +2164,87 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_m, tile_n;
-    map_tile(p, tile_m, tile_n);
-    const TileGeom g = make_geom<true, BM>(p, tile_m);
+    // a workgroup streams a RUN of p.tpw consecutive tiles of one image through one chunk ring (launch_head: tpw divides the tiles of an
+    // image): the ring never drains between tiles -- the chunk two ahead is in flight and the one ahead is being normalised whichever
+    // tile they belong to -- so the first-fetch latency and the table load are paid once per run, not once per 4 chunks
+    int run, tile_n;
+    map_tile(p, run, tile_n);  // (p.tiles_m = number of runs)
+    const int tile0 = run * p.tpw, ntile = p.tpw;
+    const TileGeom g = make_geom<true, BM>(p, tile0);  // n_first: the image of the whole run
     AbScale asc = {EOD_SPLIT_ASCALE, 1.0f};  // split-fp16 product: operand scale of this tile's image (see conv3x3_halo_kernel)
+    const float silu_k = p.gn_silu ? -1.44269504088896341f : 0.0f, silu_c = p.gn_silu ? 0.0f : -__builtin_inff();
     if constexpr (SPLIT) {
         if (p.a_bound) asc = ab_scale_of(ab_wave_bound(p.a_bound, g.n_first));
     }
 
     const int srow = lane >> 3, sslot = lane & 7;
-    unsigned ppix[LAH];
-    unsigned pck = 0, pvalid = 0;
+    // patch pieces of this lane: the chunk slot of a piece is a property of the patch position (the same for every tile), source pixel
+    // and validity belong to a tile: one set for the tile whose chunks are being ISSUED, one for the tile being TRANSFORMED
+    struct PatchGeom {
+        unsigned ppix[LAH];
+        unsigned pvalid;
+    };
+    unsigned pck = 0;
 #pragma unroll
     for (int i = 0; i < LAH; ++i) {
         const int prow = (wave + NW * i) * 8 + srow;
-        const int py = prow / PW, px = prow - py * PW;
-        const int hi = g.ty0 - 1 + py, wi = g.tx0 - 1 + px;
-        const bool ok = prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        if (ok) pvalid |= 1u << i;
-        ppix[i] = (unsigned)(hi * p.W + wi);
+        const int px = prow % PW;
         pck |= (unsigned)(sslot ^ ((px >> 1) & 7)) << (3 * i);
     }
+    auto patch_geom = [&](int k, PatchGeom& o) {  // tile k of the run (k >= ntile: past the end, nothing valid)
+        const TileGeom gk = make_geom<true, BM>(p, tile0 + (k < ntile ? k : 0));
+        o.pvalid = 0;
+#pragma unroll
+        for (int i = 0; i < LAH; ++i) {
+            const int prow = (wave + NW * i) * 8 + srow;
+            const int py = prow / PW, px = prow - py * PW;
+            const int hi = gk.ty0 - 1 + py, wi = gk.tx0 - 1 + px;
+            const bool ok = k < ntile && prow < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            if (ok) o.pvalid |= 1u << i;
+            o.ppix[i] = (unsigned)(hi * p.W + wi);
+        }
+    };
+    PatchGeom gI, gT;
+    patch_geom(0, gI);
+    gT = gI;
     auto pchunk_of = [&](int i) { return (int)((pck >> (3 * i)) & 7u); };
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.a0 + (long long)g.n_first * p.H * p.W * p.C0 * ES);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gn_ss) + (long long)g.n_first * p.C0 * 2, 0, p.C0 * 8, 0x00020000);
     const int KC = p.kc0;
 
-    auto issue_chunk = [&](int cc) {  // this wave's patch pieces of chunk cc into ring slot cc % 3
-        char* abuf = sA + (cc % 3) * ABUF;
-        const int kin = cc * BK;
+    // the stream of chunks: q = tile * KC + chunk, ring slot q % 3.  issue / transform / weights each walk it once, in order: three
+    // (tile, chunk, slot) counters instead of divisions
+    struct Cursor {
+        int k, cc, slot;
+    };
+    auto advance = [&](Cursor& c) {
+        c.slot = c.slot == 2 ? 0 : c.slot + 1;
+        if (++c.cc == KC) {
+            c.cc = 0;
+            ++c.k;
+        }
+    };
+    Cursor cI = {0, 0, 0}, cT = {0, 0, 0};
+    auto issue_next = [&]() {  // this wave's patch pieces of the next chunk of the stream into its ring slot (past the end: out of range)
+        char* abuf = sA + cI.slot * ABUF;
+        const int kin = cI.cc * BK;
         const bool ktail = kin + BK > p.C0;
 #pragma unroll
         for (int i = 0; i < LAH; ++i) {
             const int pc = pchunk_of(i);
-            unsigned v = ((pvalid >> i) & 1u) ? ppix[i] * (unsigned)(p.C0 * ES) + pc * 16 : EOD_OOB;
-            if (ktail) v = (kin + pc * EPC < p.C0) ? v : EOD_OOB;  // (also every piece of a chunk past the last one)
+            unsigned v = ((gI.pvalid >> i) & 1u) ? gI.ppix[i] * (unsigned)(p.C0 * ES) + pc * 16 : EOD_OOB;
+            if (ktail) v = (kin + pc * EPC < p.C0) ? v : EOD_OOB;
             blds16(rsA, v, (unsigned)(kin * ES), abuf + (wave + NW * i) * 1024);
         }
+        advance(cI);
+        if (cI.cc == 0) patch_geom(cI.k, gI);  // the next tile's pixels
     };
-    auto transform_chunk = [&](int cc) {  // x -> silu(x * scale + shift) [-> fp16 pair image], this wave's pieces, in place
-        char* abuf = sA + (cc % 3) * ABUF;
-        const int kin = cc * BK;
+    auto transform_next = [&]() {  // x -> silu(x * scale + shift) [-> fp16 pair image], this wave's pieces of the next chunk, in place
+        char* abuf = sA + cT.slot * ABUF;
+        const int kin = cT.cc * BK;
         const char* ssbuf = sS + kin * 8;
         const bool ktail = kin + BK > p.C0;
+        const unsigned pvalid = gT.pvalid;
 #pragma unroll
         for (int i = 0; i < LAH; ++i) {
             if ((wave + NW * i) * 8 >= PR) continue;  // the padding group
@@ -2222,9 +2260,8 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = f[e] * sc[e] + sh[e];
-                    if (p.gn_silu) v = silu_f<true>(v);
-                    o[e] = v;
+                    const float v = f[e] * sc[e] + sh[e];
+                    o[e] = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(v, silu_k, silu_c)));  // (select-free SiLU: see conv3x3_halo_kernel)
                 }
                 // (conv zero padding / masked channel tail stay zero: scale 0)
                 *reinterpret_cast<i32x4*>(ptr) = split_pair_exchange_scaled(o, ok ? asc.s : 0.0f, (pc & 1) != 0);
@@ -2243,6 +2280,8 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
                 if (ok) *reinterpret_cast<i32x4*>(ptr) = __builtin_bit_cast(i32x4, o);
             }
         }
+        advance(cT);
+        if (cT.cc == 0) patch_geom(cT.k, gT);
     };
     // weights of one chunk in registers: [tap][sub-step / (hi, lo)]; lane = (output row lr, k-quarter lh).  Packed [tap][Cout][Cin]
     // rows; split storage: 32-byte [8 x hi | 8 x lo] pairs, quarter lh takes pair {0, 3, 1, 2}[lh] like the patch reads.
@@ -2287,24 +2326,49 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
     constexpr int KEEP = LAH + 18;
     static_assert(KEEP < 64, "vmcnt is 6 bits");
     auto wait_keep_pieces = [&]() { __builtin_amdgcn_s_waitcnt(0x0f70 | (KEEP & 15) | ((KEEP >> 4) << 14)); };
-    i32x4 wcur[9][2], wnxt[9][2];
+    i32x4 wreg[2][9][2];
     if (wave == 0) {
 #pragma unroll
         for (int j = 0; j < HEAD_MAX_C / 128; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (lds_void*)(sS + j * 1024), 16, (unsigned)(lane * 16 + j * 1024), 0, 0, 0);
     }
-    issue_chunk(0);
-    load_weights(0, wcur);
-    issue_chunk(1);
+    // per output channel: {scale (operand scales x the row scale of the split weights), bias}, through LDS -- fetched by 16 lanes before
+    // any DMA is in flight and read back into registers behind the first barrier, so that no global load of the epilogue is pending
+    // inside the loop (the compiler would guard its first use with a vmcnt(0) in every iteration)
+    float* const sE = reinterpret_cast<float*>(sS + HEAD_MAX_C * 8);
+    if (tid < 16) {
+        const float alpha = SPLIT ? p.alpha * p.w_scale[1] * asc.inv : p.alpha;
+        const bool cok = tid < p.Cout;
+        sE[2 * tid] = (SPLIT && p.w_rexp && cok) ? ldexpf(alpha, -p.w_rexp[tid]) : alpha;
+        sE[2 * tid + 1] = (p.bias && cok) ? p.bias[tid] : 0.0f;
+    }
+    issue_next();
+    load_weights(0, wreg[0]);
+    issue_next();
     wait_keep_pieces();
-    __builtin_amdgcn_s_barrier();  // wave 0's table is visible
-    transform_chunk(0);
-    for (int cc = 0; cc < KC; ++cc) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my in-place rewrites of chunk cc are in LDS
-        __builtin_amdgcn_s_barrier();        // chunk cc is complete for every wave, and ring slot (cc + 2) % 3 is no longer read
-        load_weights(cc + 1, wnxt);
-        issue_chunk(cc + 2);
-        const char* abuf = sA + (cc % 3) * ABUF;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // (the 16 lanes' LDS writes)
+    __builtin_amdgcn_s_barrier();  // wave 0's tables are visible
+    float am[4], bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        am[r] = sE[2 * (4 * lh + r)];
+        bv[r] = sE[2 * (4 * lh + r) + 1];
+    }
+    transform_next();
+    const int Q = ntile * KC;
+    Cursor cR = {0, 0, 0};  // the chunk being read
+    int q = 0;
+    // one chunk of the stream: reads `wc`, fetches the next chunk's weights into `wn` (the loop alternates the two register sets:
+    // rotating one set through the other cost 36 moves per chunk)
+    auto step = [&](auto cur_c) {
+        constexpr int CUR = decltype(cur_c)::value;
+        i32x4 (&wc)[9][2] = wreg[CUR];
+        i32x4 (&wn)[9][2] = wreg[CUR ^ 1];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my in-place rewrites of chunk q are in LDS
+        __builtin_amdgcn_s_barrier();        // chunk q is complete for every wave, and ring slot (q + 2) % 3 is no longer read
+        load_weights(cR.cc + 1 == KC ? 0 : cR.cc + 1, wn);
+        issue_next();
+        const char* abuf = sA + cR.slot * ABUF;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3, dx = t - dy * 3;
@@ -2312,40 +2376,53 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
             for (int i = 0; i < 2; ++i) {
                 const i32x4 a0 = *reinterpret_cast<const i32x4*>(abuf + abase[0][dx] + (i + dy) * PW * BKB);
                 const i32x4 a1 = *reinterpret_cast<const i32x4*>(abuf + abase[1][dx] + (i + dy) * PW * BKB);
-                if constexpr (SPLIT) {  // a0 = hi, a1 = lo of the pixels; wcur[t][0] = hi, [1] = lo of the weights; smallest terms first
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][0]), __builtin_bit_cast(half8, a1), acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][1]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][0]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
+                if constexpr (SPLIT) {  // a0 = hi, a1 = lo of the pixels; wc[t][0] = hi, [1] = lo of the weights; smallest terms first
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wc[t][0]), __builtin_bit_cast(half8, a1), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wc[t][1]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wc[t][0]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
                 } else {
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][0]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wcur[t][1]), __builtin_bit_cast(half8, a1), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wc[t][0]), __builtin_bit_cast(half8, a0), acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, wc[t][1]), __builtin_bit_cast(half8, a1), acc[i], 0, 0, 0);
                 }
             }
         }
         wait_keep_pieces();
-        if (cc + 1 < KC) transform_chunk(cc + 1);
+        if (q + 1 < Q) transform_next();
+        if (cR.cc + 1 == KC) {
+            // ---- a tile is complete: rows of D = output channels 4 lh + r, column = pixel lr of tile row 2 wave + i: 64-byte runs per plane
+            // row.  (The stores are younger than every piece a later counted wait is for: they can only make it wait longer.)
+            const TileGeom gk = make_geom<true, BM>(p, tile0 + cR.k);
+            float* yb = reinterpret_cast<float*>(p.y) + (long long)g.n_first * p.Cout * p.HoWo;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            wcur[t][0] = wnxt[t][0];
-            wcur[t][1] = wnxt[t][1];
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * lh + r;
+                if (co < p.Cout) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        yb[(long long)co * p.HoWo + (long long)(gk.ty0 + wave * 2 + i) * p.Wo + gk.tx0 + lr] = acc[i][r] * am[r] + bv[r];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] = 0.0f;
+        }
+        advance(cR);
+        ++q;
+    };
+    while (q < Q) {
+        step(std::integral_constant<int, 0>{});
+        if constexpr (SPLIT) {
+            if (q < Q) step(std::integral_constant<int, 1>{});
+        } else {  // (the fp16 instance keeps the rotation: with two copies of the loop body its register arrays end up in scratch)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                wreg[0][t][0] = wreg[1][t][0];
+                wreg[0][t][1] = wreg[1][t][1];
+            }
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);  // the out-of-range pieces of the last two iterations: nothing in flight at exit
-    // ---- store: rows of D = output channels 4 lh + r, column = pixel lr of tile row 2 wave + i: 64-byte runs per plane row ----
-    {
-        const float alpha = SPLIT ? p.alpha * p.w_scale[1] * asc.inv : p.alpha;
-        float* yb = reinterpret_cast<float*>(p.y) + (long long)g.n_first * p.Cout * p.HoWo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = 4 * lh + r;
-            if (co >= p.Cout) continue;
-            const float bv = p.bias ? p.bias[co] : 0.0f;
-            const float am = (SPLIT && p.w_rexp) ? ldexpf(alpha, -p.w_rexp[co]) : alpha;  // (row scale of the split weights)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                yb[(long long)co * p.HoWo + (long long)(g.ty0 + wave * 2 + i) * p.Wo + g.tx0 + lr] = acc[i][r] * am + bv;
-        }
-    }
 }
 
 // =============================================================================================
@@ -2479,7 +2556,7 @@ template <int CP> static int launch_first(IgemmP& p, hipStream_t st) {
 
 template <typename T, bool SPLIT> static int launch_head(IgemmP& p, hipStream_t st) {
     constexpr int BK = 128 / (int)sizeof(T);
-    const size_t lds = 3 * (size_t)(24 * 1024) + HEAD_MAX_C * 8;
+    const size_t lds = 3 * (size_t)(24 * 1024) + HEAD_MAX_C * 8 + 128;
     auto kern = conv_head_kernel<T, SPLIT>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -2493,7 +2570,16 @@ template <typename T, bool SPLIT> static int launch_head(IgemmP& p, hipStream_t 
     p.th = 8;
     p.tiles_pw = p.Wo / 16;
     p.tiles_pi = p.tiles_pw * (p.Ho / 8);
-    p.tiles_m = p.tiles_pi * p.N;
+    // runs of tpw consecutive tiles of one image per workgroup (the kernel's chunk stream): the longest run that still leaves every CU its
+    // two workgroups.  A tile's result does not depend on the run it is computed in, so the choice may depend on the batch.
+    int tpw = p.tpw;  // (the caller's request: the head_tpw option; 0 = choose)
+    if (tpw <= 0) {
+        tpw = 16;
+        while (tpw > 1 && (p.tiles_pi % tpw || (long long)p.tiles_pi * p.N / tpw < 512)) tpw >>= 1;
+    }
+    while (tpw > 1 && p.tiles_pi % tpw) --tpw;
+    p.tpw = tpw;
+    p.tiles_m = p.tiles_pi / tpw * p.N;  // (runs)
     if (p.tiles_m <= 0) {
         eod_set_error("conv_head: bad grid");
         return EOD_EINVAL;
@@ -2598,13 +2684,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
 //                                              whole 256 x 256 step 0.4 % SLOWER than off (same-box A/B, three interleaved runs)
 //   halo_splitk       EOD_HALO_SPLITK=0        3x3 convs on maps with fewer than two workgroups per CU unsplit in K (64-column tiles instead)
 //   first             EOD_FIRST=0              the fp32x3 first conv (tap-major weights) on the generic kernel instead of conv_first_x3_kernel
+//   head_tpw          EOD_HEAD_TPW=n           pixel tiles per workgroup of conv_head_kernel's chunk stream (0: chosen per launch = the default)
 // (Round 2's EOD_IGEMM_CFG / EOD_MFMA_SHAPE / EOD_HALO_SPLIT_N / EOD_CONV_PARITY arms were measured slower and are gone: the fp16
 // products run on v_mfma_f32_16x16x32_f16, 384-column convs as 256 + 128, zero-insertion convs as four parity-class launches.)
-enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_HALO_SPLITK, OPT_FIRST, OPT_COUNT };
-static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw", "halo_splitk", "first"};
+enum { OPT_SKIP_FUSE, OPT_HEAD, OPT_HALO_BN256, OPT_GN_FUSE_MAX_COUT, OPT_HALO_TPW, OPT_HALO_SPLITK, OPT_FIRST, OPT_HEAD_TPW, OPT_COUNT };
+static const char* const g_opt_name[OPT_COUNT] = {"skip_fuse", "head", "halo_bn256", "gn_fuse_max_cout", "halo_tpw", "halo_splitk", "first", "head_tpw"};
 static const char* const g_opt_env[OPT_COUNT] = {"EOD_SKIP_FUSE", "EOD_HEAD", "EOD_HALO_BN256", "EOD_GN_FUSE_MAX_COUT", "EOD_HALO_TPW", "EOD_HALO_SPLITK",
-                                                 "EOD_FIRST"};
-static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 1, 1, 1};
+                                                 "EOD_FIRST", "EOD_HEAD_TPW"};
+static int g_opt[OPT_COUNT] = {1, 1, 1, -1, 1, 1, 1, 0};
 static bool g_opt_init = false;
 static int opt(int k) {
     if (!g_opt_init) {
@@ -3096,6 +3183,7 @@ extern "C" int eod_conv2d_igemm(const eod_conv_desc* d, void* stream) {
     if (conv_head_ok(d, halo_ok)) {  // output head: GroupNorm + SiLU fused, <= 16 channels, NCHW fp32 (conv_head_kernel)
         p.gn_ss = d->gn_scale_shift;
         p.gn_silu = d->gn_silu;
+        p.tpw = opt(OPT_HEAD_TPW);
         return d->dtype == EOD_F16 ? launch_head<half_t, false>(p, st) : launch_head<float, true>(p, st);
     }
     // ---- halo-patch kernels (3x3 / stride 1 / pad 1 on maps that tile into 8 x 16 patches), with or without the fused skip conv ----
