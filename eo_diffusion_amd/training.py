@@ -703,6 +703,15 @@ class UNetTrainer:
             self._call(L.eod_wgrad_reduce, ptr(partial), S, ks, cout, cs_real, ldp, ci0, cin_total, self.inv_scale, ptr(dW))
             ci0 += cs_real
 
+    @staticmethod
+    def _wgrad_splits(strips, tiles):
+        """pixel-range splits of a backward-weights launch: tiles x S workgroups must FIT the chip's 512 co-resident workgroups (2 per
+        CU).  Rounding S up put 513 workgroups on 512 slots for the 128 -> 128 convs (3 row taps x 171 splits): the one left over ran
+        alone after all the others, a second full round (EOD_WGRAD_ROUND=up restores that for A/B)"""
+        want = int(os.environ.get("EOD_WGRAD_WGS", "512"))
+        s = (want + tiles - 1) // tiles if os.environ.get("EOD_WGRAD_ROUND", "down") == "up" else want // tiles
+        return max(1, min(strips, s))
+
     def _wgrad_direct(self, rec, dy, cout):
         """3x3 / stride-1 and 1x1 backward-weights straight from the NHWC tensors: conv3x3_wgrad_kernel / gemm_tn_kernel
         (pixel-major staging + transposed LDS reads), split over pixel ranges into fp32 partial tiles"""
@@ -725,7 +734,7 @@ class UNetTrainer:
                 # with X at its stored resolution -- 4/9 of the MACs of the nine taps over the 2H x 2W gradient -- folded back into dW
                 tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * 8
                 strips4 = xs.N * (xs.H * xs.W // 64)
-                S = max(1, min(strips4, (int(os.environ.get("EOD_WGRAD_WGS", "512")) + tiles - 1) // tiles))
+                S = self._wgrad_splits(strips4, tiles)
                 partial = bp.empty((S * 16 * cout * ldp,), torch.float32)
                 t16 = bp.empty((cout * cin_total * 16,), torch.float32)
                 self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout, 2, ptr(partial), ldp, S)
@@ -734,7 +743,7 @@ class UNetTrainer:
                 ci0 += cs_real
                 continue
             tiles = ((cout + 127) // 128) * ((cs + 127) // 128) * (6 if rec.stride == 2 else ks)
-            S = max(1, min(strips, (int(os.environ.get("EOD_WGRAD_WGS", "512")) + tiles - 1) // tiles))
+            S = self._wgrad_splits(strips, tiles)
             partial = bp.empty((S * ks * ks * cout * ldp,), torch.float32)
             if ks == 3:  # (ups 3 = stride-2 conv: X gathered at pixel stride 2)
                 self._call(L.eod_conv3x3_wgrad, ptr(dy.t), ptr(xs.t), dt, dy.N, xs.H, xs.W, cs, dy.H, dy.W, dy.C, cout,
