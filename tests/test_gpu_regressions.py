@@ -76,8 +76,8 @@ def test_trainer_notices_repointed_parameters():
     fresh.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
     fresh = fresh.to(DEV).train()
     loss_ref = torch.nn.functional.mse_loss(fresh(x, t), noise)
-    assert float(loss1) == float(loss_ref), (float(loss1), float(loss_ref))
-    assert float(loss1) != float(loss0)
+    assert float(loss1.detach()) == float(loss_ref.detach()), (float(loss1.detach()), float(loss_ref.detach()))
+    assert float(loss1.detach()) != float(loss0)
 
 
 def test_unused_head_parameters_are_left_alone():
