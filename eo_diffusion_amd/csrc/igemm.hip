@@ -1178,8 +1178,14 @@ __device__ __forceinline__ void prefetch_bcol(const IgemmP& p, int ncols, int co
     }
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false, bool STREAM = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false, bool STREAM = false,
+          bool KSPLIT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void conv3x3_halo_kernel(const IgemmP p) {
+    // KSPLIT: the K slices of a split conv (p.splitk workgroups per tile, gridDim.y) are instances of their own.  As a run-time mode of
+    // every instance (round 4's first form) the chunk loop's bounds, the second epilogue of the fp16 kernels and the workspace pointer cost
+    // the UNSPLIT launches 2-6 % (fp16, 128 -> 128 at 256 x 256: 0.399 -> 0.419 ms, same box) -- found by bisecting the libraries of the
+    // round's commits on one box.
+    static_assert(!KSPLIT || (!STREAM && !UPS && BN == 128), "K slices: the 128-column 4-wave instances");
     static_assert(!SKIP || (MS == 16 && !UPS && WAVES_M == 2), "fused skip conv: 16x16x32 instances of the 8x16 tile");
     static_assert(!SPLIT || (sizeof(T) == 4 && MS == 16), "the split-fp16 product is a mode of fp32 storage, on 16x16x32 MFMAs");
     static_assert(MS == 32 || SPLIT || sizeof(T) == 2, "the 16x16x32 shape exists for the fp16 products only");
@@ -1476,7 +1482,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     // split-K (maps with too few pixel tiles to fill the chip): gridDim.y workgroups share a tile, each takes a run of channel chunks (all
     // nine taps of a chunk stay together) and writes a raw fp32 partial tile; the fused skip phase rides in the last one
     int kc_begin = 0, kc_end = KC;
-    if (p.splitk > 1) {
+    if constexpr (KSPLIT) {
         kc_begin = (int)blockIdx.y * p.splitk_per;
         kc_end = (int)blockIdx.y == p.splitk - 1 ? KC : kc_begin + p.splitk_per;
     }
@@ -1667,7 +1673,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
         qpar ^= 1;
     }
     if constexpr (SKIP) {
-      if (p.splitk <= 1 || (int)blockIdx.y == p.splitk - 1) {
+      if (!KSPLIT || (int)blockIdx.y == p.splitk - 1) {
         // ---- 1x1 skip conv over the block input: GEMM-layout ring in the same LDS, K-step = 32 / 64 channels of one source ----
         constexpr int LA = BM / 8 / NW;                    // 8-row pieces of the pixel tile per wave (4)
         constexpr int STG_A = BM * BKB, STG = STG_A + BSTAGE;
@@ -1795,14 +1801,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
     }
     EOD_STAMP_AT(2);
     IgemmP pe = p;
-    if (p.splitk > 1) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;  // raw fp32 partial tile of this K slice (the launcher cleared bias / residual / statistics)
+    if constexpr (KSPLIT) pe.y = p.y + (long long)blockIdx.y * p.M * p.Cout * 4;  // raw fp32 partial tile of this K slice (the launcher cleared bias / residual / statistics)
     if constexpr (SPLIT) {
         pe.alpha = p.alpha * wsc1 * asc.inv;  // undo the weight and activation scales (exact powers of two)
         if constexpr (DIRECT) halo_epilogue_direct<BM, BN, WAVES_M, WAVES_N>(pe, g, acc, wave, lane, n0, pre_bq, pe.alpha, pre_we);
         else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
-    } else if constexpr (sizeof(T) == 2 && !STREAM) {
-        if (p.splitk > 1) igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, true, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
-        else igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, false, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
+    } else if constexpr (sizeof(T) == 2) {
+        igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, KSPLIT, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);  // (K slices: fp32 partial tiles)
     } else {
         igemm_epilogue<T, true, BM, BN, WAVES_M, WAVES_N, sizeof(T) == 4, MS>(pe, g, acc, smem, wave, lane, n0, nullptr, 0, pre_bcol);
     }
@@ -2778,8 +2783,18 @@ static int launch_cfg(IgemmP& p, int batch, hipStream_t st) {
     return EOD_OK;
 }
 
-template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false, bool STREAM = false>
+template <typename T, int BN, int WAVES_M, int WAVES_N, bool UPS, int BSTAGES, bool GN, bool SPLIT = false, int MS = 32, bool SKIP = false, bool STREAM = false,
+          bool KSPLIT = false>
 static int launch_halo(IgemmP& p, hipStream_t st) {
+    if constexpr (!KSPLIT && !STREAM && !UPS && BN == 128 && WAVES_N == 2) {
+        if (p.splitk > 1) return launch_halo<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP, false, true>(p, st);  // the K-slice instance
+    }
+    if constexpr (!KSPLIT) {
+        if (p.splitk > 1) {
+            eod_set_error("conv_halo: K slices exist for the 128-column 4-wave instances only");
+            return EOD_EINVAL;
+        }
+    }
     constexpr int BK = 128 / (int)sizeof(T);
     constexpr int NW = WAVES_M * WAVES_N, BM = WAVES_N == 4 ? 64 * WAVES_M : 32 * NW, TH = BM / 16;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -2787,7 +2802,7 @@ static int launch_halo(IgemmP& p, hipStream_t st) {
     const size_t ring = 2 * (size_t)(PG * 1024) + BSTAGES * (size_t)BN * 128 + (GN ? 2048 : 0);
     const size_t epi = NW * (size_t)WM * (WN + 4) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP, STREAM>;
+    auto kern = conv3x3_halo_kernel<T, BN, WAVES_M, WAVES_N, UPS, BSTAGES, GN, SPLIT, MS, SKIP, STREAM, KSPLIT>;
     if constexpr (SKIP) {
         p.skc0 = (p.SC0 + BK - 1) / BK;
         p.skc1 = (p.SC1 + BK - 1) / BK;
