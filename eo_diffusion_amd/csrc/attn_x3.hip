@@ -56,17 +56,6 @@ __device__ __forceinline__ half8 ax_tr_frag(const char* tile, int rb, int j0, in
     return f;
 }
 
-// two values -> packed {hi0, hi1}, {lo0, lo1} in FOUR instructions: v_fma_mixlo / mixhi_f16 compute x * 1 + c in fp32 and write one fp16
-// half of the destination (c = 0: the high part; c = -hi taken as an fp16 operand: x - hi, exact in fp32, rounded once) -- the same bits
-// as ax_split below, which costs four instructions per VALUE as hipcc emits it (cvt, cvt back, subtract, cvt; packs on top)
-__device__ __forceinline__ void ax_split2(float x0, float x1, int& h, int& l) {
-    asm("v_fma_mixlo_f16 %0, %2, 1.0, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, 1.0, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(h), "=&v"(l)
-        : "v"(x0), "v"(x1));
-}
 __device__ __forceinline__ void ax_split(float x, half_t& hi, half_t& lo) {
     hi = (half_t)x;
     lo = (half_t)(x - (float)hi);
@@ -272,11 +261,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_x3_kernel(const AttnX3P p
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                int phi[4], pli[4];
+                half8 ph, pl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ax_split2(s[mt][8 * kb + 2 * e], s[mt][8 * kb + 2 * e + 1], phi[e], pli[e]);
-                const half8 ph = __builtin_bit_cast(half8, i32x4{phi[0], phi[1], phi[2], phi[3]});
-                const half8 pl = __builtin_bit_cast(half8, i32x4{pli[0], pli[1], pli[2], pli[3]});
+                for (int e = 0; e < 8; ++e) {
+                    half_t hi, lo;
+                    ax_split(s[mt][8 * kb + e], hi, lo);
+                    ph[e] = hi; pl[e] = lo;
+                }
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
                     const half8 vh = ax_tr_frag(sVh, mt * 32 + 16 * kb, t * 32, lane), vl = ax_tr_frag(sVl, mt * 32 + 16 * kb, t * 32, lane);
