@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wide_kernel(const AttnWideP p
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) xw[r4 * 64] = f32x4{s[4 * r4], s[4 * r4 + 1], s[4 * r4 + 2], s[4 * r4 + 3]};
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): my partial is in LDS
-            __builtin_amdgcn_s_barrier();        // (the other buffer was last read before the previous tile's barrier... of the tile before)
+            __builtin_amdgcn_s_barrier();        // every partial of this tile is in LDS.  (Two buffers: a wave that writes tile kt + 1's partial
+                                                 //  has passed THIS barrier, i.e. every wave has finished reading tile kt - 1's buffer, the one it reuses)
             const f32x4* xr = sX + (kt & 1) * 16 * 64 + lane;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
