@@ -47,7 +47,7 @@ __device__ __forceinline__ half8 aw_tr_frag(const char* tile, int rb, int j0, in
     return f;
 }
 
-// (s x0, s x1) -> packed {hi0, hi1}, {lo0, lo1}: hi = fp16(s x), lo = fp16(s x - hi), four v_fma_mix instructions (see attn_x3.hip)
+// (s x0, s x1) -> packed {hi0, hi1}, {lo0, lo1}: hi = fp16(s x), lo = fp16(s x - hi), four v_fma_mix instructions (see split4_scaled in igemm.hip)
 __device__ __forceinline__ void aw_split2(float x0, float x1, float s, int& h, int& l) {
     asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
         "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
