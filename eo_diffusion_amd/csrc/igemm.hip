@@ -2521,7 +2521,6 @@ __global__ __launch_bounds__(256, 3) void conv_first_x3_kernel(const IgemmP p) {
                 xh = *reinterpret_cast<const i32x4*>(sP + a);
                 xl = *reinterpret_cast<const i32x4*>(sP + a + 16);
             } else {
-                typedef int i32x2 __attribute__((ext_vector_type(2)));
                 const int a0 = 2 * gq < 9 ? tap_addr(2 * gq) + i * PW * PB : ZOFF;
                 const int a1 = 2 * gq + 1 < 9 ? tap_addr(2 * gq + 1) + i * PW * PB : ZOFF;
                 const i32x4 p0 = *reinterpret_cast<const i32x4*>(sP + a0), p1 = *reinterpret_cast<const i32x4*>(sP + a1);
