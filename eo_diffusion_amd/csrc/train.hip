@@ -1400,24 +1400,35 @@ extern "C" int eod_wgrad_up4_map(const float* t16, int Cout, int Cin, float* dw_
 // produces per-(image, slab, channel) sums  part[n][p][c][0];  this reduces them:
 //   dbias[c] = scale * sum_{n,p} part[n][p][c][0],   demb[n][c] = sum_p part[n][p][c][0]   (fixed order)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void channel_sums_finish_kernel(const float* __restrict__ part, int N, int P, int C, int cvalid, float scale,
-                                                                  float* __restrict__ pern, float* __restrict__ demb, long long demb_ld) {
-    // grid (64-channel blocks, N): one image per block row.  512 threads = 64 channels x 8 slab segments: every thread sums its
-    // contiguous share of the P slabs, the 8 partial sums of a channel are then combined in a FIXED order (deterministic);
-    // per-image totals go to pern[n][c] (scaled) for the bias gradient
-    __shared__ float seg[8][64];
+__global__ __launch_bounds__(1024) void channel_sums_finish_kernel(const float* __restrict__ part, int N, int P, int C, int cvalid, float scale,
+                                                                   float* __restrict__ pern, float* __restrict__ demb, long long demb_ld) {
+    // grid (64-channel blocks, N): one image per block row.  1024 threads = 64 channels x 16 slab segments: every thread sums its
+    // contiguous share of the P slabs with FOUR loads in flight (four accumulators, combined in a fixed order), the 16 partial sums of
+    // a channel are then combined in a FIXED order (deterministic); per-image totals go to pern[n][c] (scaled) for the bias gradient.
+    // (A batch of 2 at 512 x 512 hands over 2048 slabs per image to FOUR workgroups: with 8 segments and one load in flight at a time this
+    //  launch took 40-100 us, 5 % of that training step.)
+    constexpr int SEG = 16;
+    __shared__ float seg[SEG][64];
     const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
-    const int per = (P + 7) / 8, p0 = sg * per, p1 = min(P, p0 + per);
-    float a = 0.0f;
-    if (c < cvalid)
-        for (int p = p0; p < p1; ++p) a += part[(((long long)n * P + p) * C + c) * 2];
-    seg[sg][cl] = a;
+    const int per = (P + SEG - 1) / SEG, p0 = sg * per, p1 = min(P, p0 + per);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (c < cvalid) {
+        const float* base = part + ((long long)n * P * C + c) * 2;
+        const long long st = (long long)C * 2;
+        int p = p0;
+        for (; p + 3 < p1; p += 4) {
+            const float v0 = base[(long long)p * st], v1 = base[(long long)(p + 1) * st], v2 = base[(long long)(p + 2) * st], v3 = base[(long long)(p + 3) * st];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; p < p1; ++p) a0 += base[(long long)p * st];
+    }
+    seg[sg][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (sg == 0 && c < cvalid) {
         float t = seg[0][cl];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += seg[k][cl];
+        for (int k = 1; k < SEG; ++k) t += seg[k][cl];
         if (demb) demb[(long long)n * demb_ld + c] = t;
         if (pern) pern[(long long)n * cvalid + c] = t * scale;
     }
@@ -1427,7 +1438,7 @@ extern "C" int eod_channel_sums_finish(const float* part, int N, int P, int C, i
                                        int64_t demb_ld, float* scratch, void* stream) {
     EOD_REQUIRE(part && N > 0 && P > 0 && C > 0 && cvalid > 0 && cvalid <= C && (dbias || demb) && N <= 65535, "channel_sums_finish: bad args");
     EOD_REQUIRE(!dbias || scratch, "channel_sums_finish: the bias gradient needs a scratch of N*cvalid floats");
-    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((cvalid + 63) / 64, N), dim3(512), 0, (hipStream_t)stream, part, N, P, C, cvalid, scale,
+    hipLaunchKernelGGL(channel_sums_finish_kernel, dim3((cvalid + 63) / 64, N), dim3(1024), 0, (hipStream_t)stream, part, N, P, C, cvalid, scale,
                        dbias ? scratch : nullptr, demb, (long long)demb_ld);
     if (dbias) hipLaunchKernelGGL(colsum_kernel, dim3((cvalid + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, N, cvalid, dbias);
     EOD_CHECK_LAUNCH("channel_sums_finish");
