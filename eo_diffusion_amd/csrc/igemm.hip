@@ -2105,6 +2105,7 @@ __global__ __launch_bounds__(256, 2) void conv_up4_halo_kernel(const IgemmP p) {
     TileGeom ge = g;
     if constexpr (!BWD) {
         pe.par = 1; pe.par_y = par_y; pe.par_x = par_x;
+        pe.Wd = p.W;  // decode_row masks the tile columns behind an 8-wide STORED map (before the parity scaling)
         pe.tiles_per_image = p.tiles_pi * 4;  // statistics slots: (tile of the stored map, class)
         ge.tile_m = g.n_first * pe.tiles_per_image + (tile_m - g.n_first * p.tiles_pi) * 4 + cls;
     }
@@ -2131,7 +2132,7 @@ template <typename T, bool SPLIT, bool BWD = false> static int launch_up4(IgemmP
     p.tiles_n = (BWD ? 1 : 4) * ((p.Cout + 127) / 128);  // forward: (class, column tile)
     p.tw_log2 = 4;                            // 8 x 16 tiles of the STORED map
     p.th = 8;
-    p.tiles_pw = p.W / 16;
+    p.tiles_pw = (p.W + 15) / 16;
     p.tiles_pi = p.tiles_pw * (p.H / 8);
     p.tiles_m = p.tiles_pi * p.N;
     const long long nblk = (long long)p.tiles_m * p.tiles_n;
@@ -2912,8 +2913,8 @@ static bool conv_parity_ok(const eod_conv_desc* d, int Ho, int Wo) {
 static bool conv_up4_ok(const eod_conv_desc* d) {
     const bool store_ok = d->dtype == EOD_F16 || (d->dtype == EOD_F32 && d->w_split);
     return d->upsample == 3 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->pad_tl && d->C1 == 0 && !d->x2 && d->Cout > 64 &&
-           d->Cout % 8 == 0 && d->C0 % 8 == 0 && d->W % 16 == 0 && d->H % 8 == 0 && !d->out_nchw_f32 && !d->w_tapmajor && !d->gn_scale_shift &&
-           store_ok;
+           d->Cout % 8 == 0 && d->C0 % 8 == 0 && (d->W % 16 == 0 || d->W == 8) && d->H % 8 == 0 && !d->out_nchw_f32 && !d->w_tapmajor &&
+           !d->gn_scale_shift && store_ok;  // (8-wide stored maps: the right half of the 8 x 16 tile masked, like conv3x3_halo_kernel's)
 }
 extern "C" int eod_conv_up4_ok(const eod_conv_desc* d) { return d && conv_up4_ok(d) ? 1 : 0; }
 // upsample = 4: backward-data of the parity-class upsample conv (conv_up4_halo_kernel<BWD>): x = dY [N][H][W][C0] on the (2H' x 2W') grid,
@@ -3076,6 +3077,7 @@ extern "C" int eod_conv_stats_slots(const eod_conv_desc* d) {
     const int Heff = d->H * (d->upsample ? 2 : 1), Weff = d->W * (d->upsample ? 2 : 1);
     const int Ho = (Heff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
     const int Wo = (Weff + d->pad_tl + 2 * d->pad - d->ksize) / d->stride + 1;
+    if (d->upsample == 3) return (d->H / 8) * ((d->W + 15) / 16) * 8;  // parity-class form: (8 x 16 tile of the STORED map, class, wave row)
     const bool halo = conv_uses_halo(d, Ho, Wo);
     if (conv_splitk(d, Ho, Wo, halo) > 1) return 1;  // split-K: the reduce pass takes the sums, one slot per image
     if (halo) return (Ho / 8) * ((Wo + 15) / 16) * 2;  // 8 x 16 pixel tiles (8-wide maps: half of each tile masked), two wave rows each
