@@ -517,15 +517,26 @@ def test_first_conv_tapmajor(prec, dims):
     w = synth_input(f"tw{dims}", (Cout, Cin, 3, 3), 41, scale=1.0 / math.sqrt(Cin * 9))
     b = synth_input(f"tb{dims}", (Cout,), 41, scale=0.1)
 
-    def emit(prog, a):
-        if (a.C // prog.epc) not in (1, 2, 4):
-            pytest.skip("channel padding outside the tap-major range for this precision")
-        y, _ = prog.conv(a, prog.pack_conv_tapmajor(w.to(DEV), a.C), prog.f32(b.to(DEV)), Cout, w_tapmajor=True, stats=True)
-        return y
+    gam = 1.0 + 0.2 * synth_input("tg", (Cout,), 41)
+    bet = 0.1 * synth_input("te", (Cout,), 41)
+    for gn in (False, True):  # gn: a GroupNorm behind the conv consumes the partial sums of its epilogue (the slots of whichever kernel ran)
+        applied = []
 
-    got = run_program(prec, x, emit)
-    ref = F.conv2d(x, w, b, padding=1)
-    assert rel_l2(got, ref) < TOL[prec]
+        def emit(prog, a):
+            if (a.C // prog.epc) not in (1, 2, 4):
+                pytest.skip("channel padding outside the tap-major range for this precision")
+            y, _ = prog.conv(a, prog.pack_conv_tapmajor(w.to(DEV), a.C), prog.f32(b.to(DEV)), Cout, w_tapmajor=True, stats=True)
+            if gn and Cout % 32 == 0:
+                applied.append(True)
+                return prog.group_norm([y], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV)), silu=False)
+            return y
+
+        got = run_program(prec, x, emit)
+        ref = F.conv2d(x, w, b, padding=1)
+        if applied:
+            assert rel_l2(got, F.group_norm(ref, 32, gam, bet, eps=1e-5)) < (2e-5 if prec != "fp16" else 3e-3)
+        else:
+            assert rel_l2(got, ref) < TOL[prec]
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16", "fp32x3"])
@@ -556,6 +567,47 @@ def test_head_conv_nchw_f32(prec, dims, fused_gn):
     hin = F.silu(F.group_norm(x, 32, gam, bet, eps=1e-5)) if fused_gn else x
     ref = F.conv2d(hin, w, b, padding=1)
     assert rel_l2(out.cpu(), ref) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["fp16", "fp32x3"])
+@pytest.mark.parametrize("dims,tpws", [((2, 128, 40, 48, 3), (3, 5, 15)), ((1, 96, 32, 64, 3), (2, 4, 16)), ((3, 160, 8, 32, 16), (2,))])
+def test_head_conv_tile_streams_are_bit_identical_to_single_tiles(prec, dims, tpws):
+    """conv_head_kernel's chunk stream (head_tpw: a workgroup walks a run of consecutive tiles of one image through one chunk ring; the
+    default picks runs only on maps with >= 512 tiles): every run length that divides the tiles of an image gives the bits of the
+    one-tile-per-workgroup form -- several tiles per run, runs that end at an image end, channel tails, three images"""
+    from eo_diffusion_amd import _lib
+    from eo_diffusion_amd.engine import Act
+    L = _lib.lib()
+    N, C, H, W, Cout = dims
+    x = synth_input(f"hsx{dims}", (N, C, H, W), 47, scale=1.5) + 0.2
+    gam = 1.0 + 0.2 * synth_input("hsg", (C,), 47)
+    bet = 0.1 * synth_input("hsb", (C,), 47)
+    w = synth_input(f"hsw{dims}", (Cout, C, 3, 3), 47, scale=0.05)
+    b = synth_input(f"hsbias{dims}", (Cout,), 47, scale=0.1)
+
+    def run(tpw):
+        prev = L.eod_set_option(b"head_tpw", tpw)
+        try:
+            prog = Program(DEV, prec)
+            a = prog.act(N, H, W, C)
+            a.t.copy_(x.permute(0, 2, 3, 1).to(DEV).to(a.t.dtype))
+            out = torch.full((N, Cout, H, W), 7.0, dtype=torch.float32, device=DEV)
+            gn = (prog.gn_stats([a], prog.f32(gam.to(DEV)), prog.f32(bet.to(DEV))), True)
+            _, idx = prog.conv(a, prog.pack_conv(w.to(DEV)), prog.f32(b.to(DEV)), Cout, out_nchw_f32=True, gn=gn)
+            assert prog.op_stats()[-1]["kernel"] == "conv_head_kernel"
+            prog.ops[idx].u.conv.y = out.data_ptr()
+            prog.run()
+            torch.cuda.synchronize()
+            return out.cpu()
+        finally:
+            L.eod_set_option(b"head_tpw", prev)
+
+    one = run(1)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gam, bet, eps=1e-5)), w, b, padding=1)
+    assert rel_l2(one, ref) < TOL[prec]
+    for tpw in tpws:
+        assert (H // 8) * (W // 16) % tpw == 0, "the test wants run lengths that divide the tiles of an image"
+        assert torch.equal(run(tpw), one), tpw
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16"])
