@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_N == 4 ? 1 : 2) void 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = (float)h[e] * pre.q[e >> 1][(e & 1) * 2] + pre.q[e >> 1][(e & 1) * 2 + 1];
-                    if (p.gn_silu) v = silu_f<true>(v);
+                    v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(v, silu_k, silu_c)));  // (select-free SiLU, see below)
                     o[e] = (half_t)v;
                 }
                 outv = __builtin_bit_cast(i32x4, o);
@@ -2280,7 +2280,7 @@ __global__ __launch_bounds__(256, 2) void conv_head_kernel(const IgemmP p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float v = (float)h[e] * q[e >> 1][(e & 1) * 2] + q[e >> 1][(e & 1) * 2 + 1];
-                    if (p.gn_silu) v = silu_f<true>(v);
+                    v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(v, silu_k, silu_c)));  // (select-free SiLU)
                     o[e] = (half_t)v;
                 }
                 if (ok) *reinterpret_cast<i32x4*>(ptr) = __builtin_bit_cast(i32x4, o);
